@@ -1,0 +1,200 @@
+/* pdegpu.h — C-ABI of libpdegpu.so: the MI355X (gfx950) structured-grid FEM solve path that replaces
+ * DOLFIN's assemble()+solve() behind the reference's box heat / static elasticity tools.
+ *
+ * Every entry point below is what a foreign-function binding of the reference's solve path binds.
+ * The reference interface each one replaces is cited as file:line into the reference repository
+ * (fenics_mcp_server.py unless stated otherwise).
+ *
+ * Conventions: plain C types only; returns 0 on success, a negative PDEGPU_E* code on failure (never
+ * throws, never writes to stdout — stdout is the reference server's JSON-RPC channel, :222-225);
+ * pdegpu_last_error() returns the message of the last failure on that context; the caller owns every
+ * output buffer (host memory, C-contiguous fp64); the library owns all device memory inside the
+ * context.  One context = one GPU = one process rank (one process per GPU).
+ */
+#ifndef PDEGPU_H
+#define PDEGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDEGPU_OK            0
+#define PDEGPU_EINVAL       (-1)   /* bad argument (shape, enum, null pointer) */
+#define PDEGPU_EHIP         (-2)   /* a HIP runtime call failed */
+#define PDEGPU_ENOCONV      (-3)   /* CG hit max_iter before reaching rtol */
+#define PDEGPU_ENODEV       (-4)   /* no usable gfx950 device */
+#define PDEGPU_EUNSUPPORTED (-5)   /* valid request outside the accelerated path */
+
+/* element_mode: which constant macro-element matrix is integrated on the device.
+ * P1SPLIT = the reference's discretisation, FunctionSpace(mesh,"P",1) on IntervalMesh/RectangleMesh/
+ * BoxMesh (:229-230, :369-370, :533-535): each grid cell split into 1 interval / 2 triangles / 6 Kuhn
+ * tetrahedra.  Q1 = multilinear element on the same nodes (BASELINE.json wording; differs by O(h^2)). */
+#define PDEGPU_ELEM_P1SPLIT 0
+#define PDEGPU_ELEM_Q1      1
+
+/* initial condition (:276-292, :408-423, :672-687) */
+#define PDEGPU_IC_CONSTANT 0
+#define PDEGPU_IC_ZERO     1
+#define PDEGPU_IC_NODAL    2       /* caller supplies nodal values u0[N] (used for the projected sine/cosine IC) */
+
+/* Dirichlet set selection for heat */
+#define PDEGPU_BC_UNIFORM     0    /* every boundary node = bc_value[0]            (:373-376, :626-628) */
+#define PDEGPU_BC_DIRECTIONAL 1    /* x==0 -> bc_value[0], x==Lx -> bc_value[1], other boundary nodes
+                                      with 0<x<Lx -> bc_value[2]; bc_present[i]==0 leaves that part
+                                      natural (:233-241 for 1-D, :606-623 for the 3-D box) */
+
+#define PDEGPU_QUANTITY_STRESS 0
+#define PDEGPU_QUANTITY_STRAIN 1
+
+typedef struct pdegpu_ctx pdegpu_ctx;
+
+/* structured grid = the reference's IntervalMesh/RectangleMesh/BoxMesh arguments (:229, :369, :533,
+ * :1516, :1648, :1803): dim, cells per axis, box lengths.  Unused axes: n=0, L=0. */
+typedef struct pdegpu_grid {
+    int32_t dim;            /* 1, 2 or 3 */
+    int32_t n[3];           /* cells per axis (nx, ny, nz) */
+    double  L[3];           /* Lx, Ly, Lz */
+    int32_t element_mode;   /* PDEGPU_ELEM_* */
+    int32_t reserved;
+} pdegpu_grid;
+
+/* arguments of _solve_heat_{1,2,3}d_raw (:204-219, :345-361, :475-500), box branch */
+typedef struct pdegpu_heat {
+    double  kappa;              /* diffusivity */
+    double  dt;
+    int32_t num_steps;
+    int32_t steady;             /* 1: one steady solve, times=[0] (:259-269) */
+    double  source;             /* constant f (0 when source_type == "none") */
+    int32_t ic_type;            /* PDEGPU_IC_* */
+    int32_t bc_mode;            /* PDEGPU_BC_* */
+    double  ic_value;           /* T_initial */
+    double  bc_value[3];
+    int32_t bc_present[3];
+    int32_t snapshot_stride;    /* store every stride-th state (state 0 and the last one always); 1 = all,
+                                   as the reference does (:694-696, :711-713) */
+    double  rtol;               /* CG: stop when ||r|| <= rtol * ||b - A g|| */
+    int32_t max_iter;           /* per linear solve */
+    int32_t fast_path;          /* 1 (default): use the fused z-marching kernels when the problem
+                                   qualifies; 0: force the general class-table kernels */
+} pdegpu_heat;
+
+/* arguments of _solve_elasticity_{1,2,3}d_static (:1470-1477, :1593-1604, :1749-1762) */
+typedef struct pdegpu_elasticity {
+    double  E, nu;
+    double  area;               /* 1-D bar only (:1474) */
+    double  body[3];            /* body force; 1-D uses body[0] */
+    int32_t plane_stress;       /* 2-D only (:1603, :1658-1665) */
+    int32_t quantity;           /* PDEGPU_QUANTITY_* */
+    double  rtol;
+    int32_t max_iter;
+    int32_t reserved;
+} pdegpu_elasticity;
+
+typedef struct pdegpu_stats {
+    int64_t n_nodes;            /* grid nodes */
+    int64_t n_unknowns;         /* free scalar unknowns of the main linear system */
+    int64_t cg_iterations;      /* total over all linear solves of the call */
+    int32_t linear_solves;
+    int32_t converged;          /* 1 if every solve reached rtol */
+    double  final_rel_residual; /* of the last solve */
+    double  solve_ms;           /* device time of the whole call (hipEvent) */
+    double  cg_ms;              /* device time inside CG iterations */
+    double  kernel_ms[4];       /* summed hipEvent time: [0] operator apply (SpMV, fused or not),
+                                   [1] vector update(s), [2] right-hand-side/other, [3] transfers */
+    int64_t kernel_launches[4];
+    double  alg_bytes[4];       /* algorithmic HBM bytes of the launches counted in kernel_ms */
+    int32_t path;               /* 0 general class-table kernels, 1 fused z-marching kernels */
+    int32_t reserved;
+} pdegpu_stats;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+/* One context per GPU.  device_id is the HIP ordinal; stream is a hipStream_t passed as void* (NULL =
+ * the library creates its own non-blocking stream). */
+int         pdegpu_create(pdegpu_ctx** out, int device_id, void* stream);
+void        pdegpu_destroy(pdegpu_ctx* ctx);
+const char* pdegpu_last_error(const pdegpu_ctx* ctx);
+int         pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen);
+const char* pdegpu_version(void);
+
+/* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw
+ *      (:229-318, :369-447, :533-716).  Node order of every array: x fastest, then y, then z
+ *      (N = (nx+1)(ny+1)(nz+1)); the reference exposes its dof order only through coordinates.
+ *      values_out [n_snap][N], times_out [n_snap], n_snap = pdegpu_heat_num_snapshots(...);
+ *      u0 = nodal initial values [N] when ic_type == PDEGPU_IC_NODAL, else NULL. */
+int pdegpu_heat_num_snapshots(const pdegpu_heat* h);
+int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat,
+                      const double* u0, double* values_out, double* times_out, pdegpu_stats* stats);
+
+/* ---- project(f, V) with a consistent mass matrix (:284, :415, :679, :1542, :1714, :1862):
+ *      solves M s = rhs on the device, rhs[N] is the assembled load vector int f phi_i. */
+int pdegpu_mass_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const double* rhs, double* s_out,
+                      double rtol, int max_iter, pdegpu_stats* stats);
+
+/* ---- operator access for tests and the roofline harness -------------------------------------- */
+/* y = (cM*M + cK*K) x on the full grid, no Dirichlet elimination; x, y: host [N].  Also returns the
+ * load vector m_i = int phi_i in load_out when non-NULL. */
+int pdegpu_heat_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, double cM, double cK,
+                      const double* x, double* y, double* load_out, int fast_path);
+
+/* class tables integrated on the device: tabK/tabM [27 classes][27 offsets], load [27] */
+int pdegpu_heat_tables(pdegpu_ctx* ctx, const pdegpu_grid* grid, double* tabK, double* tabM, double* load);
+/* host twin of the same integration (same source, compiled for the CPU): lets the CPU-only test-suite
+ * check the macro-element math against the oracle's assembled matrices without a GPU */
+int pdegpu_heat_tables_host(const pdegpu_grid* grid, double* tabK, double* tabM, double* load);
+
+/* ---- elasticity: replaces _solve_elasticity_{1,2,3}d_static's VectorFunctionSpace assembly, clamp at
+ *      x = 0, solve, per-cell von Mises and project() (:1516-1564, :1648-1718, :1803-1866).
+ *      field_out [N] = projected von Mises stress|strain (1-D: axial stress|strain);
+ *      disp_out  [N][dim] nullable. */
+int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el,
+                            double* field_out, double* disp_out, pdegpu_stats* stats);
+int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el,
+                            const double* u, double* y, int use_mfma);
+
+/* ---- slab-resident CG session: the unit the benchmark and the multi-GPU driver step -------------
+ * A session owns the device vectors of ONE slab of a 3-D (or 2-D) heat system
+ *      A = cM*M + cK*K  with the Dirichlet set of `heat`,
+ * for global node planes [k0, k0+nk) of the slowest axis (z in 3-D, y in 2-D), plus one ghost plane on
+ * each side.  Single GPU: k0 = 0, nk = n_slowest+1.  The multi-GPU host loop (one process per GPU)
+ * interleaves these calls with its RCCL halo exchange / all-reduce; every call only enqueues work on
+ * the context stream (no host synchronisation) unless stated.  */
+typedef struct pdegpu_session pdegpu_session;
+
+int  pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat,
+                           int64_t k0, int64_t nk, pdegpu_session** out);
+void pdegpu_session_destroy(pdegpu_session* s);
+/* set x to the Dirichlet values on constrained nodes and `fill` elsewhere; b = M*(fill_rhs) i.e. the
+ * right-hand side of a constant load (steady: b = source*m) is prepared by session_begin. */
+int  pdegpu_session_begin(pdegpu_session* s, double x_fill);
+/* device pointers / geometry the host needs for halo exchange: plane `which` of vector `vec`
+ * (0:x 1:r 2:p(current) 3:q), which = -1 lower ghost, 0 first owned, nk-1 last owned, nk upper ghost.
+ * plane_doubles = number of fp64 in one contiguous plane. */
+void*   pdegpu_session_plane_ptr(pdegpu_session* s, int vec, int64_t which);
+int64_t pdegpu_session_plane_doubles(const pdegpu_session* s);
+/* pointer to the 4 device scalars {pq_local, rr_local, pq_global, rr_global}.  After
+ * pdegpu_session_reduce_local the *_local entries hold this slab's partial dot products; the host
+ * all-reduces them into *_global (single GPU: pdegpu_session_reduce_local copies local->global). */
+double* pdegpu_session_scalars(pdegpu_session* s);
+int  pdegpu_session_residual(pdegpu_session* s);            /* r = P(b - A x), rr_local */
+int  pdegpu_session_k1(pdegpu_session* s);                  /* x+=a*p; p=r+beta*p; q=A p; pq_local */
+int  pdegpu_session_k2(pdegpu_session* s);                  /* r-=alpha*q; rr_local */
+int  pdegpu_session_reduce_local(pdegpu_session* s, int which /*0 pq, 1 rr*/, int copy_to_global);
+int  pdegpu_session_flush(pdegpu_session* s);               /* pending x += alpha*p */
+/* run `iters` full CG iterations on a single slab without the host in the loop (k1,k2 back to back).
+ * If time_kernels != 0, brackets every launch with hipEvents and accumulates stats->kernel_ms. */
+int  pdegpu_session_iterate(pdegpu_session* s, int iters, int time_kernels, pdegpu_stats* stats);
+int  pdegpu_session_rr(pdegpu_session* s, double* rr_out);  /* synchronises; global r.r */
+int  pdegpu_session_get_x(pdegpu_session* s, double* x_out /* host [nk][plane nodes] */);
+int  pdegpu_session_sync(pdegpu_session* s);
+
+/* ---- CPU-visible helpers that need no GPU (used by `-m "not gpu"` tests) ---------------------- */
+int64_t pdegpu_grid_num_nodes(const pdegpu_grid* grid);
+int     pdegpu_slab_partition(int64_t n_planes, int n_ranks, int rank, int64_t* k0, int64_t* nk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDEGPU_H */

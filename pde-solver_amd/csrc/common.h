@@ -1,0 +1,164 @@
+// common.h — internal declarations shared by the HIP translation units of libpdegpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/pdegpu.h"
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct pdegpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    std::string err;
+    char name[256] = {0};
+};
+
+int pdegpu_set_err(pdegpu_ctx* ctx, int code, const char* fmt, ...);
+
+#define PG_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return pdegpu_set_err((ctx), PDEGPU_EHIP, "%s failed: %s (%s:%d)", #call,              \
+                                  hipGetErrorString(e__), __FILE__, __LINE__);                     \
+    } while (0)
+
+#define PG_TRY(call)                                                                               \
+    do {                                                                                           \
+        int rc__ = (call);                                                                         \
+        if (rc__ != PDEGPU_OK) return rc__;                                                        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// slab-resident pitched grid.  Node (i, j, lk) of a vector v lives at v[lk*PP + j*PX + i], lk = local
+// plane index in [-1, nkl] (-1 / nkl = ghost planes).  Rows are padded to PX (multiple of 16 doubles =
+// 128 B); pad entries, ghost planes of boundary slabs and guards are zero and stay zero.
+// ------------------------------------------------------------------------------------------------
+struct GridDev {
+    int dim;
+    int NX, NY, NZ;        // global node counts (1 on unused axes)
+    int PX;                // row pitch in doubles
+    int nkl;               // owned planes of this slab (slowest axis)
+    int k0;                // global index of local plane 0
+    long long PP;          // plane pitch in doubles = PX*NY
+    int bc_mode;           // PDEGPU_BC_*
+    int bc_present[3];
+    double bc_value[3];
+};
+
+static constexpr int kGuard = 64;   // extra doubles (beyond one row) before/after the ghost planes
+
+struct DevVec {
+    double* base = nullptr;    // allocation
+    double* v = nullptr;       // origin: node (0,0,lk=0)
+    size_t total = 0;          // doubles allocated
+};
+
+inline size_t vec_front(const GridDev& g) { return (size_t)g.PX + kGuard + (size_t)g.PP; }
+inline size_t vec_total(const GridDev& g) { return 2 * ((size_t)g.PX + kGuard) + (size_t)(g.nkl + 2) * g.PP; }
+
+__host__ __device__ inline bool pg_on_boundary(const GridDev& g, int i, int j, int kg) {
+    bool b = (i == 0) | (i == g.NX - 1);
+    if (g.dim >= 2) b |= (j == 0) | (j == g.NY - 1);
+    if (g.dim >= 3) b |= (kg == 0) | (kg == g.NZ - 1);
+    return b;
+}
+
+// Dirichlet set + value.  Mirrors the reference predicates (fenics_mcp_server.py:233-241, 373-376,
+// 606-628) with exact index tests instead of near().
+__host__ __device__ inline bool pg_dirichlet(const GridDev& g, int i, int j, int kg, double* val) {
+    if (!pg_on_boundary(g, i, j, kg)) return false;
+    if (g.bc_mode == PDEGPU_BC_UNIFORM) {
+        if (!g.bc_present[0]) return false;
+        *val = g.bc_value[0];
+        return true;
+    }
+    if (i == 0) {
+        if (!g.bc_present[0]) return false;
+        *val = g.bc_value[0];
+        return true;
+    }
+    if (i == g.NX - 1) {
+        if (!g.bc_present[1]) return false;
+        *val = g.bc_value[1];
+        return true;
+    }
+    if (!g.bc_present[2]) return false;
+    *val = g.bc_value[2];
+    return true;
+}
+
+// boundary class of an index along one axis: 0 = low face, 1 = interior, 2 = high face
+__host__ __device__ inline int pg_axis_class(int idx, int n_nodes) {
+    return idx == 0 ? 0 : (idx == n_nodes - 1 ? 2 : 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// class tables (tables.hip): integrated on the device from the macro-element matrices
+// ------------------------------------------------------------------------------------------------
+struct HeatTables {
+    double* d_tabK = nullptr;   // [27][27]
+    double* d_tabM = nullptr;   // [27][27]
+    double* d_load = nullptr;   // [27]
+    double* d_tabA = nullptr;   // [27][27] = cM*tabM + cK*tabK (filled by tables_combine)
+    double h_tabK[27 * 27], h_tabM[27 * 27], h_load[27];
+};
+int tables_build(pdegpu_ctx* ctx, const pdegpu_grid* grid, HeatTables* t);
+int tables_combine(pdegpu_ctx* ctx, HeatTables* t, double cM, double cK, double* d_out, double* h_out);
+void tables_free(HeatTables* t);
+
+// ------------------------------------------------------------------------------------------------
+// kernels launched through host wrappers (stencil.hip / vecops.hip)
+// ------------------------------------------------------------------------------------------------
+enum ApplyMode { APPLY_PLAIN = 0, APPLY_RESIDUAL = 1, APPLY_CG_K1 = 2 };
+
+struct StencilArgs {
+    GridDev g;
+    const double* tabA;       // device [27][27] class table (general path)
+    double w[8];              // interior coefficients: c0, cx, cy, cz, cxy, cxz, cyz, cxyz (fast path)
+    const double* in;         // PLAIN/RESIDUAL: input vector;  CG_K1: r
+    const double* rhs;        // RESIDUAL: right-hand side vector (nullable -> rhs_const)
+    double rhs_const;         // RESIDUAL with rhs == nullptr: constant right-hand side per free node
+    double in_shift;          // PLAIN: out = T (in + in_shift)
+    double* out;              // PLAIN/RESIDUAL: output;  CG_K1: q
+    const double* p_old;      // CG_K1
+    double* p_new;            // CG_K1
+    double* x;                // CG_K1 (updated in place)
+    const double* scal;       // CG_K1: device scalars (see Scal* below)
+    double* partials;         // per-workgroup partial dot products
+    int mask_dirichlet;       // 1: Dirichlet rows give 0 (P applied to the output)
+    int npt;                  // 7 or 15 (fast path)
+};
+
+// device scalar block used by the CG kernels
+enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_COUNT = 8 };
+
+struct LaunchInfo { int grid = 0; int block = 256; };
+
+int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
+bool stencil_fast_supported(const GridDev& g, int element_mode);
+int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
+int stencil_max_partials(pdegpu_ctx* ctx);
+
+int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
+void vec_free(DevVec* v);
+int vec_zero(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
+// x = Dirichlet value on constrained nodes, `fill` (or nodal[] when non-null, dense host-order device
+// array of the slab) elsewhere
+int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const double* nodal_dense, int only_bc);
+int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal);
+int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const double* scal, double* partials, LaunchInfo* li);
+int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
+int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
+int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
+int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense
+int vec_unpack(pdegpu_ctx* ctx, const GridDev& g, const double* dense, double* v);   // dense -> pitched
+
+GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0, int64_t nk);
+int validate_grid(pdegpu_ctx* ctx, const pdegpu_grid* grid);

@@ -1,0 +1,726 @@
+// heat.hip — slab-resident CG session, the one-shot heat solve and the C-ABI entry points of the heat path.
+//
+// Host-side restatement of the reference's solver bodies (fenics_mcp_server.py:259-318, 391-447, 653-716):
+//   steady:     kappa K u = f m                          (one solve, times = [0])
+//   transient:  (M + dt kappa K) u^{n+1} = M u^n + dt f m (backward Euler, snapshot per step)
+// with Dirichlet rows treated as identity rows.  Where the reference assembles a sparse matrix and runs a
+// sparse LU every step, this drives a matrix-free CG on full-grid vectors: Dirichlet nodes carry their
+// value in x and zeros in r, p, q, so the lifting A_IB g is exactly the initial residual and no separate
+// lifting pass exists.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+struct pdegpu_session {
+    pdegpu_ctx* ctx = nullptr;
+    pdegpu_grid grid{};
+    pdegpu_heat heat{};
+    GridDev g{};
+    HeatTables tabs{};
+    double cM = 0, cK = 0;
+    bool fast = false;
+    int npt = 15;
+    double hA[27 * 27];
+    DevVec x, r, p[2], q, b;
+    int pcur = 0;
+    double* d_scal = nullptr;
+    double* d_part = nullptr;
+    double* d_dense = nullptr;
+    double* h_pin = nullptr;       // pinned host scalars
+    std::vector<hipEvent_t> events;
+};
+
+// ---------------------------------------------------------------------------------------------
+// grid helpers (no GPU needed)
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t pdegpu_grid_num_nodes(const pdegpu_grid* grid) {
+    if (!grid || grid->dim < 1 || grid->dim > 3) return -1;
+    int64_t n = 1;
+    for (int r = 0; r < grid->dim; ++r) {
+        if (grid->n[r] < 1) return -1;
+        n *= (int64_t)grid->n[r] + 1;
+    }
+    return n;
+}
+
+// contiguous, near-equal node-plane ranges; every plane has exactly one owner (dot products are never
+// double counted), lower ranks take the remainder.
+extern "C" int pdegpu_slab_partition(int64_t n_planes, int n_ranks, int rank, int64_t* k0, int64_t* nk) {
+    if (n_planes < 1 || n_ranks < 1 || rank < 0 || rank >= n_ranks || !k0 || !nk) return PDEGPU_EINVAL;
+    const int64_t base = n_planes / n_ranks, rem = n_planes % n_ranks;
+    *nk = base + (rank < rem ? 1 : 0);
+    *k0 = rank * base + std::min<int64_t>(rank, rem);
+    return PDEGPU_OK;
+}
+
+extern "C" int pdegpu_heat_num_snapshots(const pdegpu_heat* h) {
+    if (!h) return PDEGPU_EINVAL;
+    if (h->steady) return 1;
+    const int stride = h->snapshot_stride < 1 ? 1 : h->snapshot_stride;
+    int n = 0;
+    for (int s = 0; s <= h->num_steps; ++s)
+        if (s % stride == 0 || s == h->num_steps) ++n;
+    return n;
+}
+
+int validate_grid(pdegpu_ctx* ctx, const pdegpu_grid* grid) {
+    if (!grid) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "grid is null");
+    if (grid->dim < 1 || grid->dim > 3) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "dim must be 1, 2 or 3 (got %d)", grid->dim);
+    for (int r = 0; r < grid->dim; ++r) {
+        if (grid->n[r] < 1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "n[%d] must be >= 1 (got %d)", r, grid->n[r]);
+        if (!(grid->L[r] > 0.0) || !std::isfinite(grid->L[r]))
+            return pdegpu_set_err(ctx, PDEGPU_EINVAL, "L[%d] must be a positive finite length", r);
+    }
+    if (grid->element_mode != PDEGPU_ELEM_P1SPLIT && grid->element_mode != PDEGPU_ELEM_Q1)
+        return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown element_mode %d", grid->element_mode);
+    return PDEGPU_OK;
+}
+
+GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0, int64_t nk) {
+    GridDev g{};
+    g.dim = grid->dim;
+    g.NX = grid->n[0] + 1;
+    g.NY = grid->dim >= 2 ? grid->n[1] + 1 : 1;
+    g.NZ = grid->dim >= 3 ? grid->n[2] + 1 : 1;
+    g.PX = (g.NX + 15) / 16 * 16;
+    g.PP = (long long)g.PX * g.NY;
+    g.k0 = (int)k0;
+    g.nkl = (int)nk;
+    if (heat) {
+        g.bc_mode = heat->bc_mode;
+        for (int r = 0; r < 3; ++r) {
+            g.bc_present[r] = heat->bc_present[r];
+            g.bc_value[r] = heat->bc_value[r];
+        }
+    } else {
+        g.bc_mode = PDEGPU_BC_DIRECTIONAL;   // nothing constrained
+    }
+    return g;
+}
+
+namespace {
+
+void fast_weights(const double* tab, double* w) {
+    const double* c = tab + 13 * 27;   // interior class
+    w[0] = c[13]; w[1] = c[14]; w[2] = c[16]; w[3] = c[22];
+    w[4] = c[17]; w[5] = c[23]; w[6] = c[25]; w[7] = c[26];
+}
+
+bool is_seven_point(const double* w) {
+    const double tol = 1e-12 * std::fabs(w[0]);
+    return std::fabs(w[4]) <= tol && std::fabs(w[5]) <= tol && std::fabs(w[6]) <= tol && std::fabs(w[7]) <= tol;
+}
+
+// out = T (in + shift)   with T = A (which==0) or M (which==1); unmasked unless mask
+int op_plain(pdegpu_session* s, int which, const double* in, double shift, double* out, int mask) {
+    StencilArgs a{};
+    a.g = s->g;
+    a.in = in;
+    a.in_shift = shift;
+    a.out = out;
+    a.partials = s->d_part;
+    a.mask_dirichlet = mask;
+    const double* htab = which == 0 ? s->hA : s->tabs.h_tabM;
+    a.tabA = which == 0 ? s->tabs.d_tabA : s->tabs.d_tabM;
+    if (s->fast) {
+        fast_weights(htab, a.w);
+        a.npt = is_seven_point(a.w) ? 7 : 15;
+        return stencil_fast(s->ctx, a, APPLY_PLAIN, nullptr);
+    }
+    return stencil_general(s->ctx, a, APPLY_PLAIN, nullptr);
+}
+
+// out = P (rhs - A in), partials of out.out
+int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* out, LaunchInfo* li) {
+    StencilArgs a{};
+    a.g = s->g;
+    a.in = in;
+    a.rhs = rhs;
+    a.out = out;
+    a.partials = s->d_part;
+    a.mask_dirichlet = 1;
+    a.tabA = s->tabs.d_tabA;
+    if (s->fast) {
+        fast_weights(s->hA, a.w);
+        a.npt = s->npt;
+        return stencil_fast(s->ctx, a, APPLY_RESIDUAL, li);
+    }
+    return stencil_general(s->ctx, a, APPLY_RESIDUAL, li);
+}
+
+int op_k1(pdegpu_session* s, LaunchInfo* li) {
+    StencilArgs a{};
+    a.g = s->g;
+    a.in = s->r.v;
+    a.p_old = s->p[s->pcur].v;
+    a.p_new = s->p[1 - s->pcur].v;
+    a.x = s->x.v;
+    a.out = s->q.v;
+    a.scal = s->d_scal;
+    a.partials = s->d_part;
+    a.mask_dirichlet = 1;
+    a.tabA = s->tabs.d_tabA;
+    int rc;
+    if (s->fast) {
+        fast_weights(s->hA, a.w);
+        a.npt = s->npt;
+        rc = stencil_fast(s->ctx, a, APPLY_CG_K1, li);
+    } else {
+        rc = stencil_general(s->ctx, a, APPLY_CG_K1, li);
+    }
+    if (rc == PDEGPU_OK) s->pcur ^= 1;
+    return rc;
+}
+
+// x (including the ghost planes that lie inside the global domain) = Dirichlet values / fill / nodal
+int set_bc_ext(pdegpu_session* s, double* x, double fill, const double* nodal_dense, int only_bc) {
+    GridDev g2 = s->g;
+    if (nodal_dense || s->g.dim < 3) return vec_set_bc(s->ctx, s->g, x, fill, nodal_dense, only_bc);
+    const int lo = s->g.k0 > 0 ? 1 : 0;
+    const int hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
+    g2.k0 = s->g.k0 - lo;
+    g2.nkl = s->g.nkl + lo + hi;
+    return vec_set_bc(s->ctx, g2, x - (long long)lo * s->g.PP, fill, nullptr, only_bc);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* pdegpu_version(void) { return "pdegpu 0.1 (gfx950)"; }
+
+extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
+    if (!out) return PDEGPU_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return PDEGPU_ENODEV;
+    if (device_id < 0 || device_id >= ndev) return PDEGPU_ENODEV;
+    pdegpu_ctx* ctx = new pdegpu_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return PDEGPU_ENODEV; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return PDEGPU_ENODEV; }
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+        ctx->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return PDEGPU_OK;
+}
+
+extern "C" void pdegpu_destroy(pdegpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* pdegpu_last_error(const pdegpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf || buflen == 0) return PDEGPU_EINVAL;
+    snprintf(buf, buflen, "%s", ctx->name);
+    return PDEGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// session
+// ---------------------------------------------------------------------------------------------
+extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    vec_free(&s->x); vec_free(&s->r); vec_free(&s->p[0]); vec_free(&s->p[1]); vec_free(&s->q); vec_free(&s->b);
+    tables_free(&s->tabs);
+    if (s->d_scal) (void)hipFree(s->d_scal);
+    if (s->d_part) (void)hipFree(s->d_part);
+    if (s->d_dense) (void)hipFree(s->d_dense);
+    if (s->h_pin) (void)hipHostFree(s->h_pin);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    delete s;
+}
+
+extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0,
+                                     int64_t nk, pdegpu_session** out) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!out || !heat) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    *out = nullptr;
+    PG_TRY(validate_grid(ctx, grid));
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
+    if (k0 < 0 || nk < 1 || k0 + nk > nslow)
+        return pdegpu_set_err(ctx, PDEGPU_EINVAL, "slab [%lld, %lld) outside the %lld node planes", (long long)k0,
+                              (long long)(k0 + nk), (long long)nslow);
+    if (heat->bc_mode != PDEGPU_BC_UNIFORM && heat->bc_mode != PDEGPU_BC_DIRECTIONAL)
+        return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown bc_mode %d", heat->bc_mode);
+    if (!(heat->kappa > 0.0)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "kappa must be > 0");
+    if (!heat->steady && !(heat->dt > 0.0)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "dt must be > 0 for a transient solve");
+
+    pdegpu_session* s = new pdegpu_session();
+    s->ctx = ctx;
+    s->grid = *grid;
+    s->heat = *heat;
+    s->g = make_grid_dev(grid, heat, k0, nk);
+    s->cM = heat->steady ? 0.0 : 1.0;
+    s->cK = heat->steady ? heat->kappa : heat->dt * heat->kappa;
+    int rc = tables_build(ctx, grid, &s->tabs);
+    if (rc == PDEGPU_OK) rc = tables_combine(ctx, &s->tabs, s->cM, s->cK, s->tabs.d_tabA, s->hA);
+    s->fast = heat->fast_path != 0 && stencil_fast_supported(s->g, grid->element_mode);
+    if (s->fast) {
+        double w[8];
+        fast_weights(s->hA, w);
+        s->npt = is_seven_point(w) ? 7 : 15;
+    }
+    DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
+    for (DevVec* v : vecs)
+        if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);
+    const int npart = stencil_max_partials(ctx);
+    if (rc == PDEGPU_OK && hipMalloc(&s->d_scal, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc scal");
+    if (rc == PDEGPU_OK && hipMalloc(&s->d_part, npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
+    if (rc == PDEGPU_OK && hipHostMalloc(&s->h_pin, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipHostMalloc");
+    if (rc == PDEGPU_OK && hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset scal");
+    if (rc == PDEGPU_OK && hipMemsetAsync(s->d_part, 0, npart * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset partials");
+    if (rc != PDEGPU_OK) { pdegpu_session_destroy(s); return rc; }
+    *out = s;
+    return PDEGPU_OK;
+}
+
+extern "C" int pdegpu_session_begin(pdegpu_session* s, double x_fill) {
+    if (!s) return PDEGPU_EINVAL;
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
+    PG_TRY(vec_zero(ctx, s->g, &s->p[0]));
+    PG_TRY(vec_zero(ctx, s->g, &s->p[1]));
+    s->pcur = 0;
+    PG_TRY(set_bc_ext(s, s->x.v, x_fill, nullptr, 0));
+    // constant-source right-hand side b = M (0 + f) = f m  (fenics_mcp_server.py:262, 394, 658)
+    PG_TRY(vec_zero(ctx, s->g, &s->q));
+    PG_TRY(op_plain(s, 1, s->q.v, s->heat.source, s->b.v, 0));
+    return PDEGPU_OK;
+}
+
+extern "C" void* pdegpu_session_plane_ptr(pdegpu_session* s, int vec, int64_t which) {
+    if (!s || which < -1 || which > s->g.nkl) return nullptr;
+    double* base = nullptr;
+    switch (vec) {
+        case 0: base = s->x.v; break;
+        case 1: base = s->r.v; break;
+        case 2: base = s->p[s->pcur].v; break;
+        case 3: base = s->q.v; break;
+        default: return nullptr;
+    }
+    return base + which * s->g.PP;
+}
+
+extern "C" int64_t pdegpu_session_plane_doubles(const pdegpu_session* s) { return s ? (int64_t)s->g.PP : -1; }
+extern "C" double* pdegpu_session_scalars(pdegpu_session* s) { return s ? s->d_scal : nullptr; }
+
+extern "C" int pdegpu_session_residual(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    LaunchInfo li;
+    PG_TRY(op_residual(s, s->x.v, s->b.v, s->r.v, &li));
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 0);
+}
+
+extern "C" int pdegpu_session_k1(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    LaunchInfo li;
+    PG_TRY(op_k1(s, &li));
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 0, 0);
+}
+
+extern "C" int pdegpu_session_k2(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    LaunchInfo li;
+    PG_TRY(vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, &li));
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 0);
+}
+
+// single-slab convenience: local -> global (the multi-GPU host all-reduces instead)
+extern "C" int pdegpu_session_reduce_local(pdegpu_session* s, int which, int copy_to_global) {
+    if (!s || (which != 0 && which != 1)) return PDEGPU_EINVAL;
+    if (!copy_to_global) return PDEGPU_OK;
+    const int src = which == 0 ? SC_PQ_LOCAL : SC_RR_LOCAL, dst = which == 0 ? SC_PQ : SC_RR;
+    PG_HIP(s->ctx, hipMemcpyAsync(s->d_scal + dst, s->d_scal + src, sizeof(double), hipMemcpyDeviceToDevice, s->ctx->stream));
+    return PDEGPU_OK;
+}
+
+extern "C" int pdegpu_session_flush(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    PG_TRY(vec_axpy_flush(s->ctx, s->g, s->x.v, s->p[s->pcur].v, s->d_scal));
+    // the pending update is applied: make the next K1 skip it (alpha_prev = 0) while beta stays valid
+    PG_HIP(s->ctx, hipMemsetAsync(s->d_scal + SC_PQ, 0, sizeof(double), s->ctx->stream));
+    return PDEGPU_OK;
+}
+
+extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_kernels, pdegpu_stats* stats) {
+    if (!s || iters < 0) return PDEGPU_EINVAL;
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = time_kernels ? (size_t)iters * 4 : 0;
+    while (s->events.size() < need) {
+        hipEvent_t e;
+        PG_HIP(ctx, hipEventCreate(&e));
+        s->events.push_back(e);
+    }
+    LaunchInfo l1, l2;
+    for (int it = 0; it < iters; ++it) {
+        if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 0], ctx->stream));
+        PG_TRY(op_k1(s, &l1));
+        if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 1], ctx->stream));
+        PG_TRY(vec_reduce(ctx, s->d_part, l1.grid, s->d_scal, 0, 1));
+        if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 2], ctx->stream));
+        PG_TRY(vec_k2(ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, &l2));
+        if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
+        PG_TRY(vec_reduce(ctx, s->d_part, l2.grid, s->d_scal, 1, 1));
+    }
+    if (stats) {
+        stats->cg_iterations += iters;
+        stats->path = s->fast ? 1 : 0;
+        if (time_kernels && iters > 0) {
+            PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const double nloc = (double)s->g.nkl * s->g.NY * s->g.NX;
+            for (int it = 0; it < iters; ++it) {
+                float ms = 0;
+                PG_HIP(ctx, hipEventElapsedTime(&ms, s->events[4 * it + 0], s->events[4 * it + 1]));
+                stats->kernel_ms[0] += ms;
+                PG_HIP(ctx, hipEventElapsedTime(&ms, s->events[4 * it + 2], s->events[4 * it + 3]));
+                stats->kernel_ms[1] += ms;
+            }
+            stats->kernel_launches[0] += iters;
+            stats->kernel_launches[1] += iters;
+            stats->alg_bytes[0] += 48.0 * nloc * iters;   // K1: read r, p, x; write p, q, x
+            stats->alg_bytes[1] += 24.0 * nloc * iters;   // K2: read r, q; write r
+        }
+    }
+    return PDEGPU_OK;
+}
+
+extern "C" int pdegpu_session_rr(pdegpu_session* s, double* rr_out) {
+    if (!s || !rr_out) return PDEGPU_EINVAL;
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    PG_HIP(ctx, hipMemcpyAsync(s->h_pin, s->d_scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *rr_out = s->h_pin[SC_RR];
+    return PDEGPU_OK;
+}
+
+extern "C" int pdegpu_session_sync(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    PG_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return PDEGPU_OK;
+}
+
+namespace {
+int ensure_dense(pdegpu_session* s) {
+    if (s->d_dense) return PDEGPU_OK;
+    const size_t n = (size_t)s->g.nkl * s->g.NY * s->g.NX;
+    PG_HIP(s->ctx, hipMalloc(&s->d_dense, n * sizeof(double)));
+    return PDEGPU_OK;
+}
+int get_vec(pdegpu_session* s, const double* v, double* host_out) {
+    PG_TRY(ensure_dense(s));
+    const size_t n = (size_t)s->g.nkl * s->g.NY * s->g.NX;
+    PG_TRY(vec_pack(s->ctx, s->g, v, s->d_dense));
+    PG_HIP(s->ctx, hipMemcpyAsync(host_out, s->d_dense, n * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
+    PG_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return PDEGPU_OK;
+}
+int put_vec(pdegpu_session* s, const double* host_in, double* v) {
+    PG_TRY(ensure_dense(s));
+    const size_t n = (size_t)s->g.nkl * s->g.NY * s->g.NX;
+    PG_HIP(s->ctx, hipMemcpyAsync(s->d_dense, host_in, n * sizeof(double), hipMemcpyHostToDevice, s->ctx->stream));
+    PG_TRY(vec_unpack(s->ctx, s->g, s->d_dense, v));
+    PG_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return PDEGPU_OK;
+}
+}  // namespace
+
+extern "C" int pdegpu_session_get_x(pdegpu_session* s, double* x_out) {
+    if (!s || !x_out) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return get_vec(s, s->x.v, x_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CG on one slab until ||r|| <= rtol * bnorm  (host polls r.r every `chunk` iterations)
+// ---------------------------------------------------------------------------------------------
+namespace {
+int cg_solve(pdegpu_session* s, double bnorm2, double rtol, int max_iter, pdegpu_stats* st, int* iters_out, double* rel_out) {
+    pdegpu_ctx* ctx = s->ctx;
+    double rr = 0;
+    PG_TRY(pdegpu_session_rr(s, &rr));
+    const double target = rtol * rtol * bnorm2;
+    int it = 0;
+    int chunk = 8;
+    hipEvent_t e0, e1;
+    PG_HIP(ctx, hipEventCreate(&e0));
+    PG_HIP(ctx, hipEventCreate(&e1));
+    PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    while (rr > target && it < max_iter && std::isfinite(rr)) {
+        const int n = std::min(chunk, max_iter - it);
+        PG_TRY(pdegpu_session_iterate(s, n, 0, nullptr));
+        it += n;
+        PG_TRY(pdegpu_session_rr(s, &rr));
+        if (chunk < 64) chunk *= 2;
+    }
+    PG_TRY(pdegpu_session_flush(s));
+    PG_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    PG_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st) {
+        st->cg_iterations += it;
+        st->cg_ms += ms;
+        st->linear_solves += 1;
+    }
+    *iters_out = it;
+    *rel_out = bnorm2 > 0 ? std::sqrt(rr / bnorm2) : std::sqrt(rr);
+    if (!std::isfinite(rr)) return pdegpu_set_err(ctx, PDEGPU_ENOCONV, "CG diverged (non-finite residual) after %d iterations", it);
+    if (rr > target) return pdegpu_set_err(ctx, PDEGPU_ENOCONV, "CG did not reach rtol=%g in %d iterations (rel=%g)", rtol, it, *rel_out);
+    return PDEGPU_OK;
+}
+
+// one linear solve A x = b on the session: reference norm from the lifted right-hand side, CG from x
+int linear_solve(pdegpu_session* s, bool x_is_lift_only, pdegpu_stats* st) {
+    pdegpu_ctx* ctx = s->ctx;
+    LaunchInfo li;
+    double bnorm2 = 0;
+    PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
+    PG_TRY(vec_zero(ctx, s->g, &s->p[0]));
+    PG_TRY(vec_zero(ctx, s->g, &s->p[1]));
+    s->pcur = 0;
+    if (!x_is_lift_only) {
+        // ||P (b - A g)||: g = Dirichlet values, zero elsewhere (held in q for this pass, result in r)
+        PG_TRY(vec_zero(ctx, s->g, &s->q));
+        PG_TRY(set_bc_ext(s, s->q.v, 0.0, nullptr, 0));
+        PG_TRY(op_residual(s, s->q.v, s->b.v, s->r.v, &li));
+        PG_TRY(vec_reduce(ctx, s->d_part, li.grid, s->d_scal, 1, 1));
+        PG_TRY(pdegpu_session_rr(s, &bnorm2));
+        PG_TRY(vec_zero(ctx, s->g, &s->q));
+        PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
+    }
+    PG_TRY(op_residual(s, s->x.v, s->b.v, s->r.v, &li));
+    PG_TRY(vec_reduce(ctx, s->d_part, li.grid, s->d_scal, 1, 1));
+    if (x_is_lift_only) PG_TRY(pdegpu_session_rr(s, &bnorm2));
+    int iters = 0;
+    double rel = 0;
+    int rc = cg_solve(s, bnorm2, s->heat.rtol, s->heat.max_iter, st, &iters, &rel);
+    if (st) {
+        st->final_rel_residual = rel;
+        if (rc != PDEGPU_OK) st->converged = 0;
+    }
+    return rc;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// one-shot heat solve (single GPU)
+// ---------------------------------------------------------------------------------------------
+extern "C" int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat_in, const double* u0,
+                                 double* values_out, double* times_out, pdegpu_stats* stats) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!heat_in || !values_out || !times_out) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    PG_TRY(validate_grid(ctx, grid));
+    pdegpu_heat heat = *heat_in;
+    if (heat.rtol <= 0) heat.rtol = 1e-10;
+    if (heat.max_iter <= 0) heat.max_iter = 100000;
+    if (heat.snapshot_stride < 1) heat.snapshot_stride = 1;
+    if (!heat.steady && heat.num_steps < 0) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "num_steps must be >= 0");
+    if (!heat.steady && heat.ic_type == PDEGPU_IC_NODAL && !u0) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "ic_type NODAL needs u0");
+    pdegpu_stats st{};
+    st.converged = 1;
+    const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
+    pdegpu_session* s = nullptr;
+    PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));
+    const size_t N = (size_t)pdegpu_grid_num_nodes(grid);
+    st.n_nodes = (int64_t)N;
+    st.path = s->fast ? 1 : 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PDEGPU_OK;
+    auto fail = [&](int code) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        pdegpu_session_destroy(s);
+        if (stats) *stats = st;
+        return code;
+    };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(pdegpu_set_err(ctx, PDEGPU_EHIP, "hipEventCreate"));
+    (void)hipEventRecord(e0, ctx->stream);
+
+    // free unknowns = nodes that are not Dirichlet (counted on the host; cheap index arithmetic)
+    {
+        int64_t nfree = 0;
+        const GridDev& g = s->g;
+        for (int k = 0; k < g.NZ; ++k)
+            for (int j = 0; j < g.NY; ++j) {
+                // only rows touching a face need the per-node test
+                const bool face_row = (g.dim >= 2 && (j == 0 || j == g.NY - 1)) || (g.dim >= 3 && (k == 0 || k == g.NZ - 1));
+                if (!face_row) {
+                    double v;
+                    nfree += g.NX - 2 + (pg_dirichlet(g, 0, j, k, &v) ? 0 : 1) + (g.NX > 1 && pg_dirichlet(g, g.NX - 1, j, k, &v) ? 0 : 1);
+                    continue;
+                }
+                for (int i = 0; i < g.NX; ++i) {
+                    double v;
+                    if (!pg_dirichlet(g, i, j, k, &v)) ++nfree;
+                }
+            }
+        st.n_unknowns = nfree;
+    }
+
+    if (heat.steady) {
+        rc = pdegpu_session_begin(s, 0.0);
+        if (rc == PDEGPU_OK) rc = linear_solve(s, true, &st);
+        if (rc == PDEGPU_OK || rc == PDEGPU_ENOCONV) {
+            int rc2 = get_vec(s, s->x.v, values_out);
+            if (rc2 != PDEGPU_OK) rc = rc2;
+            times_out[0] = 0.0;
+        }
+    } else {
+        // u^0: initial condition with the Dirichlet values imposed (fenics_mcp_server.py:296-297, 426, 690-691)
+        if (heat.ic_type == PDEGPU_IC_NODAL) {
+            rc = ensure_dense(s);
+            if (rc == PDEGPU_OK && hipMemcpyAsync(s->d_dense, u0, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "upload u0");
+            if (rc == PDEGPU_OK) rc = vec_set_bc(ctx, s->g, s->x.v, 0.0, s->d_dense, 0);
+        } else {
+            rc = set_bc_ext(s, s->x.v, heat.ic_type == PDEGPU_IC_ZERO ? 0.0 : heat.ic_value, nullptr, 0);
+        }
+        const int stride = heat.snapshot_stride;
+        int snap = 0;
+        if (rc == PDEGPU_OK) {
+            rc = get_vec(s, s->x.v, values_out);
+            times_out[snap++] = 0.0;
+        }
+        for (int n = 0; n < heat.num_steps && rc == PDEGPU_OK; ++n) {
+            // b = M (u^n + dt f)   — `u_n*v*dx + dt*f*v*dx` (:305, :434, :703)
+            rc = op_plain(s, 1, s->x.v, heat.dt * heat.source, s->b.v, 0);
+            if (rc == PDEGPU_OK) rc = linear_solve(s, false, &st);
+            const int step = n + 1;
+            if ((rc == PDEGPU_OK) && (step % stride == 0 || step == heat.num_steps)) {
+                rc = get_vec(s, s->x.v, values_out + (size_t)snap * N);
+                times_out[snap++] = step * heat.dt;
+            }
+        }
+    }
+    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    st.solve_ms = ms;
+    return fail(rc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// project(): consistent-mass solve M s = rhs, no Dirichlet rows
+// ---------------------------------------------------------------------------------------------
+extern "C" int pdegpu_mass_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const double* rhs, double* s_out, double rtol,
+                                 int max_iter, pdegpu_stats* stats) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!rhs || !s_out) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    PG_TRY(validate_grid(ctx, grid));
+    pdegpu_heat heat{};
+    heat.kappa = 1.0;
+    heat.dt = 1.0;
+    heat.steady = 0;
+    heat.bc_mode = PDEGPU_BC_DIRECTIONAL;      // nothing constrained
+    heat.rtol = rtol > 0 ? rtol : 1e-12;
+    heat.max_iter = max_iter > 0 ? max_iter : 10000;
+    heat.fast_path = 0;
+    const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
+    pdegpu_session* s = nullptr;
+    PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));
+    // operator = M only
+    s->cM = 1.0;
+    s->cK = 0.0;
+    int rc = tables_combine(ctx, &s->tabs, 1.0, 0.0, s->tabs.d_tabA, s->hA);
+    pdegpu_stats st{};
+    st.converged = 1;
+    st.n_nodes = st.n_unknowns = pdegpu_grid_num_nodes(grid);
+    if (rc == PDEGPU_OK) rc = put_vec(s, rhs, s->b.v);
+    if (rc == PDEGPU_OK) rc = vec_zero(ctx, s->g, &s->x);
+    if (rc == PDEGPU_OK) rc = linear_solve(s, true, &st);
+    if (rc == PDEGPU_OK || rc == PDEGPU_ENOCONV) {
+        int rc2 = get_vec(s, s->x.v, s_out);
+        if (rc2 != PDEGPU_OK) rc = rc2;
+    }
+    pdegpu_session_destroy(s);
+    if (stats) *stats = st;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operator access for tests / roofline harness
+// ---------------------------------------------------------------------------------------------
+extern "C" int pdegpu_heat_tables(pdegpu_ctx* ctx, const pdegpu_grid* grid, double* tabK, double* tabM, double* load) {
+    if (!ctx) return PDEGPU_EINVAL;
+    PG_TRY(validate_grid(ctx, grid));
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    HeatTables t{};
+    int rc = tables_build(ctx, grid, &t);
+    if (rc == PDEGPU_OK) {
+        if (tabK) memcpy(tabK, t.h_tabK, sizeof t.h_tabK);
+        if (tabM) memcpy(tabM, t.h_tabM, sizeof t.h_tabM);
+        if (load) memcpy(load, t.h_load, sizeof t.h_load);
+    }
+    tables_free(&t);
+    return rc;
+}
+
+extern "C" int pdegpu_heat_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, double cM, double cK, const double* x, double* y,
+                                 double* load_out, int fast_path) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!x || !y) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    PG_TRY(validate_grid(ctx, grid));
+    pdegpu_heat heat{};
+    heat.kappa = 1.0;
+    heat.dt = 1.0;
+    heat.steady = 0;
+    heat.fast_path = fast_path;
+    if (fast_path) {                       // fast kernels exist for the all-Dirichlet operator only
+        heat.bc_mode = PDEGPU_BC_UNIFORM;
+        heat.bc_present[0] = 1;
+    } else {
+        heat.bc_mode = PDEGPU_BC_DIRECTIONAL;
+    }
+    const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
+    pdegpu_session* s = nullptr;
+    PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));
+    if (fast_path && !s->fast) {
+        pdegpu_session_destroy(s);
+        return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "fast path needs a 3-D P1 grid with >= 2 cells per axis");
+    }
+    s->cM = cM;
+    s->cK = cK;
+    int rc = tables_combine(ctx, &s->tabs, cM, cK, s->tabs.d_tabA, s->hA);
+    if (rc == PDEGPU_OK) rc = put_vec(s, x, s->x.v);
+    // fast path computes the free rows only (Dirichlet rows -> 0); general path applies the full operator
+    if (rc == PDEGPU_OK) rc = op_plain(s, 0, s->x.v, 0.0, s->q.v, fast_path ? 1 : 0);
+    if (rc == PDEGPU_OK) rc = get_vec(s, s->q.v, y);
+    if (rc == PDEGPU_OK && load_out) {
+        s->fast = false;                   // load vector on every node: general class-table kernel
+        rc = vec_zero(ctx, s->g, &s->r);
+        if (rc == PDEGPU_OK) rc = vec_zero(ctx, s->g, &s->b);
+        if (rc == PDEGPU_OK) rc = op_plain(s, 1, s->r.v, 1.0, s->b.v, 0);
+        if (rc == PDEGPU_OK) rc = get_vec(s, s->b.v, load_out);
+    }
+    pdegpu_session_destroy(s);
+    return rc;
+}

@@ -1,0 +1,414 @@
+// stencil.hip — matrix-free operator application for the heat path (gfx950).
+//
+// Replaces DOLFIN's assembled sparse matrix + `solve(a == L, u, bcs)` inner products
+// (fenics_mcp_server.py:265, 311, 397, 440, 661, 709): the operator A = cM*M + cK*K is never stored;
+// it is applied as a constant-coefficient node stencil (7-point stiffness / 15-point consistent mass for
+// the reference's P1 simplex split, 27-point for Q1) over full-grid fp64 vectors in HBM.
+//
+// Two implementations of the same three operations (PLAIN apply, RESIDUAL, fused CG "K1"):
+//   * general: one thread per node, coupling weights looked up per boundary class from the 27x27 class
+//     table in LDS (any dimension, any Dirichlet/natural face mix, P1 or Q1);
+//   * fast: 3-D, every boundary node Dirichlet, P1 split.  One wavefront owns a 128-node x 4-row column
+//     of the grid and marches along z keeping three planes in registers, so every input plane is read
+//     once per wave; x-neighbours come from DPP wave shifts (no LDS traffic), y/z neighbours from
+//     registers; loads and stores are 16 B per lane (global_load/store_dwordx4), fully coalesced 1 KiB
+//     per wave-instruction.  Workgroups are mapped so that one XCD sweeps one z-chunk of the whole x-y
+//     plane: the y-halo rows shared by neighbouring workgroups are then served by that XCD's L2.
+//
+// CG K1 (both implementations) fuses, per iteration n:  x += alpha_{n-1} p_{n-1};  p_n = r_n + beta_{n-1}
+// p_{n-1};  q_n = A p_n;  partial(p_n . q_n)  — p_n is recomputed on the fly at the stencil neighbours
+// from r_n and p_{n-1}, which removes the separate p-update pass (72 B/DoF per CG iteration in total).
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// reductions: per-lane partials -> wavefront (__shfl_down over 64 lanes) -> LDS across the 4 waves
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;   // valid in lane 0
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);   // fixed order: bitwise reproducible
+}
+
+__device__ __forceinline__ void cg_scalars(const double* __restrict__ scal, double* alpha_prev, double* beta) {
+    // alpha_{n-1} = rr_{n-1} / (p_{n-1}.q_{n-1}),  beta_{n-1} = rr_n / rr_{n-1};  both 0 on the first iteration
+    const double pq = scal[SC_PQ], rr = scal[SC_RR], rr_prev = scal[SC_RR_PREV];
+    *alpha_prev = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
+    *beta = (rr_prev > 0.0) ? rr / rr_prev : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// general path
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_general(StencilArgs a) {
+    __shared__ double sTab[27 * 27];
+    __shared__ double sRed[4];
+    for (int e = threadIdx.x; e < 27 * 27; e += 256) sTab[e] = a.tabA[e];
+    __syncthreads();
+
+    const GridDev& g = a.g;
+    const long long total = (long long)g.nkl * g.PP;
+    double alpha_prev = 0.0, beta = 0.0;
+    if (MODE == APPLY_CG_K1) cg_scalars(a.scal, &alpha_prev, &beta);
+
+    double acc = 0.0;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int i = (int)(idx % g.PX);
+        const long long row = idx / g.PX;
+        const int j = (int)(row % g.NY);
+        const int lk = (int)(row / g.NY);
+        const int kg = g.k0 + lk;
+        const bool real = i < g.NX;
+        double dval = 0.0;
+        const bool dir = real && a.mask_dirichlet && pg_dirichlet(g, i, j, kg, &dval);
+
+        double pn = 0.0;
+        if (MODE == APPLY_CG_K1) {
+            const double po = a.p_old[idx];
+            pn = a.in[idx] + beta * po;
+            a.p_new[idx] = pn;
+            if (alpha_prev != 0.0) a.x[idx] += alpha_prev * po;
+        }
+        double s = 0.0;
+        if (real && !dir) {
+            const int cls = pg_axis_class(i, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
+                            9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
+            const double* w = &sTab[cls * 27];
+#pragma unroll
+            for (int o = 0; o < 27; ++o) {
+                const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+                const double wo = w[o];
+                if (wo != 0.0) {
+                    const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
+                    double v;
+                    if (MODE == APPLY_CG_K1) v = a.in[nb] + beta * a.p_old[nb];
+                    else v = a.in[nb] + a.in_shift;
+                    s += wo * v;
+                }
+            }
+        }
+        if (MODE == APPLY_PLAIN) {
+            a.out[idx] = s;
+            if (real) acc += a.in[idx] * s;
+        } else if (MODE == APPLY_RESIDUAL) {
+            double rv = 0.0;
+            if (real && !dir) rv = (a.rhs ? a.rhs[idx] : a.rhs_const) - s;
+            a.out[idx] = rv;
+            acc += rv * rv;
+        } else {
+            a.out[idx] = s;
+            acc += pn * s;
+        }
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast path: z-marching, registers + DPP
+// ---------------------------------------------------------------------------------------------
+struct FastGeom {
+    int ntx, nty;          // 128-node x-tiles, RY-row y-tiles covering the interior
+    int wxt, wyt;          // waves of a workgroup along x / y (wxt*wyt == 4)
+    int nxg, nyg, nzc;     // workgroup counts along x, y; z-chunks
+    int lkb, lke;          // local interior plane range [lkb, lke)
+    int zlen;              // planes per z-chunk
+};
+
+// lane l receives the value of lane l-1 (lane 0 receives 0): v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ double dpp_from_lower(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// lane l receives the value of lane l+1 (lane 63 receives 0): v_mov_b32_dpp wave_shl:1
+__device__ __forceinline__ double dpp_from_upper(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NPT, int RY, int MODE>
+__global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
+    __shared__ double sRed[4];
+    const GridDev& g = a.g;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr bool K1 = (MODE == APPLY_CG_K1);
+    constexpr bool W15 = (NPT == 15);
+    constexpr int RH = RY + 2;                 // rows held per plane (own rows + one halo row each side)
+
+    // XCD-aware workgroup -> tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only), so
+    // XCD x gets the contiguous work range [x*G/8, (x+1)*G/8): neighbouring y-tiles of one z-chunk.
+    const int G = gridDim.x;
+    int wid = blockIdx.x;
+    if ((G & 7) == 0) wid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int xg = wid % fg.nxg, yg = (wid / fg.nxg) % fg.nyg, zc = wid / (fg.nxg * fg.nyg);
+    const int xt = xg * fg.wxt + (wv % fg.wxt), yt = yg * fg.wyt + (wv / fg.wxt);
+    const int i0 = xt * 128 + 2 * lane;
+    const int j0 = 1 + yt * RY;
+    const int lk0 = fg.lkb + zc * fg.zlen;
+    const int lk1 = min(lk0 + fg.zlen, fg.lke);
+    const bool active = (xt < fg.ntx) && (yt < fg.nty) && (lk0 < lk1);
+
+    double acc = 0.0;
+    if (active) {
+        double alpha_prev = 0.0, beta = 0.0;
+        if (K1) cg_scalars(a.scal, &alpha_prev, &beta);
+        const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wz = a.w[3];
+        const double wxy = a.w[4], wxz = a.w[5], wyz = a.w[6], wxyz = a.w[7];
+        const double shift = a.in_shift;
+
+        const bool lane_ok = i0 < g.PX;                       // pair inside the padded row
+        const bool ma = (i0 >= 1) && (i0 <= g.NX - 2);        // node a = i0 is an interior (free) node
+        const bool mb = (i0 + 1 <= g.NX - 2);                 // node b = i0+1
+        const bool edge_lane = (lane == 0) || (lane == 63);
+        const long long edge_off = (lane == 0) ? -1 : 2;      // lane 0: node i0-1, lane 63: node i0+2
+
+        // value of one row-plane: K1 -> p_n = r + beta p_{n-1}; PLAIN -> in + shift; RESIDUAL -> in
+        auto row_ok = [&](int j) { return (j >= 0) && (j < g.NY); };
+        auto load_pair = [&](const double* __restrict__ v, long long off) {
+            return *reinterpret_cast<const double2*>(v + off);
+        };
+        auto value_row = [&](int lk, int j, double2* po_out) {
+            double2 val = make_double2(0.0, 0.0);
+            if (row_ok(j) && lane_ok) {
+                const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
+                if (K1) {
+                    const double2 rr = load_pair(a.in, off), po = load_pair(a.p_old, off);
+                    val.x = rr.x + beta * po.x;
+                    val.y = rr.y + beta * po.y;
+                    if (po_out) *po_out = po;
+                } else {
+                    const double2 v = load_pair(a.in, off);
+                    val.x = v.x + shift;
+                    val.y = v.y + shift;
+                }
+            }
+            return val;
+        };
+        auto edge_value = [&](int lk, int j) {
+            double e = 0.0;
+            if (row_ok(j) && edge_lane) {
+                const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0 + edge_off;
+                if (K1) e = a.in[off] + beta * a.p_old[off];
+                else e = a.in[off] + shift;
+            }
+            return e;
+        };
+        // K1: x += alpha p_{n-1}, store p_n for an owned row-plane
+        auto own_update = [&](int lk, int j, const double2& pn, const double2& po) {
+            if (K1) {
+                if (j <= g.NY - 2 && lane_ok) {
+                    const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
+                    *reinterpret_cast<double2*>(a.p_new + off) = pn;
+                    if (alpha_prev != 0.0) {
+                        double2 xv = *reinterpret_cast<const double2*>(a.x + off);
+                        xv.x += alpha_prev * po.x;
+                        xv.y += alpha_prev * po.y;
+                        *reinterpret_cast<double2*>(a.x + off) = xv;
+                    }
+                }
+            }
+        };
+
+        // registers: P = plane lk-1, C = plane lk, N = plane lk+1; index 0..RH-1 <-> rows j0-1 .. j0+RY
+        double2 P[RH], C[RH], N[RH];
+        double EP[RH], EC[RH], EN[RH];      // edge values (lane 0: node i0-1, lane 63: node i0+2)
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+            const bool own = (r >= 1) && (r <= RY);
+            const int j = j0 - 1 + r;
+            // plane lk0-1: 7-point needs own rows only; 15-point rows j-1..j (r = 0..RY)
+            if (W15 ? (r <= RY) : own) {
+                P[r] = value_row(lk0 - 1, j, nullptr);
+                EP[r] = W15 ? edge_value(lk0 - 1, j) : 0.0;
+            } else {
+                P[r] = make_double2(0.0, 0.0);
+                EP[r] = 0.0;
+            }
+            double2 po = make_double2(0.0, 0.0);
+            C[r] = value_row(lk0, j, &po);
+            EC[r] = (W15 || own) ? edge_value(lk0, j) : 0.0;
+            if (own) own_update(lk0, j, C[r], po);
+        }
+
+        for (int lk = lk0; lk < lk1; ++lk) {
+            // ---- issue the loads of plane lk+1 -------------------------------------------------
+            double2 PO[RH];
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                const int j = j0 - 1 + r;
+                PO[r] = make_double2(0.0, 0.0);
+                N[r] = value_row(lk + 1, j, &PO[r]);
+                const bool own = (r >= 1) && (r <= RY);
+                EN[r] = (W15 || own) ? edge_value(lk + 1, j) : 0.0;
+            }
+            double2 RHS[RY];
+            if (MODE == APPLY_RESIDUAL) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    const int j = j0 + r;
+                    RHS[r] = make_double2(a.rhs_const, a.rhs_const);
+                    if (a.rhs && j <= g.NY - 2 && lane_ok)
+                        RHS[r] = load_pair(a.rhs, (long long)lk * g.PP + (long long)j * g.PX + i0);
+                }
+            }
+
+            // ---- stencil of plane lk -----------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const int c = r + 1;
+                const int j = j0 + r;
+                if (j <= g.NY - 2) {                                  // wave-uniform
+                    double lC = dpp_from_lower(C[c].y), rC = dpp_from_upper(C[c].x);
+                    lC = (lane == 0) ? EC[c] : lC;
+                    rC = (lane == 63) ? EC[c] : rC;
+                    double qa = w0 * C[c].x + wx * (lC + C[c].y) + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x);
+                    double qb = w0 * C[c].y + wx * (C[c].x + rC) + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y);
+                    if (W15) {
+                        // same-sign diagonals of the Kuhn split: +-(1,1,0), +-(1,0,1), +-(0,1,1), +-(1,1,1)
+                        double lCm = dpp_from_lower(C[c - 1].y), rCp = dpp_from_upper(C[c + 1].x);
+                        double lP = dpp_from_lower(P[c].y), rN = dpp_from_upper(N[c].x);
+                        double lPm = dpp_from_lower(P[c - 1].y), rNp = dpp_from_upper(N[c + 1].x);
+                        lCm = (lane == 0) ? EC[c - 1] : lCm;
+                        rCp = (lane == 63) ? EC[c + 1] : rCp;
+                        lP = (lane == 0) ? EP[c] : lP;
+                        rN = (lane == 63) ? EN[c] : rN;
+                        lPm = (lane == 0) ? EP[c - 1] : lPm;
+                        rNp = (lane == 63) ? EN[c + 1] : rNp;
+                        qa += wxy * (C[c + 1].y + lCm) + wxz * (N[c].y + lP) + wyz * (N[c + 1].x + P[c - 1].x) +
+                              wxyz * (N[c + 1].y + lPm);
+                        qb += wxy * (rCp + C[c - 1].x) + wxz * (rN + P[c].x) + wyz * (N[c + 1].y + P[c - 1].y) +
+                              wxyz * (rNp + P[c - 1].x);
+                    }
+                    double2 o;
+                    if (MODE == APPLY_RESIDUAL) {
+                        o.x = ma ? RHS[r].x - qa : 0.0;
+                        o.y = mb ? RHS[r].y - qb : 0.0;
+                        acc += o.x * o.x + o.y * o.y;
+                    } else {
+                        o.x = ma ? qa : 0.0;
+                        o.y = mb ? qb : 0.0;
+                        acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
+                    }
+                    if (lane_ok)
+                        *reinterpret_cast<double2*>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0) = o;
+                }
+            }
+
+            // ---- K1: owned rows of plane lk+1: x update + p_n store ------------------------------
+            if (K1 && lk + 1 < lk1) {
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) own_update(lk + 1, j0 - 1 + r, N[r], PO[r]);
+            }
+            // ---- rotate planes -----------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                P[r] = C[r];
+                EP[r] = EC[r];
+                C[r] = N[r];
+                EC[r] = EN[r];
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+}
+
+FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
+    FastGeom fg{};
+    fg.ntx = (g.NX - 1 + 127) / 128;
+    fg.nty = (g.NY - 2 + RY - 1) / RY;
+    fg.wxt = fg.ntx >= 4 ? 4 : (fg.ntx >= 2 ? 2 : 1);
+    fg.wyt = 4 / fg.wxt;
+    fg.nxg = (fg.ntx + fg.wxt - 1) / fg.wxt;
+    fg.nyg = (fg.nty + fg.wyt - 1) / fg.wyt;
+    fg.lkb = g.k0 >= 1 ? 0 : 1 - g.k0;
+    fg.lke = (g.NZ - 1 - g.k0) < g.nkl ? (g.NZ - 1 - g.k0) : g.nkl;
+    int planes = fg.lke - fg.lkb;
+    if (planes < 0) planes = 0;
+    const int xy = fg.nxg * fg.nyg;
+    // one resident round: (workgroups that fit per CU) x CUs, at least 8 planes per chunk
+    int target = wg_per_cu * ctx->num_cu;
+    int nzc = (target + xy - 1) / xy;
+    if (nzc < 1) nzc = 1;
+    int maxc = planes / 8;
+    if (maxc < 1) maxc = 1;
+    if (nzc > maxc) nzc = maxc;
+    fg.zlen = planes > 0 ? (planes + nzc - 1) / nzc : 1;
+    fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
+    return fg;
+}
+
+template <int NPT, int RY>
+int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    static int occ[3] = {0, 0, 0};   // resident workgroups per CU of each instantiation
+    if (occ[mode] == 0) {
+        int nb = 0;
+        hipError_t e = hipSuccess;
+        switch (mode) {
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1>, 256, 0); break;
+        }
+        if (e != hipSuccess || nb < 1) nb = 2;
+        if (nb > 4) nb = 4;
+        occ[mode] = nb;
+    }
+    int wg_per_cu = occ[mode];
+    if (const char* ev = getenv("PDEGPU_FAST_WG_PER_CU")) { int v = atoi(ev); if (v >= 1 && v <= 8) wg_per_cu = v; }
+    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu);
+    const int G = fg.nxg * fg.nyg * fg.nzc;
+    if (li) { li->grid = G; li->block = 256; }
+    if (G == 0) return PDEGPU_OK;
+    switch (mode) {
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+    }
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+}  // namespace
+
+int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    const long long total = (long long)a.g.nkl * a.g.PP;
+    long long nb = (total + 255) / 256;
+    const long long cap = 8LL * ctx->num_cu;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    if (li) { li->grid = (int)nb; li->block = 256; }
+    switch (mode) {
+        case APPLY_PLAIN: hipLaunchKernelGGL(k_general<APPLY_PLAIN>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL(k_general<APPLY_RESIDUAL>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(k_general<APPLY_CG_K1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+    }
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+// fast path: 3-D, P1 split, every boundary node Dirichlet (uniform mode), at least one interior node per axis
+bool stencil_fast_supported(const GridDev& g, int element_mode) {
+    return g.dim == 3 && element_mode == PDEGPU_ELEM_P1SPLIT && g.bc_mode == PDEGPU_BC_UNIFORM && g.bc_present[0] &&
+           g.NX >= 3 && g.NY >= 3 && g.NZ >= 3;
+}
+
+int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    if (a.npt == 7) return launch_fast<7, 4>(ctx, a, mode, li);
+    return launch_fast<15, 4>(ctx, a, mode, li);
+}
+
+int stencil_max_partials(pdegpu_ctx* ctx) { return 16 * ctx->num_cu + 4096; }

@@ -1,0 +1,168 @@
+"""ctypes binding of libpdegpu.so (include/pdegpu.h).  No CPU fallback: if the HIP library is missing
+or no gfx950 device is usable, every solver entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+
+import numpy as np
+
+PKG_ROOT = Path(__file__).resolve().parent.parent          # .../pde-solver_amd
+LIB_PATH = PKG_ROOT / "lib" / "libpdegpu.so"
+
+OK, EINVAL, EHIP, ENOCONV, ENODEV, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+ELEM_P1SPLIT, ELEM_Q1 = 0, 1
+IC_CONSTANT, IC_ZERO, IC_NODAL = 0, 1, 2
+BC_UNIFORM, BC_DIRECTIONAL = 0, 1
+QUANTITY_STRESS, QUANTITY_STRAIN = 0, 1
+
+
+class PdeGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pdegpu error {code}: {msg}")
+        self.code = code
+
+
+class Grid(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n", C.c_int32 * 3), ("L", C.c_double * 3),
+                ("element_mode", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Heat(C.Structure):
+    _fields_ = [("kappa", C.c_double), ("dt", C.c_double), ("num_steps", C.c_int32), ("steady", C.c_int32),
+                ("source", C.c_double), ("ic_type", C.c_int32), ("bc_mode", C.c_int32), ("ic_value", C.c_double),
+                ("bc_value", C.c_double * 3), ("bc_present", C.c_int32 * 3), ("snapshot_stride", C.c_int32),
+                ("rtol", C.c_double), ("max_iter", C.c_int32), ("fast_path", C.c_int32)]
+
+
+class Elasticity(C.Structure):
+    _fields_ = [("E", C.c_double), ("nu", C.c_double), ("area", C.c_double), ("body", C.c_double * 3),
+                ("plane_stress", C.c_int32), ("quantity", C.c_int32), ("rtol", C.c_double),
+                ("max_iter", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_unknowns", C.c_int64), ("cg_iterations", C.c_int64),
+                ("linear_solves", C.c_int32), ("converged", C.c_int32), ("final_rel_residual", C.c_double),
+                ("solve_ms", C.c_double), ("cg_ms", C.c_double), ("kernel_ms", C.c_double * 4),
+                ("kernel_launches", C.c_int64 * 4), ("alg_bytes", C.c_double * 4), ("path", C.c_int32),
+                ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {"n_nodes": self.n_nodes, "n_unknowns": self.n_unknowns, "cg_iterations": self.cg_iterations,
+                "linear_solves": self.linear_solves, "converged": bool(self.converged),
+                "final_rel_residual": self.final_rel_residual, "solve_ms": self.solve_ms, "cg_ms": self.cg_ms,
+                "kernel_ms": list(self.kernel_ms), "kernel_launches": list(self.kernel_launches),
+                "alg_bytes": list(self.alg_bytes), "path": "fast" if self.path == 1 else "general"}
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# every symbol include/pdegpu.h declares: (restype, argtypes)
+SYMBOLS = {
+    "pdegpu_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
+    "pdegpu_destroy": (None, [_vp]),
+    "pdegpu_last_error": (C.c_char_p, [_vp]),
+    "pdegpu_device_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "pdegpu_version": (C.c_char_p, []),
+    "pdegpu_heat_num_snapshots": (C.c_int, [C.POINTER(Heat)]),
+    "pdegpu_heat_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
+    "pdegpu_mass_solve": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, C.c_double, C.c_int, C.POINTER(Stats)]),
+    "pdegpu_heat_apply": (C.c_int, [_vp, C.POINTER(Grid), C.c_double, C.c_double, _dp, _dp, _dp, C.c_int]),
+    "pdegpu_heat_tables": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, _dp]),
+    "pdegpu_heat_tables_host": (C.c_int, [C.POINTER(Grid), _dp, _dp, _dp]),
+    "pdegpu_elasticity_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp, C.POINTER(Stats)]),
+    "pdegpu_elasticity_apply": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp, C.c_int]),
+    "pdegpu_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), C.c_int64, C.c_int64, C.POINTER(_vp)]),
+    "pdegpu_session_destroy": (None, [_vp]),
+    "pdegpu_session_begin": (C.c_int, [_vp, C.c_double]),
+    "pdegpu_session_plane_ptr": (_vp, [_vp, C.c_int, C.c_int64]),
+    "pdegpu_session_plane_doubles": (C.c_int64, [_vp]),
+    "pdegpu_session_scalars": (_vp, [_vp]),
+    "pdegpu_session_residual": (C.c_int, [_vp]),
+    "pdegpu_session_k1": (C.c_int, [_vp]),
+    "pdegpu_session_k2": (C.c_int, [_vp]),
+    "pdegpu_session_reduce_local": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "pdegpu_session_flush": (C.c_int, [_vp]),
+    "pdegpu_session_iterate": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(Stats)]),
+    "pdegpu_session_rr": (C.c_int, [_vp, _dp]),
+    "pdegpu_session_get_x": (C.c_int, [_vp, _dp]),
+    "pdegpu_session_sync": (C.c_int, [_vp]),
+    "pdegpu_grid_num_nodes": (C.c_int64, [C.POINTER(Grid)]),
+    "pdegpu_slab_partition": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_ctx_cache = {}
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; fails loudly when it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise PdeGpuError(ENODEV, f"{LIB_PATH} is missing — build it with `python -c 'import "
+                                          f"__graft_entry__ as g; g.build()'` or `make -C {PKG_ROOT}`; "
+                                          "there is no CPU fallback")
+            lib = C.CDLL(str(LIB_PATH))
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(lib, name)          # AttributeError if the header and the library disagree
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def context(device: int | None = None):
+    """One pdegpu context per (process, device).  Raises if no gfx950 device is usable."""
+    lib = load_library()
+    if device is None:
+        device = int(os.environ.get("PDEGPU_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _lock:
+        ctx = _ctx_cache.get(device)
+        if ctx is None:
+            h = _vp()
+            rc = lib.pdegpu_create(C.byref(h), device, None)
+            if rc != OK:
+                raise PdeGpuError(rc, f"pdegpu_create(device={device}) failed — no usable MI355X/gfx950 device; "
+                                      "this path has no CPU fallback")
+            ctx = h
+            _ctx_cache[device] = ctx
+    return ctx
+
+
+def check(ctx, rc: int, allow=()):
+    if rc != OK and rc not in allow:
+        msg = load_library().pdegpu_last_error(ctx)
+        raise PdeGpuError(rc, msg.decode() if msg else "")
+    return rc
+
+
+def dptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def make_grid(dim, n, L, element_mode=ELEM_P1SPLIT) -> Grid:
+    g = Grid()
+    g.dim = dim
+    for r in range(3):
+        g.n[r] = int(n[r]) if r < dim else 0
+        g.L[r] = float(L[r]) if r < dim else 0.0
+    g.element_mode = element_mode
+    return g
+
+
+def element_mode_from_env() -> int:
+    """PDEGPU_ELEMENT = p1split (default, the reference's discretisation) | q1"""
+    v = os.environ.get("PDEGPU_ELEMENT", "p1split").lower()
+    if v in ("p1split", "p1"):
+        return ELEM_P1SPLIT
+    if v == "q1":
+        return ELEM_Q1
+    raise ValueError(f"PDEGPU_ELEMENT must be p1split or q1, got {v!r}")

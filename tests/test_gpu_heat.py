@@ -1,0 +1,247 @@
+"""GPU parity tests of the heat path: HIP kernels (through the C-ABI) vs the CPU oracle on the same inputs.
+Floating point (fp64): the stated tolerance is 1e-9 relative to max|u| with CG rtol 1e-12;
+operator applications are compared at 1e-13 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import fem_p1 as o
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def rel_err(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _mesh(dim, n, Ls):
+    if dim == 1:
+        return o.interval_mesh(n[0], 0.0, Ls[0])
+    if dim == 2:
+        return o.rectangle_mesh(Ls[0], Ls[1], n[0], n[1])
+    return o.box_mesh(*Ls, *n)
+
+
+def test_device_name_is_gfx950(lib, gpu_ctx):
+    buf = C.create_string_buffer(256)
+    assert lib.pdegpu_device_name(gpu_ctx, buf, 256) == 0
+    assert b"gfx950" in buf.value, buf.value
+
+
+@pytest.mark.parametrize("dim,n,Ls", [(1, (9,), (2.0,)), (2, (6, 5), (1.0, 0.5)), (3, (5, 4, 3), (1.0, 0.6, 0.25))])
+def test_device_tables_equal_host_twin(lib, gpu_ctx, dim, n, Ls):
+    from pdegpu import _lib
+    for em in (_lib.ELEM_P1SPLIT, _lib.ELEM_Q1):
+        g = _lib.make_grid(dim, n, Ls, em)
+        dev = [np.zeros(729), np.zeros(729), np.zeros(27)]
+        host = [np.zeros(729), np.zeros(729), np.zeros(27)]
+        _lib.check(gpu_ctx, lib.pdegpu_heat_tables(gpu_ctx, g, *[_lib.dptr(a) for a in dev]))
+        assert lib.pdegpu_heat_tables_host(g, *[_lib.dptr(a) for a in host]) == 0
+        for d, h in zip(dev, host):
+            assert np.abs(d - h).max() <= 1e-14 * np.abs(h).max()
+
+
+@pytest.mark.parametrize("dim,n,Ls", [(1, (37,), (2.0,)), (2, (19, 23), (1.0, 0.5)), (3, (9, 7, 6), (1.0, 0.6, 0.25)),
+                                      (3, (130, 5, 4), (2.0, 0.3, 0.2))])
+@pytest.mark.parametrize("cM,cK", [(0.0, 1.0), (1.0, 0.0), (1.0, 0.37)])
+def test_general_apply_matches_assembled_matrix(lib, gpu_ctx, dim, n, Ls, cM, cK):
+    """full-grid operator (natural boundaries everywhere) == scipy CSR SpMV of the oracle's matrices"""
+    from pdegpu import _lib
+    c, cells = _mesh(dim, n, Ls)
+    K, M, load = o.assemble_scalar(c, cells)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, c.shape[0])
+    y, ld = np.empty_like(x), np.empty_like(x)
+    g = _lib.make_grid(dim, n, Ls)
+    _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, g, cM, cK, _lib.dptr(x), _lib.dptr(y), _lib.dptr(ld), 0))
+    ref = cM * (M @ x) + cK * (K @ x)
+    assert rel_err(y, ref) < 1e-13
+    assert rel_err(ld, load) < 1e-13
+
+
+@pytest.mark.parametrize("n,Ls", [((9, 7, 6), (1.0, 0.6, 0.25)), ((130, 9, 5), (2.0, 0.3, 0.2)), ((260, 6, 11), (1.0, 1.0, 1.0)),
+                                  ((16, 16, 40), (1.0, 1.0, 1.0)), ((2, 2, 2), (1.0, 1.0, 1.0))])
+@pytest.mark.parametrize("cM,cK", [(0.0, 1.0), (1.0, 0.0), (1.0, 0.37)])
+def test_fast_apply_matches_assembled_matrix_on_free_rows(lib, gpu_ctx, n, Ls, cM, cK):
+    """fused z-marching kernel (7-point when cM == 0, 15-point otherwise; DPP x-shifts, tile edges, partial
+    tiles in x / y / z) == assembled matrix on the free rows, exactly 0 on the Dirichlet rows"""
+    from pdegpu import _lib
+    c, cells = o.box_mesh(*Ls, *n)
+    K, M, _ = o.assemble_scalar(c, cells)
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, c.shape[0])
+    y = np.empty_like(x)
+    g = _lib.make_grid(3, n, Ls)
+    _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, g, cM, cK, _lib.dptr(x), _lib.dptr(y), None, 1))
+    mask, _ = o.box_dirichlet(*n, T_boundary=0.0)
+    ref = cM * (M @ x) + cK * (K @ x)
+    ref[mask] = 0.0
+    assert np.all(y[mask] == 0.0)
+    assert rel_err(y, ref) < 1e-13
+
+
+def test_heat_1d_config1_matches_oracle(lib, gpu_ctx):
+    """BASELINE config 1 kwargs, shortened to 25 steps for the GPU suite; plus the
+    known steady answers"""
+    from pdegpu import heat
+    got = heat._solve_heat_1d_raw(2.0, 1000, 1.0, 20.0, 0.0, 0.0, 0.01, 25, rtol=1e-12)
+    ref = o.solve_heat_1d(2.0, 1000, 1.0, 20.0, 0.0, 0.0, 0.01, 25)
+    assert got.values.shape == (26, 1001) and np.allclose(got.times, ref.times)
+    assert np.array_equal(got.coords, ref.coords)
+    assert rel_err(got.values, ref.values) < TOL
+    st = heat._solve_heat_1d_raw(2.0, 64, 0.7, 5.0, -1.0, 0.0, 0.01, 3, steady=True, source_type="constant",
+                                 source_value=3.0, rtol=1e-13)
+    x = st.coords[:, 0]
+    assert np.abs(st.values[0] - (5.0 - 3.0 * x + 3.0 * x * (2.0 - x) / 1.4)).max() < 1e-9
+    assert st.times.tolist() == [0.0] and st.meta["steady"] is True
+
+
+@pytest.mark.parametrize("steady", [False, True])
+def test_heat_2d_matches_oracle(lib, gpu_ctx, steady):
+    from pdegpu import heat
+    kw = dict(Lx=1.0, Ly=0.5, nx=24, ny=17, diffusivity=0.8, T_boundary=3.0, T_initial=20.0, dt=0.004, num_steps=4,
+              steady=steady, source_type="constant", source_value=5.0)
+    got = heat._solve_heat_2d_raw(**kw, rtol=1e-12)
+    ref = o.solve_heat_2d(**kw)
+    assert got.values.shape == ref.values.shape
+    assert np.allclose(got.coords, ref.coords, atol=1e-15)
+    assert rel_err(got.values, ref.values) < TOL
+    assert set(ref.meta) <= set(got.meta)
+
+
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("steady", [False, True])
+def test_heat_3d_uniform_bc_matches_oracle(lib, gpu_ctx, fast, steady):
+    from pdegpu import heat
+    kw = dict(Lx=1.0, Ly=0.8, Lz=0.5, nx=14, ny=11, nz=9, diffusivity=1.2, T_boundary=2.0, T_initial=20.0, dt=0.003,
+              num_steps=3, steady=steady, source_type="constant", source_value=4.0)
+    got = heat._solve_heat_3d_raw(**kw, rtol=1e-12, fast_path=fast)
+    ref = o.solve_heat_3d(**kw)
+    assert got.meta["solver_path"] == ("fast" if fast else "general")
+    assert np.allclose(got.coords, ref.coords, atol=1e-15)
+    assert rel_err(got.values, ref.values) < TOL
+    for k in ("name", "unit", "pde", "coordinate_system", "Lx", "Ly", "Lz", "geometry_type", "T_boundary", "diffusivity"):
+        assert got.meta[k] == ref.meta[k]
+
+
+def test_heat_3d_wide_grid_fast_path(lib, gpu_ctx):
+    """several 128-node x-tiles and a ragged last tile; two z-chunks"""
+    from pdegpu import heat
+    kw = dict(Lx=2.0, Ly=0.3, Lz=0.4, nx=150, ny=6, nz=20, diffusivity=1.0, T_boundary=0.0, T_initial=20.0, dt=0.002,
+              num_steps=2)
+    got = heat._solve_heat_3d_raw(**kw, rtol=1e-12)
+    ref = o.solve_heat_3d(**kw)
+    assert got.meta["solver_path"] == "fast"
+    assert rel_err(got.values, ref.values) < TOL
+
+
+@pytest.mark.parametrize("bcs", [dict(T_left=10.0, T_right=1.0, T_side=None), dict(T_left=10.0, T_right=None, T_side=3.0),
+                                 dict(T_left=None, T_right=4.0, T_side=None), dict(T_left=5.0, T_right=6.0, T_side=7.0)])
+def test_heat_3d_directional_bc_natural_faces(lib, gpu_ctx, bcs):
+    """faces left natural use the truncated class stencils (fenics_mcp_server.py:606-623)"""
+    from pdegpu import heat
+    kw = dict(Lx=1.0, Ly=0.5, Lz=0.4, nx=9, ny=6, nz=5, diffusivity=1.0, T_boundary=0.0, T_initial=2.0, dt=0.01,
+              num_steps=3, source_type="constant", source_value=1.5, **bcs)
+    got = heat._solve_heat_3d_raw(**kw, rtol=1e-12)
+    ref = o.solve_heat_3d(**kw)
+    assert got.meta["solver_path"] == "general"
+    assert rel_err(got.values, ref.values) < TOL
+    for k, v in bcs.items():
+        assert (k in got.meta) == (v is not None)
+    assert "T_boundary" not in got.meta
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["sine", "cosine"])
+def test_projected_trig_initial_condition(lib, gpu_ctx, dim, kind):
+    """initial_type sine/cosine = project(Expression(degree=2), V) then bc.apply (:278-297)"""
+    from pdegpu import heat
+    common = dict(dt=0.005, num_steps=2, initial_type=kind, initial_amplitude=2.0, initial_wavenumber=3.0)
+    if dim == 1:
+        got = heat._solve_heat_1d_raw(2.0, 40, 1.0, 1.0, 0.5, 0.0, rtol=1e-12, **common)
+        ref = o.solve_heat_1d(2.0, 40, 1.0, 1.0, 0.5, 0.0, **common)
+    elif dim == 2:
+        got = heat._solve_heat_2d_raw(1.0, 1.5, 12, 10, 1.0, 0.25, 0.0, rtol=1e-12, **common)
+        ref = o.solve_heat_2d(1.0, 1.5, 12, 10, 1.0, 0.25, 0.0, **common)
+    else:
+        got = heat._solve_heat_3d_raw(1.0, 1.5, 0.5, 8, 7, 6, 1.0, 0.25, 0.0, rtol=1e-12, **common)
+        ref = o.solve_heat_3d(1.0, 1.5, 0.5, 8, 7, 6, 1.0, 0.25, 0.0, **common)
+    assert rel_err(got.values[0], ref.values[0]) < TOL          # the projected IC itself
+    assert rel_err(got.values, ref.values) < TOL
+
+
+def test_trivial_and_edge_cases(lib, gpu_ctx):
+    from pdegpu import heat, _lib
+    # steady, all-Dirichlet, no source: u == T_b exactly; CG takes zero iterations
+    f = heat._solve_heat_3d_raw(1, 1, 1, 8, 8, 8, 1.0, 7.5, 0.0, 0.1, 1, steady=True)
+    assert np.all(f.values[0] == 7.5) and f.meta["cg_iterations"] == 0
+    # smallest grids: one cell per axis has no free node
+    f = heat._solve_heat_3d_raw(1, 1, 1, 1, 1, 1, 1.0, 2.0, 9.0, 0.1, 2)
+    assert f.values.shape == (3, 8) and np.all(f.values == 2.0)
+    f = heat._solve_heat_1d_raw(1.0, 1, 1.0, 3.0, 4.0, 0.0, 0.1, 2)
+    assert np.array_equal(f.values, [[3.0, 4.0]] * 3)
+    # num_steps = 0: only the initial state
+    f = heat._solve_heat_2d_raw(1, 1, 4, 4, 1.0, 1.0, 5.0, 0.1, 0)
+    assert f.values.shape == (1, 25) and f.times.tolist() == [0.0]
+    # snapshot stride keeps state 0, every stride-th and the last state
+    full = heat._solve_heat_3d_raw(1, 1, 1, 6, 6, 6, 1.0, 0.0, 20.0, 0.01, 5, rtol=1e-12)
+    part = heat._solve_heat_3d_raw(1, 1, 1, 6, 6, 6, 1.0, 0.0, 20.0, 0.01, 5, rtol=1e-12, snapshot_stride=2)
+    assert np.allclose(part.times, [0.0, 0.02, 0.04, 0.05])
+    assert np.array_equal(part.values, full.values[[0, 2, 4, 5]])
+    # invalid arguments come back as errors, not crashes
+    with pytest.raises(_lib.PdeGpuError):
+        heat._solve_heat_3d_raw(1, 1, 1, 0, 4, 4, 1.0, 0.0, 20.0, 0.01, 1)
+    with pytest.raises(_lib.PdeGpuError):
+        heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, -1.0, 0.0, 20.0, 0.01, 1)
+    with pytest.raises(NotImplementedError):
+        heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 1, geometry_type="cylinder", cylinder_radius=0.5)
+
+
+def test_q1_mode_differs_by_h2(lib, gpu_ctx):
+    """Q1 element mode (BASELINE.json wording) vs the reference's P1 split: O(h^2) apart, not equal"""
+    from pdegpu import heat, _lib
+    errs = []
+    for n in (8, 16):
+        kw = dict(Lx=1.0, Ly=1.0, Lz=1.0, nx=n, ny=n, nz=n, diffusivity=1.0, T_boundary=0.0, T_initial=20.0, dt=0.01,
+                  num_steps=5)
+        q1 = heat._solve_heat_3d_raw(**kw, rtol=1e-12, element_mode=_lib.ELEM_Q1)
+        ref = o.solve_heat_3d(**kw)
+        assert q1.meta["element_mode"] == "q1" and q1.meta["solver_path"] == "general"
+        errs.append(rel_err(q1.values[-1], ref.values[-1]))
+    assert 1e-4 < errs[1] < errs[0] < 0.1
+    assert errs[0] / errs[1] > 2.5
+
+
+def test_fast_and_general_sessions_agree(lib, gpu_ctx):
+    """same CG iterates from the fused z-marching kernels and from the class-table kernels"""
+    from pdegpu import _lib
+    grid = _lib.make_grid(3, (40, 21, 18), (1.0, 1.0, 1.0))
+    out = []
+    for fast in (1, 0):
+        h = _lib.Heat()
+        h.kappa, h.dt, h.steady, h.source = 1.0, 1.0, 1, 1.0
+        h.bc_mode, h.fast_path = _lib.BC_UNIFORM, fast
+        h.bc_present[0] = 1
+        s = C.c_void_p()
+        _lib.check(gpu_ctx, lib.pdegpu_session_create(gpu_ctx, grid, h, 0, 19, C.byref(s)))
+        try:
+            _lib.check(gpu_ctx, lib.pdegpu_session_begin(s, 0.0))
+            _lib.check(gpu_ctx, lib.pdegpu_session_residual(s))
+            _lib.check(gpu_ctx, lib.pdegpu_session_reduce_local(s, 1, 1))
+            st = _lib.Stats()
+            _lib.check(gpu_ctx, lib.pdegpu_session_iterate(s, 12, 1, st))
+            rr = C.c_double()
+            _lib.check(gpu_ctx, lib.pdegpu_session_rr(s, C.byref(rr)))
+            _lib.check(gpu_ctx, lib.pdegpu_session_flush(s))
+            x = np.empty(41 * 22 * 19)
+            _lib.check(gpu_ctx, lib.pdegpu_session_get_x(s, _lib.dptr(x)))
+            assert st.kernel_ms[0] > 0 and st.kernel_ms[1] > 0 and st.kernel_launches[0] == 12
+            assert st.path == fast
+            out.append((rr.value, x))
+        finally:
+            lib.pdegpu_session_destroy(s)
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-10)
+    assert rel_err(out[0][1], out[1][1]) < 1e-11

@@ -1,0 +1,166 @@
+"""CPU-only checks of the product's host logic and of the C-ABI library itself (no compute on a GPU):
+the library loads and exports every symbol include/pdegpu.h declares, the device's macro-element
+integration (run through its host twin, same source) agrees with the oracle's assembled matrices for
+every boundary class, the slab partition is a partition, and the host-side load vector of
+project(Expression(degree=2)) agrees with the oracle."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import fem_p1 as o
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from pdegpu import _lib
+    header = (ROOT / "include" / "pdegpu.h").read_text()
+    declared = set(re.findall(r"\b(pdegpu_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pdegpu_ctx", "pdegpu_session"}
+    assert declared, "no declarations found"
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared in pdegpu.h but not exported by libpdegpu.so: {missing}"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert b"gfx950" in lib.pdegpu_version()
+
+
+def test_struct_layout_matches_header(lib):
+    from pdegpu import _lib
+    assert C.sizeof(_lib.Grid) == 48
+    assert C.sizeof(_lib.Heat) == 8 * 2 + 8 + 8 + 8 + 8 + 24 + 12 + 4 + 8 + 8
+    assert C.sizeof(_lib.Stats) == 8 * 3 + 8 + 8 * 3 + 32 + 32 + 32 + 8
+
+
+def _class_node(c, n):
+    return {0: 0, 1: 1, 2: n}[c]
+
+
+@pytest.mark.parametrize("dim,n,Ls", [(1, (3,), (2.0,)), (2, (3, 2), (1.0, 0.5)), (3, (2, 3, 2), (1.0, 0.6, 0.25))])
+def test_device_tables_match_oracle_assembly(lib, dim, n, Ls):
+    """every (boundary class, offset) weight of the class tables == the assembled matrix entry"""
+    from pdegpu import _lib
+    g = _lib.make_grid(dim, n, Ls, _lib.ELEM_P1SPLIT)
+    tK, tM, ld = np.zeros(729), np.zeros(729), np.zeros(27)
+    assert lib.pdegpu_heat_tables_host(g, _lib.dptr(tK), _lib.dptr(tM), _lib.dptr(ld)) == 0
+    tK, tM = tK.reshape(27, 27), tM.reshape(27, 27)
+    if dim == 1:
+        c, cells = o.interval_mesh(n[0], 0.0, Ls[0])
+    elif dim == 2:
+        c, cells = o.rectangle_mesh(Ls[0], Ls[1], n[0], n[1])
+    else:
+        c, cells = o.box_mesh(*Ls, *n)
+    K, M, load = o.assemble_scalar(c, cells)
+    K, M = K.toarray(), M.toarray()
+    nn = [n[r] + 1 if r < dim else 1 for r in range(3)]
+    scaleK, scaleM = np.abs(K).max(), np.abs(M).max()
+    checked = 0
+    for cls in range(27):
+        cc = (cls % 3, (cls // 3) % 3, cls // 9)
+        if any(cc[r] != 1 for r in range(dim, 3)):
+            continue                                    # classes of unused axes are never looked up
+        idx3 = [_class_node(cc[r], n[r]) if r < dim else 0 for r in range(3)]
+        if any(r < dim and n[r] < 2 and cc[r] == 1 for r in range(3)):
+            continue
+        row = idx3[0] + nn[0] * (idx3[1] + nn[1] * idx3[2])
+        assert ld[cls] == pytest.approx(load[row], rel=1e-13)
+        for off in range(27):
+            d = (off % 3 - 1, (off // 3) % 3 - 1, off // 9 - 1)
+            nb = [idx3[r] + d[r] for r in range(3)]
+            inside = all(0 <= nb[r] < nn[r] for r in range(3))
+            if not inside:
+                assert tK[cls, off] == 0.0 and tM[cls, off] == 0.0
+                continue
+            col = nb[0] + nn[0] * (nb[1] + nn[1] * nb[2])
+            assert tK[cls, off] == pytest.approx(K[row, col], abs=1e-13 * scaleK)
+            assert tM[cls, off] == pytest.approx(M[row, col], abs=1e-13 * scaleM)
+            checked += 1
+    assert checked >= 3 ** dim * 2
+
+
+def test_q1_tables_are_consistent(lib):
+    from pdegpu import _lib
+    g = _lib.make_grid(3, (4, 4, 4), (1.0, 1.0, 1.0), _lib.ELEM_Q1)
+    tK, tM, ld = np.zeros(729), np.zeros(729), np.zeros(27)
+    assert lib.pdegpu_heat_tables_host(g, _lib.dptr(tK), _lib.dptr(tM), _lib.dptr(ld)) == 0
+    h = 0.25
+    k = tK.reshape(27, 27)[13] / h
+    # classic trilinear stencil: centre 8/3, faces 0, edges -1/6, corners -1/12
+    for off in range(27):
+        d = (off % 3 - 1, (off // 3) % 3 - 1, off // 9 - 1)
+        nnz = sum(abs(v) for v in d)
+        assert k[off] == pytest.approx({0: 8 / 3, 1: 0.0, 2: -1 / 6, 3: -1 / 12}[nnz], abs=1e-13)
+    m = tM.reshape(27, 27)[13] / h ** 3 * 216
+    for off in range(27):
+        d = (off % 3 - 1, (off // 3) % 3 - 1, off // 9 - 1)
+        assert m[off] == pytest.approx({0: 64, 1: 16, 2: 4, 3: 1}[sum(abs(v) for v in d)], abs=1e-10)
+    assert ld[13] == pytest.approx(h ** 3) and ld[0] == pytest.approx(h ** 3 / 8)
+    assert abs(tK.reshape(27, 27).sum(axis=1)).max() < 1e-12          # constants in the null space, every class
+
+
+def test_tables_host_rejects_bad_grid(lib):
+    from pdegpu import _lib
+    g = _lib.make_grid(3, (4, 0, 4), (1.0, 1.0, 1.0))
+    buf = np.zeros(729)
+    assert lib.pdegpu_heat_tables_host(g, _lib.dptr(buf), _lib.dptr(buf.copy()), _lib.dptr(np.zeros(27))) == _lib.EINVAL
+    assert lib.pdegpu_grid_num_nodes(g) == -1
+    assert lib.pdegpu_grid_num_nodes(_lib.make_grid(3, (512, 512, 512), (1, 1, 1))) == 513 ** 3
+
+
+@pytest.mark.parametrize("planes,ranks", [(513, 1), (513, 2), (513, 8), (1025, 8), (7, 3), (8, 8)])
+def test_slab_partition_is_a_partition(lib, planes, ranks):
+    k0, nk = C.c_int64(), C.c_int64()
+    nxt = 0
+    sizes = []
+    for r in range(ranks):
+        assert lib.pdegpu_slab_partition(planes, ranks, r, C.byref(k0), C.byref(nk)) == 0
+        assert k0.value == nxt and nk.value >= 1
+        nxt += nk.value
+        sizes.append(nk.value)
+    assert nxt == planes and max(sizes) - min(sizes) <= 1
+    assert lib.pdegpu_slab_partition(planes, ranks, ranks, C.byref(k0), C.byref(nk)) != 0
+
+
+def test_num_snapshots(lib):
+    from pdegpu import _lib
+    h = _lib.Heat()
+    h.num_steps, h.snapshot_stride = 200, 1
+    assert lib.pdegpu_heat_num_snapshots(h) == 201
+    h.snapshot_stride = 50
+    assert lib.pdegpu_heat_num_snapshots(h) == 5
+    h.snapshot_stride = 64
+    assert lib.pdegpu_heat_num_snapshots(h) == 5          # 0, 64, 128, 192 and the last state 200
+    h.steady = 1
+    assert lib.pdegpu_heat_num_snapshots(h) == 1
+
+
+@pytest.mark.parametrize("dim,n,Ls", [(1, (7,), (2.0,)), (2, (5, 4), (1.0, 2.0)), (3, (3, 4, 2), (1.0, 0.5, 2.0))])
+@pytest.mark.parametrize("kind", ["cosine", "sine"])
+def test_p2_expression_load_matches_oracle(dim, n, Ls, kind):
+    from pdegpu.project import p2_expression_load, trig_product
+    import scipy.sparse.linalg as spla
+    A, k = 1.7, 2.3
+    b = p2_expression_load(dim, n, Ls, trig_product(kind, A, k, dim))
+    if dim == 1:
+        c, cells = o.interval_mesh(n[0], 0.0, Ls[0])
+    elif dim == 2:
+        c, cells = o.rectangle_mesh(Ls[0], Ls[1], n[0], n[1])
+    else:
+        c, cells = o.box_mesh(*Ls, *n)
+    _, M, _ = o.assemble_scalar(c, cells)
+    f = np.cos if kind == "cosine" else np.sin
+    ref = o._project_p2_expression(c, cells, lambda X: A * np.prod(f(k * X), axis=1), M)
+    got = spla.splu(M.tocsc()).solve(b)
+    assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_no_gpu_fails_loudly(lib):
+    """without a device the product path raises — there is no CPU fallback"""
+    import torch
+    from pdegpu import _lib, heat
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.PdeGpuError):
+        heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 1)
