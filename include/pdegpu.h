@@ -187,6 +187,10 @@ int  pdegpu_session_flush(pdegpu_session* s);               /* pending x += alph
  * If time_kernels != 0, brackets every launch with hipEvents and accumulates stats->kernel_ms. */
 int  pdegpu_session_iterate(pdegpu_session* s, int iters, int time_kernels, pdegpu_stats* stats);
 int  pdegpu_session_rr(pdegpu_session* s, double* rr_out);  /* synchronises; global r.r */
+/* roofline harness: average device time (ms, hipEvents on the context stream) of `reps` launches of the bare
+ * operator application b = A r (the matrix-free SpMV alone: read one vector, write one, 16 B/DoF).
+ * Overwrites b; call after the solve. */
+int  pdegpu_session_time_apply(pdegpu_session* s, int reps, double* avg_ms_out);
 int  pdegpu_session_get_x(pdegpu_session* s, double* x_out /* host [nk][plane nodes] */);
 int  pdegpu_session_sync(pdegpu_session* s);
 

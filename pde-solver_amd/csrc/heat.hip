@@ -418,6 +418,26 @@ extern "C" int pdegpu_session_rr(pdegpu_session* s, double* rr_out) {
     return PDEGPU_OK;
 }
 
+extern "C" int pdegpu_session_time_apply(pdegpu_session* s, int reps, double* avg_ms_out) {
+    if (!s || reps < 1 || !avg_ms_out) return PDEGPU_EINVAL;
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    PG_HIP(ctx, hipEventCreate(&e0));
+    PG_HIP(ctx, hipEventCreate(&e1));
+    PG_TRY(op_plain(s, 0, s->r.v, 0.0, s->b.v, 1));          // warm-up
+    PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; ++i) PG_TRY(op_plain(s, 0, s->r.v, 0.0, s->b.v, 1));
+    PG_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    PG_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms_out = ms / reps;
+    return PDEGPU_OK;
+}
+
 extern "C" int pdegpu_session_sync(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));

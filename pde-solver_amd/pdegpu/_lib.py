@@ -89,6 +89,7 @@ SYMBOLS = {
     "pdegpu_session_flush": (C.c_int, [_vp]),
     "pdegpu_session_iterate": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(Stats)]),
     "pdegpu_session_rr": (C.c_int, [_vp, _dp]),
+    "pdegpu_session_time_apply": (C.c_int, [_vp, C.c_int, _dp]),
     "pdegpu_session_get_x": (C.c_int, [_vp, _dp]),
     "pdegpu_session_sync": (C.c_int, [_vp]),
     "pdegpu_grid_num_nodes": (C.c_int64, [C.POINTER(Grid)]),
