@@ -153,6 +153,8 @@ int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdeg
                             double* field_out, double* disp_out, pdegpu_stats* stats);
 int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el,
                             const double* u, double* y, int use_mfma);
+/* host twin of the device fold of the d x d block class table, tab [27 classes][15 offsets][3x3] (CPU tests) */
+int pdegpu_elasticity_tables_host(const pdegpu_grid* grid, double lam, double mu, double* tab);
 
 /* ---- slab-resident CG session: the unit the benchmark and the multi-GPU driver step -------------
  * A session owns the device vectors of ONE slab of a 3-D (or 2-D) heat system

@@ -76,6 +76,7 @@ SYMBOLS = {
     "pdegpu_heat_tables_host": (C.c_int, [C.POINTER(Grid), _dp, _dp, _dp]),
     "pdegpu_elasticity_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_elasticity_apply": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp, C.c_int]),
+    "pdegpu_elasticity_tables_host": (C.c_int, [C.POINTER(Grid), C.c_double, C.c_double, _dp]),
     "pdegpu_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "pdegpu_session_destroy": (None, [_vp]),
     "pdegpu_session_begin": (C.c_int, [_vp, C.c_double]),

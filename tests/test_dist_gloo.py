@@ -1,0 +1,96 @@
+"""N>1 path on CPU: pdegpu.dist.SlabCG (the product's multi-GPU driver) under torch.distributed `gloo`,
+world sizes 1, 2 and 3, with the numpy slab engine of tests/slab_engine_numpy.py standing in for the HIP
+session.  Checks that the slab-decomposed CG reproduces (a) the single-rank iterates and (b) the oracle's
+solution of the same system."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+N_CELLS, LS, KAPPA, SRC, TB = (7, 6, 11), (1.0, 0.8, 1.5), 1.3, 2.0, 0.5
+ITERS = 120
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, outdir):
+    for p in (ROOT, ROOT / "pde-solver_amd", ROOT / "tests"):
+        if str(p) not in sys.path:
+            sys.path.insert(0, str(p))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pdegpu.dist import SlabCG, slab_range
+        from slab_engine_numpy import NumpySlabEngine
+        k0, nk = slab_range(N_CELLS[2] + 1, world, rank)
+        eng = NumpySlabEngine(N_CELLS, LS, KAPPA, SRC, TB, k0, nk)
+        cg = SlabCG(eng, rank, world)
+        cg.start(0.0)
+        rr0 = float(eng.scalars()[3])
+        cg.iterate(5)
+        rr5 = float(eng.scalars()[3])
+        cg.iterate(ITERS - 5)
+        rr_end = float(eng.scalars()[3])
+        cg.finish()
+        np.savez(Path(outdir) / f"rank{rank}.npz", x=eng.owned_x(), k0=k0, nk=nk, rr=np.array([rr0, rr5, rr_end]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, tmp_path):
+    out = tmp_path / f"w{world}"
+    out.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    parts = [np.load(out / f"rank{r}.npz") for r in range(world)]
+    assert sum(int(p["nk"]) for p in parts) == N_CELLS[2] + 1
+    x = np.concatenate([p["x"] for p in parts], axis=0)
+    for p in parts[1:]:
+        assert np.array_equal(p["rr"], parts[0]["rr"])            # every rank sees the same all-reduced scalars
+    return x, parts[0]["rr"]
+
+
+@pytest.mark.timeout(300)
+def test_slab_cg_world_1_2_3_agree_and_match_oracle(tmp_path):
+    from oracle import fem_p1 as o
+    x1, rr1 = _run(1, tmp_path)
+    ref = o.solve_heat_3d(*LS, *N_CELLS, KAPPA, TB, 0.0, 0.1, 1, steady=True, source_type="constant", source_value=SRC)
+    ref = ref.values[0].reshape(x1.shape)
+    assert np.abs(x1 - ref).max() < 1e-9 * np.abs(ref).max()
+    assert rr1[2] < 1e-20 * rr1[0]
+    for world in (2, 3):
+        xw, rrw = _run(world, tmp_path)
+        assert np.allclose(rrw[:2], rr1[:2], rtol=1e-11)           # same iterates up to summation order
+        assert np.abs(xw - ref).max() < 1e-9 * np.abs(ref).max()
+        assert np.abs(xw - x1).max() < 1e-11 * np.abs(ref).max()
+
+
+def test_slab_engine_matches_c_port():
+    """the numpy engine itself is checked against the oracle's C port (same CG, rr history)"""
+    for p in (ROOT / "tests",):
+        if str(p) not in sys.path:
+            sys.path.insert(0, str(p))
+    from oracle import cg_port
+    from pdegpu.dist import SlabCG
+    from slab_engine_numpy import NumpySlabEngine
+    eng = NumpySlabEngine(N_CELLS, LS, KAPPA, SRC, TB, 0, N_CELLS[2] + 1)
+    cg = SlabCG(eng, 0, 1)
+    cg.start(0.0)
+    hist = [float(eng.scalars()[3])]
+    for _ in range(10):
+        cg.iterate(1)
+        hist.append(float(eng.scalars()[3]))
+    h = [LS[r] / N_CELLS[r] for r in range(3)]
+    _, rr, _ = cg_port.run(tuple(n + 1 for n in N_CELLS), cg_port.p1_weights(h, 0.0, KAPPA), SRC * h[0] * h[1] * h[2], TB, 10)
+    assert np.allclose(hist, rr, rtol=1e-10)

@@ -1,0 +1,87 @@
+"""GPU parity tests of the static elasticity path vs the CPU oracle (fp64; tolerance 1e-8 relative to the field
+maximum with PCG rtol 1e-12: the clamped cantilever systems have condition numbers of 1e4-1e6)."""
+import numpy as np
+import pytest
+
+from oracle import fem_p1 as o
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def rel_err(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("dim,n,Ls", [(2, (9, 7), (1.0, 0.5)), (3, (6, 5, 4), (1.0, 0.6, 0.25)), (3, (70, 3, 2), (2.0, 0.3, 0.2))])
+@pytest.mark.parametrize("plane_stress", [True, False])
+def test_block_operator_matches_assembled_matrix(lib, gpu_ctx, dim, n, Ls, plane_stress):
+    from pdegpu import _lib
+    if dim == 3 and plane_stress:
+        pytest.skip("plane stress is a 2-D notion")
+    E, nu = 210e9, 0.3
+    lam, mu = o.lame(E, nu, plane_stress and dim == 2)
+    c, cells = o.rectangle_mesh(Ls[0], Ls[1], n[0], n[1]) if dim == 2 else o.box_mesh(*Ls, *n)
+    K = o.assemble_elasticity(c, cells, lam, mu)
+    rng = np.random.default_rng(3)
+    u = rng.uniform(-1, 1, (c.shape[0], dim))
+    y = np.empty_like(u)
+    el = _lib.Elasticity()
+    el.E, el.nu, el.plane_stress = E, nu, int(plane_stress)
+    g = _lib.make_grid(dim, n, Ls)
+    _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 0))
+    ref = (K @ u.ravel()).reshape(-1, dim)
+    assert rel_err(y, ref) < 1e-12
+
+
+@pytest.mark.parametrize("quantity", ["stress", "strain"])
+def test_bar_1d_matches_oracle(lib, gpu_ctx, quantity):
+    from pdegpu import elasticity
+    got = elasticity._solve_elasticity_1d_static(2.0, 40, 210e9, 0.5, 1.0e4, quantity, rtol=1e-13, want_displacement=True)
+    ref = o.solve_elasticity_1d(2.0, 40, 210e9, 0.5, 1.0e4, quantity)
+    assert got.values.shape == (1, 41) and got.times.tolist() == [0.0]
+    assert rel_err(got.displacement[:, 0], ref.extra["displacement"]) < TOL
+    assert rel_err(got.values, ref.values) < TOL
+    for k, v in ref.meta.items():
+        assert got.meta[k] == v
+
+
+@pytest.mark.parametrize("plane_stress", [True, False])
+@pytest.mark.parametrize("quantity", ["stress", "strain"])
+def test_elasticity_2d_matches_oracle(lib, gpu_ctx, plane_stress, quantity):
+    from pdegpu import elasticity
+    kw = dict(Lx=1.0, Ly=0.4, nx=16, ny=7, E=210e9, nu=0.3, body_fx=1.0e4, body_fy=-76518.0, quantity=quantity,
+              plane_stress=plane_stress)
+    got = elasticity._solve_elasticity_2d_static(**kw, rtol=1e-12, want_displacement=True)
+    ref = o.solve_elasticity_2d(**kw)
+    assert rel_err(got.displacement, ref.extra["displacement"]) < TOL
+    assert rel_err(got.values, ref.values) < TOL
+    for k, v in ref.meta.items():
+        assert got.meta[k] == v
+
+
+@pytest.mark.parametrize("quantity", ["stress", "strain"])
+def test_elasticity_3d_matches_oracle(lib, gpu_ctx, quantity):
+    """scaled-down BASELINE config 5: cantilever under gravity (dispatcher default body_fz = -9.81*7800)"""
+    from pdegpu import elasticity
+    kw = dict(Lx=1.0, Ly=0.25, Lz=0.25, nx=16, ny=4, nz=4, E=210e9, nu=0.3, body_fx=0.0, body_fy=0.0, body_fz=-76518.0,
+              quantity=quantity)
+    got = elasticity._solve_elasticity_3d_static(**kw, rtol=1e-12, want_displacement=True)
+    ref = o.solve_elasticity_3d(**kw)
+    assert np.allclose(got.coords, ref.coords, atol=1e-15)
+    assert rel_err(got.displacement, ref.extra["displacement"]) < TOL
+    assert rel_err(got.values, ref.values) < TOL
+    for k, v in ref.meta.items():
+        assert got.meta[k] == v
+
+
+def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
+    from pdegpu import elasticity, _lib
+    f = elasticity._solve_elasticity_3d_static(1, 1, 1, 4, 4, 4, 210e9, 0.3)          # no load -> u = 0 (:2639-2642)
+    assert np.all(f.values == 0.0) and f.meta["cg_iterations"] == 0
+    f = elasticity._solve_elasticity_2d_static(1, 1, 4, 4, 210e9, 0.3, quantity="strain")
+    assert np.all(f.values == 0.0)
+    with pytest.raises(_lib.PdeGpuError):
+        elasticity._solve_elasticity_3d_static(1, 1, 1, 4, 4, 4, 210e9, 0.5, body_fz=-1.0)   # incompressible limit
+    with pytest.raises(_lib.PdeGpuError):
+        elasticity._solve_elasticity_2d_static(1, 1, 0, 4, 210e9, 0.3)

@@ -248,3 +248,77 @@ def test_fast_and_general_sessions_agree(lib, gpu_ctx):
             lib.pdegpu_session_destroy(s)
     assert out[0][0] == pytest.approx(out[1][0], rel=1e-10)
     assert rel_err(out[0][1], out[1][1]) < 1e-11
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("nslabs", [2, 3])
+def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, nslabs):
+    """slab sessions (k0 > 0, ghost planes, global boundary classes) with the halo exchange / all-reduce done by
+    plain device copies on ONE GPU: same order of operations as pdegpu.dist.SlabCG.iterate, no RCCL needed.
+    Must reproduce the single-slab CG iterates and the oracle's solution."""
+    import torch
+    from pdegpu import _lib
+    from pdegpu.dist import GpuSlabEngine, slab_range, VEC_R, VEC_P, SC_PQ, SC_RR
+    n, Ls = (20, 9, 13), (1.0, 0.7, 1.2)
+    grid = _lib.make_grid(3, n, Ls)
+    h = _lib.Heat()
+    h.kappa, h.steady, h.source = 1.1, 1, 3.0
+    h.bc_mode, h.fast_path = _lib.BC_UNIFORM, fast
+    h.bc_present[0], h.bc_value[0] = 1, 0.25
+    iters = 150
+
+    def solve(ns):
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            engs = []
+            for r in range(ns):
+                k0, nk = slab_range(n[2] + 1, ns, r)
+                engs.append(GpuSlabEngine(grid, h, k0, nk, 0, stream))
+
+            def exchange():
+                for v in (VEC_R, VEC_P):
+                    for r in range(ns - 1):
+                        lo, hi = engs[r], engs[r + 1]
+                        hi.plane_tensor(v, -1).copy_(lo.plane_tensor(v, lo.nk - 1))
+                        lo.plane_tensor(v, lo.nk).copy_(hi.plane_tensor(v, 0))
+
+            def allreduce(which):
+                slot = SC_PQ if which == 0 else SC_RR
+                for e in engs:
+                    e.local_to_global(which)
+                tot = sum(e.scalars()[slot:slot + 1].clone() for e in engs)
+                for e in engs:
+                    e.scalars()[slot:slot + 1].copy_(tot)
+
+            for e in engs:
+                e.begin(0.0)
+                e.residual()
+            allreduce(1)
+            hist = [engs[0].rr()]
+            for it in range(iters):
+                exchange()
+                for e in engs:
+                    e.k1()
+                allreduce(0)
+                for e in engs:
+                    e.k2()
+                allreduce(1)
+                if it < 6:
+                    hist.append(engs[0].rr())
+            xs = []
+            for e in engs:
+                e.flush()
+                x = np.empty(e.nk * (n[1] + 1) * (n[0] + 1))
+                _lib.check(e.ctx, lib.pdegpu_session_get_x(e.s, _lib.dptr(x)))
+                xs.append(x)
+                assert e.lib.pdegpu_session_plane_doubles(e.s) == e.plane
+            for e in engs:
+                e.close()
+        return np.concatenate(xs), np.array(hist)
+
+    x1, h1 = solve(1)
+    xs, hs = solve(nslabs)
+    ref = o.solve_heat_3d(*Ls, *n, 1.1, 0.25, 0.0, 0.1, 1, steady=True, source_type="constant", source_value=3.0).values[0]
+    assert np.allclose(hs, h1, rtol=1e-10)
+    assert rel_err(x1, ref) < TOL and rel_err(xs, ref) < TOL
+    assert rel_err(xs, x1) < 1e-11

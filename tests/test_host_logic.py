@@ -164,3 +164,38 @@ def test_no_gpu_fails_loudly(lib):
         pytest.skip("a GPU is present")
     with pytest.raises(_lib.PdeGpuError):
         heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 1)
+
+
+@pytest.mark.parametrize("dim,n,Ls", [(2, (3, 2), (1.0, 0.5)), (3, (2, 3, 2), (1.0, 0.6, 0.25))])
+def test_elasticity_block_tables_match_oracle_assembly(lib, dim, n, Ls):
+    """d x d block class table of the elasticity operator (host twin of the device fold) == assembled matrix"""
+    from pdegpu import _lib
+    lam, mu = o.lame(210e9, 0.3)
+    g = _lib.make_grid(dim, n, Ls)
+    tab = np.zeros(27 * 15 * 9)
+    assert lib.pdegpu_elasticity_tables_host(g, lam, mu, _lib.dptr(tab)) == 0
+    tab = tab.reshape(27, 15, 3, 3)
+    off15 = [13, 12, 14, 10, 16, 4, 22, 9, 17, 3, 23, 1, 25, 0, 26]
+    c, cells = o.rectangle_mesh(Ls[0], Ls[1], n[0], n[1]) if dim == 2 else o.box_mesh(*Ls, *n)
+    K = o.assemble_elasticity(c, cells, lam, mu).toarray()
+    scale = np.abs(K).max()
+    nn = [n[r] + 1 if r < dim else 1 for r in range(3)]
+    seen = np.zeros_like(K, dtype=bool)
+    for cls in range(27):
+        cc = (cls % 3, (cls // 3) % 3, cls // 9)
+        if any(cc[r] != 1 for r in range(dim, 3)) or any(r < dim and n[r] < 2 and cc[r] == 1 for r in range(3)):
+            continue
+        idx3 = [_class_node(cc[r], n[r]) if r < dim else 0 for r in range(3)]
+        row = idx3[0] + nn[0] * (idx3[1] + nn[1] * idx3[2])
+        for q, off in enumerate(off15):
+            d = (off % 3 - 1, (off // 3) % 3 - 1, off // 9 - 1)
+            nb = [idx3[r] + d[r] for r in range(3)]
+            if not all(0 <= nb[r] < nn[r] for r in range(3)):
+                assert np.all(tab[cls, q] == 0.0)
+                continue
+            col = nb[0] + nn[0] * (nb[1] + nn[1] * nb[2])
+            blk = K[row * dim:(row + 1) * dim, col * dim:(col + 1) * dim]
+            assert np.abs(tab[cls, q, :dim, :dim] - blk).max() < 1e-12 * scale
+            seen[row * dim:(row + 1) * dim, col * dim:(col + 1) * dim] = True
+        # the 15 offsets are ALL the couplings of this row
+        assert np.abs(K[row * dim:(row + 1) * dim][~seen[row * dim:(row + 1) * dim]]).max() < 1e-12 * scale
