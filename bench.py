@@ -157,17 +157,25 @@ def main():
                     traffic = None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_fast<7,4,CG_K1> (x+=a*p; p=r+b*p; q=A p; p.q)" if not args.general else "k_general<CG_K1>",
+                               "kernel": "k_fast<7,2,CG_K1,nt> (x+=a*p; p=r+b*p; q=A p; p.q)" if not args.general else "k_general<CG_K1>",
                                "alg_bytes_per_launch": k1_bytes, "avg_ms": k1_ms,
                                "other_kernels": [{"kernel": "k_k2 (r-=a*q; r.r)", "alg_bytes_per_launch": k2_bytes,
                                                   "avg_ms": k2_ms, "achieved": k2_bytes / (k2_ms * 1e-3) / 1e9,
                                                   "frac": k2_bytes / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}],
                                "cg_iteration_alg_bytes_per_dof": 72}
+            # in-run streaming ceilings on this very device (same vectors, grid-stride 16 B/lane kernels)
+            vec_bytes = eng.plane * nk * 8
+            ceil = {}
+            for which, name, nvec in ((1, "read_1R", 1), (2, "write_1W", 1), (0, "copy_1R1W", 2), (3, "triad_2R1W", 3)):
+                mb = C.c_double()
+                L.check(eng.ctx, eng.lib.pdegpu_session_membench(eng.s, which, 20, C.byref(mb)))
+                ceil[name] = nvec * vec_bytes / (mb.value * 1e-3) / 1e9
+            out["roofline"]["in_run_ceiling_GBps"] = ceil
             # SpMV alone (16 B/DoF) for the north-star statement
             ms = C.c_double()
             if hasattr(eng.lib, "pdegpu_session_time_apply"):
                 L.check(eng.ctx, eng.lib.pdegpu_session_time_apply(eng.s, 50, C.byref(ms)))
-                out["roofline"]["spmv_only"] = {"kernel": "k_fast<7,4,PLAIN> (q = A p, 16 B/DoF)", "avg_ms": ms.value,
+                out["roofline"]["spmv_only"] = {"kernel": "k_fast<7,2,PLAIN,nt> (q = A p, 16 B/DoF)", "avg_ms": ms.value,
                                                 "achieved": 16.0 * unknowns / (ms.value * 1e-3) / 1e9,
                                                 "frac": 16.0 * unknowns / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS}
         eng.close()

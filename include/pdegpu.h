@@ -118,6 +118,10 @@ void        pdegpu_destroy(pdegpu_ctx* ctx);
 const char* pdegpu_last_error(const pdegpu_ctx* ctx);
 int         pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen);
 const char* pdegpu_version(void);
+/* performance tunables of a context (also read from PDEGPU_<KEY> at pdegpu_create): "fast_ry" rows per thread of
+ * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_wg_per_cu" (0 = occupancy API),
+ * "k2_variant" (0|1|2), "grid_mult" workgroups per CU of the flat kernels.  Results do not depend on them. */
+int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 
 /* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw
  *      (:229-318, :369-447, :533-716).  Node order of every array: x fastest, then y, then z
@@ -193,6 +197,9 @@ int  pdegpu_session_rr(pdegpu_session* s, double* rr_out);  /* synchronises; glo
  * operator application b = A r (the matrix-free SpMV alone: read one vector, write one, 16 B/DoF).
  * Overwrites b; call after the solve. */
 int  pdegpu_session_time_apply(pdegpu_session* s, int reps, double* avg_ms_out);
+/* in-run memory calibration over the session's own vectors (padded slab, nk*PP doubles each):
+ * which = 0 copy (1R+1W), 1 read-only (1R), 2 write-only (1W), 3 triad (2R+1W), 4 in-place update (2R+1W). */
+int  pdegpu_session_membench(pdegpu_session* s, int which, int reps, double* avg_ms_out);
 int  pdegpu_session_get_x(pdegpu_session* s, double* x_out /* host [nk][plane nodes] */);
 int  pdegpu_session_sync(pdegpu_session* s);
 

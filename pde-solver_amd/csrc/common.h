@@ -15,6 +15,14 @@ struct pdegpu_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
+    // tunables (pdegpu_set_tunable / PDEGPU_* environment at context creation)
+    int fast_ry = 2;            // rows per thread of the z-marching kernels (1, 2, 4, 8); 2 = 4 waves/SIMD, measured best
+    int fast_nt = -1;           // bit 0: non-temporal stores of q / p / x; bit 1: non-temporal loads of x; -1 = auto
+                                // (3 when one slab vector exceeds 64 MiB, i.e. nothing stays cache-resident)
+    int fast_wg_per_cu = 0;     // 0 = occupancy API
+    int k2_variant = 0;         // 0: grid-stride double2; 1: 4x unrolled; 2: 4x unrolled + non-temporal
+    int grid_mult = 8;          // flat kernels: workgroups per CU
+    int k2_grid_mult = 2;       // K2: workgroups per CU (few, deep streams beat many shallow ones on mixed R/W)
     std::string err;
     char name[256] = {0};
 };
@@ -156,6 +164,7 @@ int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p
 int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const double* scal, double* partials, LaunchInfo* li);
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
+int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense
 int vec_unpack(pdegpu_ctx* ctx, const GridDev& g, const double* dense, double* v);   // dense -> pitched

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cctype>
+#include <cstdlib>
 
 struct pdegpu_session {
     pdegpu_ctx* ctx = nullptr;
@@ -211,7 +213,33 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
+    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult"}) {
+        std::string env = std::string("PDEGPU_") + key;
+        for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
+        if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
+    }
     *out = ctx;
+    return PDEGPU_OK;
+}
+
+namespace {
+int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
+    if (!strcmp(key, "fast_ry")) return &ctx->fast_ry;
+    if (!strcmp(key, "fast_nt")) return &ctx->fast_nt;
+    if (!strcmp(key, "fast_wg_per_cu")) return &ctx->fast_wg_per_cu;
+    if (!strcmp(key, "k2_variant")) return &ctx->k2_variant;
+    if (!strcmp(key, "grid_mult")) return &ctx->grid_mult;
+    if (!strcmp(key, "k2_grid_mult")) return &ctx->k2_grid_mult;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return PDEGPU_EINVAL;
+    int* slot = tunable_slot(ctx, key);
+    if (!slot) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown tunable '%s'", key);
+    if ((!strcmp(key, "grid_mult") || !strcmp(key, "k2_grid_mult")) && (value < 1 || value > 64)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "grid_mult must be 1..64");
+    *slot = value;
     return PDEGPU_OK;
 }
 
@@ -428,6 +456,27 @@ extern "C" int pdegpu_session_time_apply(pdegpu_session* s, int reps, double* av
     PG_TRY(op_plain(s, 0, s->r.v, 0.0, s->b.v, 1));          // warm-up
     PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < reps; ++i) PG_TRY(op_plain(s, 0, s->r.v, 0.0, s->b.v, 1));
+    PG_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    PG_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms_out = ms / reps;
+    return PDEGPU_OK;
+}
+
+// in-run memory calibration: average ms of `reps` launches of a streaming kernel over one slab vector set
+extern "C" int pdegpu_session_membench(pdegpu_session* s, int which, int reps, double* avg_ms_out) {
+    if (!s || reps < 1 || !avg_ms_out || which < 0 || which > 4) return PDEGPU_EINVAL;
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    PG_HIP(ctx, hipEventCreate(&e0));
+    PG_HIP(ctx, hipEventCreate(&e1));
+    PG_TRY(vec_membench(ctx, s->g, which, s->r.v, s->q.v, s->b.v, s->d_part));
+    PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; ++i) PG_TRY(vec_membench(ctx, s->g, which, s->r.v, s->q.v, s->b.v, s->d_part));
     PG_HIP(ctx, hipEventRecord(e1, ctx->stream));
     PG_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0;

@@ -140,7 +140,27 @@ __device__ __forceinline__ double dpp_from_upper(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int NPT, int RY, int MODE>
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+template <int NT>
+__device__ __forceinline__ void store_pair(double* p, const double2& v) {
+    if (NT & 1) {
+        dbl2 t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<dbl2*>(p));
+    } else {
+        *reinterpret_cast<double2*>(p) = v;
+    }
+}
+template <int NT>
+__device__ __forceinline__ double2 load_pair_x(const double* p) {
+    if (NT & 2) {
+        dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(p));
+        return make_double2(t.x, t.y);
+    }
+    return *reinterpret_cast<const double2*>(p);
+}
+
+template <int NPT, int RY, int MODE, int NT>
 __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     __shared__ double sRed[4];
     const GridDev& g = a.g;
@@ -212,12 +232,12 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             if (K1) {
                 if (j <= g.NY - 2 && lane_ok) {
                     const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
-                    *reinterpret_cast<double2*>(a.p_new + off) = pn;
+                    store_pair<NT>(a.p_new + off, pn);
                     if (alpha_prev != 0.0) {
-                        double2 xv = *reinterpret_cast<const double2*>(a.x + off);
+                        double2 xv = load_pair_x<NT>(a.x + off);
                         xv.x += alpha_prev * po.x;
                         xv.y += alpha_prev * po.y;
-                        *reinterpret_cast<double2*>(a.x + off) = xv;
+                        store_pair<NT>(a.x + off, xv);
                     }
                 }
             }
@@ -303,8 +323,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                         o.y = mb ? qb : 0.0;
                         acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
                     }
-                    if (lane_ok)
-                        *reinterpret_cast<double2*>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0) = o;
+                    if (lane_ok) store_pair<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
                 }
             }
 
@@ -352,34 +371,46 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     return fg;
 }
 
-template <int NPT, int RY>
+template <int NPT, int RY, int NT>
 int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     static int occ[3] = {0, 0, 0};   // resident workgroups per CU of each instantiation
     if (occ[mode] == 0) {
         int nb = 0;
         hipError_t e = hipSuccess;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
-        if (nb > 4) nb = 4;
+        if (nb > 8) nb = 8;
         occ[mode] = nb;
     }
     int wg_per_cu = occ[mode];
-    if (const char* ev = getenv("PDEGPU_FAST_WG_PER_CU")) { int v = atoi(ev); if (v >= 1 && v <= 8) wg_per_cu = v; }
+    if (ctx->fast_wg_per_cu >= 1 && ctx->fast_wg_per_cu <= 16) wg_per_cu = ctx->fast_wg_per_cu;
     FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu);
     const int G = fg.nxg * fg.nyg * fg.nzc;
     if (li) { li->grid = G; li->block = 256; }
     if (G == 0) return PDEGPU_OK;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
+}
+
+template <int NPT, int RY>
+int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    int nt = ctx->fast_nt;
+    if (nt < 0) nt = ((long long)a.g.nkl * a.g.PP * 8 > (64LL << 20)) ? 3 : 0;
+    switch (nt & 3) {
+        case 1: return launch_fast<NPT, RY, 1>(ctx, a, mode, li);
+        case 2: return launch_fast<NPT, RY, 2>(ctx, a, mode, li);
+        case 3: return launch_fast<NPT, RY, 3>(ctx, a, mode, li);
+        default: return launch_fast<NPT, RY, 0>(ctx, a, mode, li);
+    }
 }
 
 }  // namespace
@@ -387,7 +418,7 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     const long long total = (long long)a.g.nkl * a.g.PP;
     long long nb = (total + 255) / 256;
-    const long long cap = 8LL * ctx->num_cu;
+    const long long cap = (long long)ctx->grid_mult * ctx->num_cu;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     if (li) { li->grid = (int)nb; li->block = 256; }
@@ -407,8 +438,15 @@ bool stencil_fast_supported(const GridDev& g, int element_mode) {
 }
 
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
-    if (a.npt == 7) return launch_fast<7, 4>(ctx, a, mode, li);
-    return launch_fast<15, 4>(ctx, a, mode, li);
+    if (a.npt == 7) {
+        if (ctx->fast_ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
+        if (ctx->fast_ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);
+        if (ctx->fast_ry == 8) return launch_fast_nt<7, 8>(ctx, a, mode, li);
+        return launch_fast_nt<7, 4>(ctx, a, mode, li);
+    }
+    if (ctx->fast_ry == 1) return launch_fast_nt<15, 1>(ctx, a, mode, li);
+    if (ctx->fast_ry == 2) return launch_fast_nt<15, 2>(ctx, a, mode, li);
+    return launch_fast_nt<15, 4>(ctx, a, mode, li);
 }
 
-int stencil_max_partials(pdegpu_ctx* ctx) { return 16 * ctx->num_cu + 4096; }
+int stencil_max_partials(pdegpu_ctx* ctx) { return 64 * ctx->num_cu + 4096; }

@@ -65,6 +65,84 @@ __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const doubl
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+// U independent 16-B streams per lane per trip (2U loads in flight), optionally non-temporal
+template <int NT, int U>
+__global__ __launch_bounds__(256) void k_k2_u4(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
+                                                const double* __restrict__ scal, double* __restrict__ partials) {
+    __shared__ double sRed[4];
+    const double pq = scal[SC_PQ], rr = scal[SC_RR];
+    const double alpha = (pq > 0.0) ? rr / pq : 0.0;
+    double acc = 0.0;
+    const long long stride = (long long)gridDim.x * 256;
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; e + (U - 1) * stride < n2; e += U * stride) {
+        dbl2 rv[U], qv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const dbl2* rp = reinterpret_cast<const dbl2*>(r + e + u * stride);
+            const dbl2* qp = reinterpret_cast<const dbl2*>(q + e + u * stride);
+            rv[u] = NT ? __builtin_nontemporal_load(rp) : *rp;
+            qv[u] = NT ? __builtin_nontemporal_load(qp) : *qp;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rv[u] -= alpha * qv[u];
+            dbl2* wp = reinterpret_cast<dbl2*>(r + e + u * stride);
+            if (NT) __builtin_nontemporal_store(rv[u], wp);
+            else *wp = rv[u];
+            acc += rv[u].x * rv[u].x + rv[u].y * rv[u].y;
+        }
+    }
+    for (; e < n2; e += stride) {
+        double2 rv = r[e];
+        const double2 qv = q[e];
+        rv.x -= alpha * qv.x;
+        rv.y -= alpha * qv.y;
+        r[e] = rv;
+        acc += rv.x * rv.x + rv.y * rv.y;
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// contiguous chunk per workgroup instead of a grid-stride interleave
+__global__ __launch_bounds__(256) void k_k2_chunk(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
+                                                   const double* __restrict__ scal, double* __restrict__ partials) {
+    __shared__ double sRed[4];
+    const double pq = scal[SC_PQ], rr = scal[SC_RR];
+    const double alpha = (pq > 0.0) ? rr / pq : 0.0;
+    double acc = 0.0;
+    const long long per = ((n2 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const long long beg = per * blockIdx.x, end = beg + per < n2 ? beg + per : n2;
+    for (long long e = beg + threadIdx.x; e < end; e += 256) {
+        double2 rv = r[e];
+        const double2 qv = q[e];
+        rv.x -= alpha * qv.x;
+        rv.y -= alpha * qv.y;
+        r[e] = rv;
+        acc += rv.x * rv.x + rv.y * rv.y;
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// in-run memory calibration (bench.py): 0 copy b=q, 1 read-only sum(r), 2 write-only b=c, 3 triad b=r+c*q,
+// 4 in-place update r=r+0*q (same traffic shape as K2 without the reduction epilogue)
+__global__ __launch_bounds__(256) void k_membench(int which, double2* __restrict__ r, const double2* __restrict__ q,
+                                                   double2* __restrict__ b, long long n2, double c, double* __restrict__ sink) {
+    double acc = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long long)gridDim.x * 256) {
+        if (which == 0) b[e] = q[e];
+        else if (which == 1) { const double2 v = r[e]; acc += v.x + v.y; }
+        else if (which == 2) b[e] = make_double2(c, c);
+        else if (which == 3) { const double2 rv = r[e], qv = q[e]; b[e] = make_double2(rv.x + c * qv.x, rv.y + c * qv.y); }
+        else { double2 rv = r[e]; const double2 qv = q[e]; rv.x += c * qv.x; rv.y += c * qv.y; r[e] = rv; }
+    }
+    if (which == 1 && acc == 1.2345e300) sink[0] = acc;      // keeps the loads alive
+}
+
 __global__ __launch_bounds__(256) void k_norm2(const double2* __restrict__ a, long long n2, double* __restrict__ partials) {
     __shared__ double sRed[4];
     double acc = 0.0;
@@ -123,7 +201,7 @@ __global__ __launch_bounds__(256) void k_pack(GridDev g, const double* __restric
 
 inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
     long long nb = (n + 255) / 256;
-    const long long cap = 8LL * ctx->num_cu;
+    const long long cap = (long long)ctx->grid_mult * ctx->num_cu;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
@@ -160,10 +238,28 @@ int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const 
 
 int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const double* scal, double* partials, LaunchInfo* li) {
     const long long n2 = (long long)g.nkl * g.PP / 2;
-    const int nb = flat_grid(ctx, n2);
+    long long nbl = (n2 + 255) / 256;
+    if (nbl > (long long)ctx->k2_grid_mult * ctx->num_cu) nbl = (long long)ctx->k2_grid_mult * ctx->num_cu;
+    const int nb = nbl < 1 ? 1 : (int)nbl;
     if (li) { li->grid = nb; li->block = 256; }
-    hipLaunchKernelGGL(k_k2, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                       reinterpret_cast<const double2*>(q), n2, scal, partials);
+    if (ctx->k2_variant == 4)
+        hipLaunchKernelGGL((k_k2_u4<0, 8>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+    else if (ctx->k2_variant == 5)
+        hipLaunchKernelGGL((k_k2_u4<1, 8>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+    else if (ctx->k2_variant == 1)
+        hipLaunchKernelGGL((k_k2_u4<0, 4>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+    else if (ctx->k2_variant == 3)
+        hipLaunchKernelGGL(k_k2_chunk, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+    else if (ctx->k2_variant == 2)
+        hipLaunchKernelGGL((k_k2_u4<1, 4>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+    else
+        hipLaunchKernelGGL(k_k2, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                           reinterpret_cast<const double2*>(q), n2, scal, partials);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }
@@ -206,6 +302,14 @@ int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense) 
 int vec_unpack(pdegpu_ctx* ctx, const GridDev& g, const double* dense, double* v) {
     const long long total = (long long)g.nkl * g.NY * g.NX;
     hipLaunchKernelGGL(k_pack, dim3(flat_grid(ctx, total)), dim3(256), 0, ctx->stream, g, v, const_cast<double*>(dense), 0);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink) {
+    const long long n2 = (long long)g.nkl * g.PP / 2;
+    hipLaunchKernelGGL(k_membench, dim3(flat_grid(ctx, n2)), dim3(256), 0, ctx->stream, which, reinterpret_cast<double2*>(r),
+                       reinterpret_cast<const double2*>(q), reinterpret_cast<double2*>(b), n2, 0.0, sink);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

@@ -68,6 +68,7 @@ SYMBOLS = {
     "pdegpu_last_error": (C.c_char_p, [_vp]),
     "pdegpu_device_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "pdegpu_version": (C.c_char_p, []),
+    "pdegpu_set_tunable": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "pdegpu_heat_num_snapshots": (C.c_int, [C.POINTER(Heat)]),
     "pdegpu_heat_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_mass_solve": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, C.c_double, C.c_int, C.POINTER(Stats)]),
@@ -91,6 +92,7 @@ SYMBOLS = {
     "pdegpu_session_iterate": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(Stats)]),
     "pdegpu_session_rr": (C.c_int, [_vp, _dp]),
     "pdegpu_session_time_apply": (C.c_int, [_vp, C.c_int, _dp]),
+    "pdegpu_session_membench": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "pdegpu_session_get_x": (C.c_int, [_vp, _dp]),
     "pdegpu_session_sync": (C.c_int, [_vp]),
     "pdegpu_grid_num_nodes": (C.c_int64, [C.POINTER(Grid)]),

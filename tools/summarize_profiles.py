@@ -50,7 +50,8 @@ for k in sorted(set(fetch) | set(write)):
                              "hbm_read_bytes": 2 * fm * 1024, "hbm_write_bytes": wm * 1024,
                              "hbm_bytes": 2 * fm * 1024 + wm * 1024}
 (out / f"{rnd}{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1))
-k1 = [v for k, v in summary["kernels"].items() if "k_fast<7, 4, 2>" in k or "k_fast<7, 4, (ApplyMode)2>" in k]
+import re
+k1 = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 2[,>]", k)]
 if k1:
     (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "source": f"{rnd}{tag}_pmc_summary.json"}))
 print(json.dumps(summary, indent=1)[:3000])
