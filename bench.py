@@ -29,6 +29,7 @@ for p in (ROOT, ROOT / "pde-solver_amd"):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -145,8 +146,11 @@ def main():
             # ---- roofline of the dominant kernel (K1 = the SpMV-bearing fused kernel), HIP events ----------
             k1_ms = stats.kernel_ms[0] / max(1, stats.kernel_launches[0])
             k2_ms = stats.kernel_ms[1] / max(1, stats.kernel_launches[1])
-            k1_bytes = 48.0 * unknowns          # read r, p, x; write p, q, x  (8 B each) per unknown
-            k2_bytes = 24.0 * unknowns          # read r, q; write r
+            # K1 reads r, p, x and writes p, x (+ q in the 72-B variant); K2 reads r and p (or q), writes r
+            nodes_local = (n + 1) * (n + 1) * nk
+            k1_per_dof = round(stats.alg_bytes[0] / max(1, stats.kernel_launches[0]) / nodes_local)      # 40 or 48
+            k1_bytes = float(k1_per_dof) * unknowns
+            k2_bytes = 24.0 * unknowns
             ach = k1_bytes / (k1_ms * 1e-3) / 1e9
             traffic = None
             pmc = ROOT / "profiles" / "pmc_latest.json"
@@ -157,12 +161,12 @@ def main():
                     traffic = None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_fast<7,2,CG_K1,nt> (x+=a*p; p=r+b*p; q=A p; p.q)" if not args.general else "k_general<CG_K1>",
+                               "kernel": "k_fast<7,2,CG_K1,nt> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)" if not args.general else "k_general<CG_K1>",
                                "alg_bytes_per_launch": k1_bytes, "avg_ms": k1_ms,
-                               "other_kernels": [{"kernel": "k_k2 (r-=a*q; r.r)", "alg_bytes_per_launch": k2_bytes,
+                               "other_kernels": [{"kernel": "k_fast<7,2,CG_K2,nt> (r-=a*(A p); r.r)" if k1_per_dof == 40 else "k_k2 (r-=a*q; r.r)", "alg_bytes_per_launch": k2_bytes,
                                                   "avg_ms": k2_ms, "achieved": k2_bytes / (k2_ms * 1e-3) / 1e9,
                                                   "frac": k2_bytes / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}],
-                               "cg_iteration_alg_bytes_per_dof": 72}
+                               "cg_iteration_alg_bytes_per_dof": k1_per_dof + 24}
             # in-run streaming ceilings on this very device (same vectors, grid-stride 16 B/lane kernels)
             vec_bytes = eng.plane * nk * 8
             ceil = {}

@@ -120,7 +120,8 @@ int         pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen);
 const char* pdegpu_version(void);
 /* performance tunables of a context (also read from PDEGPU_<KEY> at pdegpu_create): "fast_ry" rows per thread of
  * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_wg_per_cu" (0 = occupancy API),
- * "k2_variant" (0|1|2), "grid_mult" workgroups per CU of the flat kernels.  Results do not depend on them. */
+ * "k2_variant" (0..5), "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
+ * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF).  Results do not depend on them. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 
 /* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw
@@ -157,6 +158,10 @@ int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdeg
                             double* field_out, double* disp_out, pdegpu_stats* stats);
 int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el,
                             const double* u, double* y, int use_mfma);
+/* average device time (ms) of `reps` applications of the elasticity operator: use_mfma = 0 vector block stencil,
+ * 1 element-by-element v_mfma_f64_16x16x4_f64 (3-D) */
+int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, int use_mfma,
+                                 int reps, double* avg_ms_out);
 /* host twin of the device fold of the d x d block class table, tab [27 classes][15 offsets][3x3] (CPU tests) */
 int pdegpu_elasticity_tables_host(const pdegpu_grid* grid, double lam, double mu, double* tab);
 
@@ -180,6 +185,10 @@ int  pdegpu_session_begin(pdegpu_session* s, double x_fill);
  * plane_doubles = number of fp64 in one contiguous plane. */
 void*   pdegpu_session_plane_ptr(pdegpu_session* s, int vec, int64_t which);
 int64_t pdegpu_session_plane_doubles(const pdegpu_session* s);
+/* 1 if the ghost planes of p must be exchanged together with r before every k1 (class-table kernels and the 72-B
+ * variant); 0 when k1 maintains p on the ghost planes itself (fused z-marching kernels, cg_variant 1): then only
+ * r is exchanged. */
+int     pdegpu_session_needs_p_halo(const pdegpu_session* s);
 /* pointer to the 4 device scalars {pq_local, rr_local, pq_global, rr_global}.  After
  * pdegpu_session_reduce_local the *_local entries hold this slab's partial dot products; the host
  * all-reduces them into *_global (single GPU: pdegpu_session_reduce_local copies local->global). */

@@ -22,6 +22,7 @@ struct pdegpu_ctx {
     int fast_wg_per_cu = 0;     // 0 = occupancy API
     int k2_variant = 0;         // 0: grid-stride double2; 1: 4x unrolled; 2: 4x unrolled + non-temporal
     int grid_mult = 8;          // flat kernels: workgroups per CU
+    int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
     int k2_grid_mult = 2;       // K2: workgroups per CU (few, deep streams beat many shallow ones on mixed R/W)
     std::string err;
     char name[256] = {0};
@@ -124,7 +125,7 @@ void tables_free(HeatTables* t);
 // ------------------------------------------------------------------------------------------------
 // kernels launched through host wrappers (stencil.hip / vecops.hip)
 // ------------------------------------------------------------------------------------------------
-enum ApplyMode { APPLY_PLAIN = 0, APPLY_RESIDUAL = 1, APPLY_CG_K1 = 2 };
+enum ApplyMode { APPLY_PLAIN = 0, APPLY_RESIDUAL = 1, APPLY_CG_K1 = 2, APPLY_CG_K2 = 3 };
 
 struct StencilArgs {
     GridDev g;

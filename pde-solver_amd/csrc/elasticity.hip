@@ -338,6 +338,66 @@ __global__ __launch_bounds__(256) void k_vm_gather(GridDev g, VmGeom vg, const d
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// element-by-element apply on the matrix cores: Y_e[24 x 16 elements] = K_e[24 x 24] U_e[24 x 16] with
+// v_mfma_f64_16x16x4_f64 (2 M-tiles x 6 K-steps per 16 elements), gather from / scatter-add to the node arrays.
+// The only dense contraction on the path (north_star).  Measured against the vector block stencil in
+// fp64 MFMA issues at the fp64 VALU rate on MI355X and the 24 -> 32 row padding plus the
+// scatter atomics make it the slower form, so the solver keeps the stencil; this kernel stays selectable
+// (use_mfma = 1) and parity-tested.
+// ---------------------------------------------------------------------------------------------
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_el_apply_mfma(GridDev g, long long stride, const double* __restrict__ Ke /*[24][24]*/,
+                                                        const double* __restrict__ u, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int e = lane & 15, kg = lane >> 4;
+    const int cx = g.NX - 1, cy = g.NY - 1, cz = g.NZ - 1;
+    const int nbx = (cx + 15) / 16;
+    const long long nbatch = (long long)nbx * cy * cz;
+    // A operands: K_e tile entries, constant for every element (lane: row = l&15, k = l>>4)
+    double A[2][6];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const int row = mt * 16 + e;
+            A[mt][ks] = row < 24 ? Ke[row * 24 + ks * 4 + kg] : 0.0;
+        }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    for (long long b = wave; b < nbatch; b += nwaves) {
+        const int bx = (int)(b % nbx), j = (int)((b / nbx) % cy), k = (int)(b / ((long long)nbx * cy));
+        const int i = bx * 16 + e;                     // this lane's element (column of the MFMA)
+        const bool live = i < cx;
+        const long long base = (long long)k * g.PP + (long long)j * g.PX + (live ? i : 0);
+        dbl4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const int dof = ks * 4 + kg, v = dof / 3, c = dof % 3;          // B[k = l>>4][col = l&15]
+            const long long off = base + (v & 1) + (long long)((v >> 1) & 1) * g.PX + (long long)((v >> 2) & 1) * g.PP;
+            const double bv = live ? u[c * stride + off] : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0][ks], bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[1][ks], bv, acc1, 0, 0, 0);
+        }
+        // D: col = lane & 15 (element), row = (lane >> 4) + 4 * reg   (f64 layout)
+        if (live) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = kg + 4 * reg, v = row / 3, c = row % 3;
+                const long long off = base + (v & 1) + (long long)((v >> 1) & 1) * g.PX + (long long)((v >> 2) & 1) * g.PP;
+                atomicAdd(&y[c * stride + off], acc0[reg]);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 2; ++reg) {
+                const int row = 16 + kg + 4 * reg, v = row / 3, c = row % 3;
+                const long long off = base + (v & 1) + (long long)((v >> 1) & 1) * g.PX + (long long)((v >> 2) & 1) * g.PP;
+                atomicAdd(&y[c * stride + off], acc1[reg]);
+            }
+        }
+    }
+}
+
 inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
     long long nb = (n + 255) / 256;
     const long long cap = 8LL * ctx->num_cu;
@@ -652,6 +712,37 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     return rc2 != PDEGPU_OK ? rc2 : rc;
 }
 
+namespace {
+// y = K u through the matrix cores (3-D): zero y, one launch, scatter with fp64 atomics
+int el_apply_mfma(ElSession* s, const double* u, double* y, double* d_Ke) {
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipMemsetAsync(y - vec_front(s->g), 0, (size_t)3 * s->stride * sizeof(double), ctx->stream));
+    const long long nbatch = (long long)((s->g.NX - 1 + 15) / 16) * (s->g.NY - 1) * (s->g.NZ - 1);
+    long long nb = (nbatch + 3) / 4;
+    if (nb > 8LL * ctx->num_cu) nb = 8LL * ctx->num_cu;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_el_apply_mfma, dim3((unsigned)nb), dim3(256), 0, ctx->stream, s->g, s->stride, d_Ke, u, y);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+int upload_macro_element(ElSession* s, const pdegpu_grid* grid, double** d_Ke) {
+    double h[3] = {1, 1, 1};
+    for (int r = 0; r < grid->dim; ++r) h[r] = grid->L[r] / grid->n[r];
+    static thread_local double Ke[24 * 24];
+    for (int la = 0; la < 8; ++la)
+        for (int lb = 0; lb < 8; ++lb) {
+            double blk[9];
+            macro_elasticity_block(3, h, s->lam, s->mu, la, lb, blk);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) Ke[(la * 3 + a) * 24 + lb * 3 + b] = blk[a * 3 + b];
+        }
+    PG_HIP(s->ctx, hipMalloc(d_Ke, sizeof Ke));
+    PG_HIP(s->ctx, hipMemcpyAsync(*d_Ke, Ke, sizeof Ke, hipMemcpyHostToDevice, s->ctx->stream));
+    PG_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return PDEGPU_OK;
+}
+}  // namespace
+
 // y = K u on the full grid (no clamp), u and y host arrays [N][dim] — for parity tests
 extern "C" int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, const double* u,
                                        double* y, int use_mfma) {
@@ -659,7 +750,7 @@ extern "C" int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     if (!el || !u || !y) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
     PG_TRY(validate_grid(ctx, grid));
     if (grid->dim < 2) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "block operator exists for dim 2 and 3");
-    if (use_mfma) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "MFMA element-by-element variant not built in this round");
+    if (use_mfma && grid->dim != 3) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "the MFMA element-by-element apply is 3-D only");
     PG_HIP(ctx, hipSetDevice(ctx->device));
     ElSession s;
     PG_TRY(el_create(ctx, grid, el, &s));
@@ -676,7 +767,13 @@ extern "C" int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid,
         if (rc == PDEGPU_OK) rc = vec_unpack(ctx, s.g, d_dense, s.x + (long long)c * s.stride);
         if (rc == PDEGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "sync failed");
     }
-    if (rc == PDEGPU_OK) {
+    if (rc == PDEGPU_OK && use_mfma) {
+        double* d_Ke = nullptr;
+        rc = upload_macro_element(&s, grid, &d_Ke);
+        if (rc == PDEGPU_OK) rc = el_apply_mfma(&s, s.x, s.q, d_Ke);
+        if (rc == PDEGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "sync failed");
+        if (d_Ke) (void)hipFree(d_Ke);
+    } else if (rc == PDEGPU_OK) {
         ElArgs a = s.args();
         a.in = s.x;
         a.out = s.q;
@@ -701,4 +798,42 @@ extern "C" int pdegpu_elasticity_tables_host(const pdegpu_grid* grid, double lam
     }
     for (int e = 0; e < 27 * PG_NOFF15; ++e) fold_elasticity_block(grid->dim, h, lam, mu, e / PG_NOFF15, e % PG_NOFF15, tab + e * 9);
     return PDEGPU_OK;
+}
+
+// roofline harness for the elasticity operator: average device time of `reps` full-grid applications y = K u
+// (u = the load vector pattern) with the vector block stencil (use_mfma = 0) or the MFMA element-by-element form
+extern "C" int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, int use_mfma,
+                                            int reps, double* avg_ms_out) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!el || !avg_ms_out || reps < 1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "bad argument");
+    PG_TRY(validate_grid(ctx, grid));
+    if (grid->dim != 3) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "3-D only");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    ElSession s;
+    PG_TRY(el_create(ctx, grid, el, &s));
+    hipLaunchKernelGGL(k_el_load, dim3(s.nblk), dim3(256), 0, ctx->stream, s.g, s.stride, 3, s.ht.d_load, 1.0, -2.0, 3.0, s.x);
+    PG_HIP(ctx, hipGetLastError());
+    double* d_Ke = nullptr;
+    if (use_mfma) PG_TRY(upload_macro_element(&s, grid, &d_Ke));
+    ElArgs a = s.args();
+    a.in = s.x;
+    a.out = s.q;
+    a.mask_dirichlet = 0;
+    hipEvent_t e0, e1;
+    PG_HIP(ctx, hipEventCreate(&e0));
+    PG_HIP(ctx, hipEventCreate(&e1));
+    int rc = PDEGPU_OK;
+    for (int i = -1; i < reps && rc == PDEGPU_OK; ++i) {
+        if (i == 0) (void)hipEventRecord(e0, ctx->stream);
+        rc = use_mfma ? el_apply_mfma(&s, s.x, s.q, d_Ke) : el_apply(&s, a, APPLY_PLAIN);
+    }
+    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (d_Ke) (void)hipFree(d_Ke);
+    *avg_ms_out = ms / reps;
+    return rc;
 }

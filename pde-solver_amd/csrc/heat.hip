@@ -151,6 +151,10 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     return stencil_general(s->ctx, a, APPLY_RESIDUAL, li);
 }
 
+// 64 B/DoF variant (K2 recomputes q with the marching stencil): pays for the 7-point operator only — with the
+// 15-point operator the second stencil pass costs more than the 8 B/DoF it saves (measured)
+bool k2_is_stencil(const pdegpu_session* s) { return s->fast && s->ctx->cg_variant == 1 && s->npt == 7; }
+
 int op_k1(pdegpu_session* s, LaunchInfo* li) {
     StencilArgs a{};
     a.g = s->g;
@@ -158,7 +162,7 @@ int op_k1(pdegpu_session* s, LaunchInfo* li) {
     a.p_old = s->p[s->pcur].v;
     a.p_new = s->p[1 - s->pcur].v;
     a.x = s->x.v;
-    a.out = s->q.v;
+    a.out = k2_is_stencil(s) ? nullptr : s->q.v;     // 64-B variant: q is recomputed by K2
     a.scal = s->d_scal;
     a.partials = s->d_part;
     a.mask_dirichlet = 1;
@@ -173,6 +177,24 @@ int op_k1(pdegpu_session* s, LaunchInfo* li) {
     }
     if (rc == PDEGPU_OK) s->pcur ^= 1;
     return rc;
+}
+
+// K2: r -= alpha q, partial r.r   (fast path variant 1: q = A p recomputed by the marching stencil)
+int op_k2(pdegpu_session* s, LaunchInfo* li) {
+    if (k2_is_stencil(s)) {
+        StencilArgs a{};
+        a.g = s->g;
+        a.in = s->p[s->pcur].v;
+        a.rhs = s->r.v;
+        a.out = s->r.v;
+        a.scal = s->d_scal;
+        a.partials = s->d_part;
+        a.mask_dirichlet = 1;
+        fast_weights(s->hA, a.w);
+        a.npt = s->npt;
+        return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
+    }
+    return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, li);
 }
 
 // x (including the ghost planes that lie inside the global domain) = Dirichlet values / fill / nodal
@@ -213,7 +235,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -230,6 +252,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "k2_variant")) return &ctx->k2_variant;
     if (!strcmp(key, "grid_mult")) return &ctx->grid_mult;
     if (!strcmp(key, "k2_grid_mult")) return &ctx->k2_grid_mult;
+    if (!strcmp(key, "cg_variant")) return &ctx->cg_variant;
     return nullptr;
 }
 }  // namespace
@@ -348,6 +371,9 @@ extern "C" void* pdegpu_session_plane_ptr(pdegpu_session* s, int vec, int64_t wh
     return base + which * s->g.PP;
 }
 
+extern "C" int pdegpu_session_needs_p_halo(const pdegpu_session* s) {
+    return (s && k2_is_stencil(s)) ? 0 : 1;
+}
 extern "C" int64_t pdegpu_session_plane_doubles(const pdegpu_session* s) { return s ? (int64_t)s->g.PP : -1; }
 extern "C" double* pdegpu_session_scalars(pdegpu_session* s) { return s ? s->d_scal : nullptr; }
 
@@ -371,7 +397,7 @@ extern "C" int pdegpu_session_k2(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
-    PG_TRY(vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, &li));
+    PG_TRY(op_k2(s, &li));
     return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 0);
 }
 
@@ -410,7 +436,7 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 1], ctx->stream));
         PG_TRY(vec_reduce(ctx, s->d_part, l1.grid, s->d_scal, 0, 1));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 2], ctx->stream));
-        PG_TRY(vec_k2(ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, &l2));
+        PG_TRY(op_k2(s, &l2));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
         PG_TRY(vec_reduce(ctx, s->d_part, l2.grid, s->d_scal, 1, 1));
     }
@@ -429,8 +455,9 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
             }
             stats->kernel_launches[0] += iters;
             stats->kernel_launches[1] += iters;
-            stats->alg_bytes[0] += 48.0 * nloc * iters;   // K1: read r, p, x; write p, q, x
-            stats->alg_bytes[1] += 24.0 * nloc * iters;   // K2: read r, q; write r
+            const bool v1 = k2_is_stencil(s);
+            stats->alg_bytes[0] += (v1 ? 40.0 : 48.0) * nloc * iters;   // K1: read r, p, x; write p, (q,) x
+            stats->alg_bytes[1] += 24.0 * nloc * iters;                 // K2: read r, q|p; write r
         }
     }
     return PDEGPU_OK;

@@ -18,6 +18,10 @@
 // CG K1 (both implementations) fuses, per iteration n:  x += alpha_{n-1} p_{n-1};  p_n = r_n + beta_{n-1}
 // p_{n-1};  q_n = A p_n;  partial(p_n . q_n)  — p_n is recomputed on the fly at the stencil neighbours
 // from r_n and p_{n-1}, which removes the separate p-update pass (72 B/DoF per CG iteration in total).
+// CG K2 (fast path, cg_variant 1): r -= alpha (A p) with the SAME marching stencil applied to the stored p_n, so
+// K1 does not have to store q at all: K1 = read r, p, x / write p, x (40 B/DoF), K2 = read r, p / write r
+// (24 B/DoF) -> 64 B/DoF per iteration.  K1 also stores p_n on the slab's ghost planes (it has r_n and p_{n-1}
+// there), so in the multi-GPU loop only r needs a halo exchange.
 #include "common.h"
 #include <cstdlib>
 
@@ -166,6 +170,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     const GridDev& g = a.g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr bool K1 = (MODE == APPLY_CG_K1);
+    constexpr bool K2 = (MODE == APPLY_CG_K2);
+    constexpr bool RES = (MODE == APPLY_RESIDUAL) || K2;      // out = rhs - scale * (A in)
     constexpr bool W15 = (NPT == 15);
     constexpr int RH = RY + 2;                 // rows held per plane (own rows + one halo row each side)
 
@@ -189,6 +195,11 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wz = a.w[3];
         const double wxy = a.w[4], wxz = a.w[5], wyz = a.w[6], wxyz = a.w[7];
         const double shift = a.in_shift;
+        double res_scale = 1.0;
+        if (K2) {                                             // alpha_n = rr_n / (p_n . A p_n)
+            const double pq = a.scal[SC_PQ], rr = a.scal[SC_RR];
+            res_scale = (pq > 0.0) ? rr / pq : 0.0;
+        }
 
         const bool lane_ok = i0 < g.PX;                       // pair inside the padded row
         const bool ma = (i0 >= 1) && (i0 <= g.NX - 2);        // node a = i0 is an interior (free) node
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
 
         // value of one row-plane: K1 -> p_n = r + beta p_{n-1}; PLAIN -> in + shift; RESIDUAL -> in
         auto row_ok = [&](int j) { return (j >= 0) && (j < g.NY); };
-        auto load_pair = [&](const double* __restrict__ v, long long off) {
+        auto load_pair = [&](const double* v, long long off) {
             return *reinterpret_cast<const double2*>(v + off);
         };
         auto value_row = [&](int lk, int j, double2* po_out) {
@@ -264,6 +275,19 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             if (own) own_update(lk0, j, C[r], po);
         }
 
+        // K1 keeps p_n valid on the ghost planes of the slab (same formula, same inputs as the neighbour rank)
+        auto ghost_store = [&](int lk, const double2* rows) {
+            if (K1) {
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) {
+                    const int j = j0 - 1 + r;
+                    if (j <= g.NY - 2 && lane_ok)
+                        *reinterpret_cast<double2*>(a.p_new + (long long)lk * g.PP + (long long)j * g.PX + i0) = rows[r];
+                }
+            }
+        };
+        if (K1 && lk0 == fg.lkb && lk0 == 0 && g.k0 > 0) ghost_store(-1, P);
+
         for (int lk = lk0; lk < lk1; ++lk) {
             // ---- issue the loads of plane lk+1 -------------------------------------------------
             double2 PO[RH];
@@ -276,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 EN[r] = (W15 || own) ? edge_value(lk + 1, j) : 0.0;
             }
             double2 RHS[RY];
-            if (MODE == APPLY_RESIDUAL) {
+            if (RES) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     const int j = j0 + r;
@@ -314,16 +338,16 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                               wxyz * (rNp + P[c - 1].x);
                     }
                     double2 o;
-                    if (MODE == APPLY_RESIDUAL) {
-                        o.x = ma ? RHS[r].x - qa : 0.0;
-                        o.y = mb ? RHS[r].y - qb : 0.0;
+                    if (RES) {
+                        o.x = ma ? RHS[r].x - res_scale * qa : 0.0;
+                        o.y = mb ? RHS[r].y - res_scale * qb : 0.0;
                         acc += o.x * o.x + o.y * o.y;
                     } else {
                         o.x = ma ? qa : 0.0;
                         o.y = mb ? qb : 0.0;
                         acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
                     }
-                    if (lane_ok) store_pair<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
+                    if (lane_ok && (!K1 || a.out)) store_pair<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
                 }
             }
 
@@ -341,6 +365,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 EC[r] = EN[r];
             }
         }
+        // after the last rotation C holds plane lk1: the upper ghost plane when this is the slab's last chunk
+        if (K1 && lk1 == fg.lke && lk1 == g.nkl && g.k0 + g.nkl < g.NZ) ghost_store(lk1, C);
     }
     const double tot = block_sum_256(acc, sRed);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
@@ -373,13 +399,14 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
 
 template <int NPT, int RY, int NT>
 int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
-    static int occ[3] = {0, 0, 0};   // resident workgroups per CU of each instantiation
+    static int occ[4] = {0, 0, 0, 0};   // resident workgroups per CU of each instantiation
     if (occ[mode] == 0) {
         int nb = 0;
         hipError_t e = hipSuccess;
         switch (mode) {
             case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT>, 256, 0); break;
             case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT>, 256, 0); break;
+            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K2, NT>, 256, 0); break;
             default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
@@ -395,6 +422,7 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     switch (mode) {
         case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
         case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
         default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
     }
     PG_HIP(ctx, hipGetLastError());

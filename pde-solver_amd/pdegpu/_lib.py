@@ -77,12 +77,14 @@ SYMBOLS = {
     "pdegpu_heat_tables_host": (C.c_int, [C.POINTER(Grid), _dp, _dp, _dp]),
     "pdegpu_elasticity_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_elasticity_apply": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp, C.c_int]),
+    "pdegpu_elasticity_time_apply": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), C.c_int, C.c_int, _dp]),
     "pdegpu_elasticity_tables_host": (C.c_int, [C.POINTER(Grid), C.c_double, C.c_double, _dp]),
     "pdegpu_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "pdegpu_session_destroy": (None, [_vp]),
     "pdegpu_session_begin": (C.c_int, [_vp, C.c_double]),
     "pdegpu_session_plane_ptr": (_vp, [_vp, C.c_int, C.c_int64]),
     "pdegpu_session_plane_doubles": (C.c_int64, [_vp]),
+    "pdegpu_session_needs_p_halo": (C.c_int, [_vp]),
     "pdegpu_session_scalars": (_vp, [_vp]),
     "pdegpu_session_residual": (C.c_int, [_vp]),
     "pdegpu_session_k1": (C.c_int, [_vp]),

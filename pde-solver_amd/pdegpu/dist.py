@@ -101,6 +101,9 @@ class GpuSlabEngine:
             raise L.PdeGpuError(L.EINVAL, f"no plane {which} of vector {vec}")
         return torch.as_tensor(_DevArray(ptr, self.plane), device=f"cuda:{self.device}")
 
+    def needs_p_halo(self) -> bool:
+        return bool(self.lib.pdegpu_session_needs_p_halo(self.s))
+
     def iterate_native(self, iters: int, time_kernels: bool, stats=None):
         self._ck(self.lib.pdegpu_session_iterate(self.s, iters, 1 if time_kernels else 0, stats))
 
@@ -153,8 +156,10 @@ class SlabCG:
         self.iterations = 0
 
     def iterate(self, iters: int):
+        # K1 needs r_n and p_{n-1} on the ghost planes; engines whose K1 maintains p there itself only exchange r
+        vecs = (VEC_R, VEC_P) if getattr(self.e, "needs_p_halo", lambda: True)() else (VEC_R,)
         for _ in range(iters):
-            self.exchange_halos((VEC_R, VEC_P))
+            self.exchange_halos(vecs)
             self.e.k1()
             self.allreduce(0)
             self.e.k2()

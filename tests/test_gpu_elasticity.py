@@ -34,6 +34,24 @@ def test_block_operator_matches_assembled_matrix(lib, gpu_ctx, dim, n, Ls, plane
     assert rel_err(y, ref) < 1e-12
 
 
+@pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((37, 3, 2), (2.0, 0.3, 0.2)), ((16, 1, 1), (1.0, 0.1, 0.1))])
+def test_mfma_element_by_element_apply_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
+    """v_mfma_f64_16x16x4_f64 element-by-element form (24x24 macro element, scatter by fp64 atomics) == matrix;
+    ragged 16-element batches included"""
+    from pdegpu import _lib
+    E, nu = 210e9, 0.3
+    lam, mu = o.lame(E, nu)
+    c, cells = o.box_mesh(*Ls, *n)
+    K = o.assemble_elasticity(c, cells, lam, mu)
+    u = np.random.default_rng(5).uniform(-1, 1, (c.shape[0], 3))
+    y = np.empty_like(u)
+    el = _lib.Elasticity()
+    el.E, el.nu = E, nu
+    _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, _lib.make_grid(3, n, Ls), el, _lib.dptr(u), _lib.dptr(y), 1))
+    ref = (K @ u.ravel()).reshape(-1, 3)
+    assert rel_err(y, ref) < 1e-12
+
+
 @pytest.mark.parametrize("quantity", ["stress", "strain"])
 def test_bar_1d_matches_oracle(lib, gpu_ctx, quantity):
     from pdegpu import elasticity

@@ -250,9 +250,9 @@ def test_fast_and_general_sessions_agree(lib, gpu_ctx):
     assert rel_err(out[0][1], out[1][1]) < 1e-11
 
 
-@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("fast,variant", [(1, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("nslabs", [2, 3])
-def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, nslabs):
+def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs):
     """slab sessions (k0 > 0, ghost planes, global boundary classes) with the halo exchange / all-reduce done by
     plain device copies on ONE GPU: same order of operations as pdegpu.dist.SlabCG.iterate, no RCCL needed.
     Must reproduce the single-slab CG iterates and the oracle's solution."""
@@ -274,9 +274,13 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, nslabs):
             for r in range(ns):
                 k0, nk = slab_range(n[2] + 1, ns, r)
                 engs.append(GpuSlabEngine(grid, h, k0, nk, 0, stream))
+                _lib.check(engs[-1].ctx, lib.pdegpu_set_tunable(engs[-1].ctx, b"cg_variant", variant))
+            # the 64-B variant keeps p on the ghost planes itself: only r is exchanged
+            assert engs[0].needs_p_halo() == (not (fast == 1 and variant == 1))
+            vecs = (VEC_R, VEC_P) if engs[0].needs_p_halo() else (VEC_R,)
 
             def exchange():
-                for v in (VEC_R, VEC_P):
+                for v in vecs:
                     for r in range(ns - 1):
                         lo, hi = engs[r], engs[r + 1]
                         hi.plane_tensor(v, -1).copy_(lo.plane_tensor(v, lo.nk - 1))

@@ -54,4 +54,8 @@ import re
 k1 = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 2[,>]", k)]
 if k1:
     (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "source": f"{rnd}{tag}_pmc_summary.json"}))
+k2 = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 3[,>]", k)]
+if k1 and k2:
+    (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "k2_hbm_bytes_per_launch": k2[0]["hbm_bytes"],
+                                                      "source": f"{rnd}{tag}_pmc_summary.json"}))
 print(json.dumps(summary, indent=1)[:3000])

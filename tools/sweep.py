@@ -17,18 +17,15 @@ grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0))
 N = (n - 1) ** 3
 
 configs = []
-base = dict(fast_ry=2, fast_nt=3, fast_wg_per_cu=0, k2_variant=0, grid_mult=8, k2_grid_mult=2)
-for rep in range(3):
-    for kv in (0, 1, 2, 4, 5):
-        for gm in (1, 2, 3, 4):
-            configs.append(dict(base, k2_variant=kv, k2_grid_mult=gm))
+base = dict(fast_ry=2, fast_nt=-1, fast_wg_per_cu=0, k2_variant=0, grid_mult=8, k2_grid_mult=2, cg_variant=1)
+for rep in range(2):
+    for cv, ry in ((0, 2), (1, 2), (1, 4)):
+        configs.append(dict(base, cg_variant=cv, fast_ry=ry))
 if len(sys.argv) > 3:
     configs = [dict(base, **eval(sys.argv[3]))]
 
-for steady in (1,):
+for steady in (1, 0):
     for cfg in configs:
-        if steady == 0 and (cfg["k2_variant"] or cfg["grid_mult"] != 8):
-            continue
         for k, v in cfg.items():
             L.check(ctx, lib.pdegpu_set_tunable(ctx, k.encode(), v))
         h = L.Heat()
@@ -48,7 +45,8 @@ for steady in (1,):
         ms = C.c_double()
         L.check(ctx, lib.pdegpu_session_time_apply(s, 2, C.byref(ms)))
         k1, k2 = st.kernel_ms[0] / iters, st.kernel_ms[1] / iters
-        print(f"steady={steady} {cfg}: K1 {k1:.3f} ms {48*N/k1/1e6:6.0f} GB/s | K2 {k2:.3f} ms {24*N/k2/1e6:6.0f} GB/s | "
+        tot = (k1 + k2)
+        print(f"steady={steady} cv={cfg['cg_variant']} ry={cfg['fast_ry']}: K1+K2 {tot:.3f} ms -> {N/tot/1e6:.1f} GDoF/s | K1 {k1:.3f} ms {48*N/k1/1e6:6.0f} GB/s | K2 {k2:.3f} ms {24*N/k2/1e6:6.0f} GB/s | "
               f"SpMV {ms.value:.3f} ms {16*N/ms.value/1e6:6.0f} GB/s | rr {rr.value:.9e}", flush=True)
         if False:
             names = ["copy 1R+1W", "read 1R", "write 1W", "triad 2R+1W", "inplace 2R+1W"]
