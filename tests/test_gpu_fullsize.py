@@ -1,0 +1,73 @@
+"""Parity at BASELINE.json's full size (config 3: 512^3 cells, 513^3 nodes), where the oracle cannot run:
+size-independent properties of the operator and an independent residual check of a real solve."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N1 = 513
+
+
+def _apply(lib, ctx, cM, cK, x):
+    from pdegpu import _lib
+    g = _lib.make_grid(3, (512, 512, 512), (1.0, 1.0, 1.0))
+    y = np.empty_like(x)
+    _lib.check(ctx, lib.pdegpu_heat_apply(ctx, g, cM, cK, _lib.dptr(x), _lib.dptr(y), None, 1))
+    return y
+
+
+def test_operator_properties_at_512_cubed(lib, gpu_ctx):
+    """fused z-marching kernels at full size: K annihilates constants, <Ax,y> == <x,Ay>, A(ax+by) == aAx+bAy,
+    Dirichlet rows are exactly zero, and the interior row of a delta is the closed-form 7-point stencil"""
+    rng = np.random.default_rng(7)
+    n = N1 ** 3
+    interior = np.zeros((N1, N1, N1), bool)
+    interior[1:-1, 1:-1, 1:-1] = True
+    interior = interior.ravel()
+    x = rng.uniform(-1, 1, n)
+    y = rng.uniform(-1, 1, n)
+    # the operator under test is P A P: symmetric on vectors that vanish on the Dirichlet nodes
+    x[~interior] = 0.0
+    y[~interior] = 0.0
+    Ax = _apply(lib, gpu_ctx, 0.0, 1.0, x)
+    Ay = _apply(lib, gpu_ctx, 0.0, 1.0, y)
+    assert np.all(Ax[~interior] == 0.0)
+    lhs, rhs = float(Ax @ y), float(x @ Ay)
+    assert abs(lhs - rhs) <= 1e-11 * (np.linalg.norm(Ax) * np.linalg.norm(y))
+    assert float(x @ Ax) > 0.0                                              # positive definite on the free nodes
+    comb = _apply(lib, gpu_ctx, 0.0, 1.0, 0.7 * x - 1.3 * y)
+    assert np.abs(comb - (0.7 * Ax - 1.3 * Ay)).max() <= 1e-12 * np.abs(Ax).max()
+    ones = _apply(lib, gpu_ctx, 0.0, 1.0, np.ones(n))
+    h = 1.0 / 512
+    assert np.abs(ones).max() <= 1e-12 * 6 * h                              # K 1 = 0 on every free row
+    delta = np.zeros(n)
+    c = (256 * N1 + 300) * N1 + 123
+    delta[c] = 1.0
+    col = _apply(lib, gpu_ctx, 1.0, 0.25, delta)                            # M + 0.25 K: 15-point kernel
+    v = h ** 3
+    expect = {0: 0.4 * v + 0.25 * 6 * h, 1: v / 20 - 0.25 * h, N1: v / 20 - 0.25 * h, N1 * N1: v / 20 - 0.25 * h,
+              1 + N1: v / 30, 1 + N1 * N1: v / 30, N1 + N1 * N1: v / 30, 1 + N1 + N1 * N1: v / 20}
+    for off, w in expect.items():
+        for sgn in ((1, -1) if off else (1,)):
+            assert col[c + sgn * off] == pytest.approx(w, rel=1e-12)
+    assert np.count_nonzero(col) == 15
+
+
+def test_steady_solve_at_512_cubed_satisfies_its_equation(lib, gpu_ctx):
+    """config 3(ii): steady kappa K u = f m, f = 1, T_b = 0, rtol 1e-8; the returned field is checked by an
+    independent application of the operator (||b - A u|| <= 2e-8 ||b||), by the maximum principle, by the
+    symmetry of the solution and against the known maximum of the continuous problem"""
+    from pdegpu import heat
+    f = heat._solve_heat_3d_raw(1.0, 1.0, 1.0, 512, 512, 512, 1.0, 0.0, 0.0, 0.1, 1, steady=True,
+                                source_type="constant", source_value=1.0, rtol=1e-8)
+    u = f.values[0]
+    assert f.meta["solver_path"] == "fast" and f.values.shape == (1, N1 ** 3)
+    Au = _apply(lib, gpu_ctx, 0.0, 1.0, u)
+    h = 1.0 / 512
+    U = u.reshape(N1, N1, N1)
+    r = (h ** 3 - Au.reshape(N1, N1, N1))[1:-1, 1:-1, 1:-1]
+    bnorm = h ** 3 * 511 ** 1.5
+    assert np.linalg.norm(r.ravel()) <= 2e-8 * bnorm
+    assert U.min() >= 0.0 and np.all(U[0] == 0.0) and np.all(U[:, :, -1] == 0.0)
+    assert U.max() == pytest.approx(0.0562128, rel=2e-4)                    # max of -Lap u = 1 on the unit cube
+    assert np.abs(U - U[::-1]).max() <= 1e-6 * U.max() and np.abs(U - U.transpose(2, 1, 0)).max() <= 1e-6 * U.max()
+    print(f"\n512^3 steady solve: {f.meta['cg_iterations']} CG iterations")
