@@ -406,6 +406,22 @@ inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
     return (int)nb;
 }
 
+struct EventPair {                 // RAII so that early returns do not leak events
+    hipEvent_t a = nullptr, b = nullptr;
+    bool ok = false;
+    EventPair() { ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess; }
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    float elapsed() {
+        float ms = 0;
+        (void)hipEventSynchronize(b);
+        (void)hipEventElapsedTime(&ms, a, b);
+        return ms;
+    }
+};
+
 struct ElSession {
     pdegpu_ctx* ctx = nullptr;
     GridDev g{};
@@ -607,10 +623,9 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     st.converged = 1;
     st.n_nodes = (int64_t)N;
     st.n_unknowns = (int64_t)D * (int64_t)(N - N / (grid->n[0] + 1));
-    hipEvent_t e0, e1;
-    PG_HIP(ctx, hipEventCreate(&e0));
-    PG_HIP(ctx, hipEventCreate(&e1));
-    PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    EventPair whole, cgt;
+    if (!whole.ok || !cgt.ok) return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipEventCreate failed");
+    PG_HIP(ctx, hipEventRecord(whole.a, ctx->stream));
 
     // b = body * m ; r = P(b - A 0) ; z = D^-1 r
     hipLaunchKernelGGL(k_el_load, dim3(s.nblk), dim3(256), 0, ctx->stream, s.g, s.stride, D, s.ht.d_load, el->body[0], el->body[1],
@@ -632,10 +647,7 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     const double target = rtol * rtol * bnorm2;
     double rr = bnorm2;
     int it = 0, chunk = 16;
-    hipEvent_t c0, c1;
-    PG_HIP(ctx, hipEventCreate(&c0));
-    PG_HIP(ctx, hipEventCreate(&c1));
-    PG_HIP(ctx, hipEventRecord(c0, ctx->stream));
+    PG_HIP(ctx, hipEventRecord(cgt.a, ctx->stream));
     while (rr > target && it < max_iter && std::isfinite(rr)) {
         const int n = std::min(chunk, max_iter - it);
         for (int i = 0; i < n; ++i) {
@@ -654,12 +666,8 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
         else hipLaunchKernelGGL(k_el_flush<2>, dim3(s.nblk), dim3(256), 0, ctx->stream, a, s.p[s.pcur]);
         PG_HIP(ctx, hipGetLastError());
     }
-    PG_HIP(ctx, hipEventRecord(c1, ctx->stream));
-    PG_HIP(ctx, hipEventSynchronize(c1));
-    float cms = 0;
-    PG_HIP(ctx, hipEventElapsedTime(&cms, c0, c1));
-    (void)hipEventDestroy(c0);
-    (void)hipEventDestroy(c1);
+    PG_HIP(ctx, hipEventRecord(cgt.b, ctx->stream));
+    const float cms = cgt.elapsed();
     st.cg_iterations = it;
     st.cg_ms = cms;
     st.linear_solves = 1;
@@ -675,8 +683,11 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     const long long ncell = (long long)cx * cy * cz;
     VmGeom vg = make_vm_geom(grid);
     double *d_vm = nullptr, *d_dense = nullptr;
-    PG_HIP(ctx, hipMalloc(&d_vm, (size_t)vg.ns * ncell * sizeof(double)));
-    PG_HIP(ctx, hipMalloc(&d_dense, N * sizeof(double)));
+    if (hipMalloc(&d_vm, (size_t)vg.ns * ncell * sizeof(double)) != hipSuccess ||
+        hipMalloc(&d_dense, N * sizeof(double)) != hipSuccess) {
+        if (d_vm) (void)hipFree(d_vm);
+        return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc of the von Mises work arrays failed");
+    }
     if (D == 3) {
         hipLaunchKernelGGL(k_vm_cells<3>, dim3(flat_grid(ctx, ncell)), dim3(256), 0, ctx->stream, s.g, s.stride, s.x, vg, s.lam, s.mu,
                            el->quantity, d_vm);
@@ -701,13 +712,8 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     pdegpu_stats st2{};
     if (rc2 == PDEGPU_OK) rc2 = pdegpu_mass_solve(ctx, grid, rhs.data(), field_out, 1e-13, 100000, &st2);
     st.linear_solves += st2.linear_solves;
-    PG_HIP(ctx, hipEventRecord(e1, ctx->stream));
-    PG_HIP(ctx, hipEventSynchronize(e1));
-    float ms = 0;
-    PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    st.solve_ms = ms;
+    PG_HIP(ctx, hipEventRecord(whole.b, ctx->stream));
+    st.solve_ms = whole.elapsed();
     if (stats) *stats = st;
     return rc2 != PDEGPU_OK ? rc2 : rc;
 }
@@ -728,7 +734,7 @@ int el_apply_mfma(ElSession* s, const double* u, double* y, double* d_Ke) {
 int upload_macro_element(ElSession* s, const pdegpu_grid* grid, double** d_Ke) {
     double h[3] = {1, 1, 1};
     for (int r = 0; r < grid->dim; ++r) h[r] = grid->L[r] / grid->n[r];
-    static thread_local double Ke[24 * 24];
+    double Ke[24 * 24];
     for (int la = 0; la < 8; ++la)
         for (int lb = 0; lb < 8; ++lb) {
             double blk[9];

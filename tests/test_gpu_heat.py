@@ -326,3 +326,47 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs)
     assert np.allclose(hs, h1, rtol=1e-10)
     assert rel_err(x1, ref) < TOL and rel_err(xs, ref) < TOL
     assert rel_err(xs, x1) < 1e-11
+
+
+def test_rccl_backend_on_library_owned_memory(lib, gpu_ctx):
+    """one-rank `nccl` (= RCCL) process group on this GPU: the all-reduce of the device scalars and a plane
+    send/recv-to-self run on zero-copy tensor views of library-owned memory — the exact objects the multi-GPU
+    driver hands to torch.distributed (world sizes > 1 need more GPUs than the test box has)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pdegpu import _lib
+    from pdegpu.dist import GpuSlabEngine, SlabCG, SC_RR
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        grid = _lib.make_grid(3, (24, 10, 12), (1.0, 1.0, 1.0))
+        h = _lib.Heat()
+        h.kappa, h.steady, h.source = 1.0, 1, 1.0
+        h.bc_mode, h.fast_path = _lib.BC_UNIFORM, 1
+        h.bc_present[0] = 1
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            eng = GpuSlabEngine(grid, h, 0, 13, 0, stream)
+            cg = SlabCG(eng, 0, 1)
+            cg.start(0.0)
+            rr0 = eng.rr()
+            t = eng.scalars()[SC_RR:SC_RR + 1]
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)               # in place on library memory
+            torch.cuda.synchronize()
+            assert eng.rr() == rr0
+            src, dst = eng.plane_tensor(1, 3), eng.plane_tensor(3, 5)
+            ops = [dist.P2POp(dist.isend, src, 0), dist.P2POp(dist.irecv, dst, 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(src, dst) and float(src.abs().sum()) > 0
+            cg.iterate(20)
+            assert eng.rr() < rr0
+            eng.close()
+    finally:
+        dist.destroy_process_group()
