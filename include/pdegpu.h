@@ -121,7 +121,8 @@ const char* pdegpu_version(void);
 /* performance tunables of a context (also read from PDEGPU_<KEY> at pdegpu_create): "fast_ry" rows per thread of
  * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_wg_per_cu" (0 = occupancy API),
  * "k2_variant" (0..5), "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
- * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF).  Results do not depend on them. */
+ * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF), "use_graph"
+ * (1 = replay the CG inner loop from a captured hipGraph).  Results do not depend on them. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 
 /* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw
@@ -189,9 +190,9 @@ int64_t pdegpu_session_plane_doubles(const pdegpu_session* s);
  * variant); 0 when k1 maintains p on the ghost planes itself (fused z-marching kernels, cg_variant 1): then only
  * r is exchanged. */
 int     pdegpu_session_needs_p_halo(const pdegpu_session* s);
-/* pointer to the 4 device scalars {pq_local, rr_local, pq_global, rr_global}.  After
- * pdegpu_session_reduce_local the *_local entries hold this slab's partial dot products; the host
- * all-reduces them into *_global (single GPU: pdegpu_session_reduce_local copies local->global). */
+/* pointer to the device scalars {pq_local, rr_local, pq_global, rr_global, rr_global_prev, ...}.  residual / k1 /
+ * k2 leave this slab's dot product in BOTH the *_local and the *_global slot; the multi-GPU host all-reduces
+ * the *_global slot in place (8 bytes, stays on the device); single GPU: nothing to do. */
 double* pdegpu_session_scalars(pdegpu_session* s);
 int  pdegpu_session_residual(pdegpu_session* s);            /* r = P(b - A x), rr_local */
 int  pdegpu_session_k1(pdegpu_session* s);                  /* x+=a*p; p=r+beta*p; q=A p; pq_local */

@@ -23,6 +23,9 @@ struct pdegpu_ctx {
     int k2_variant = 0;         // 0: grid-stride double2; 1: 4x unrolled; 2: 4x unrolled + non-temporal
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
+    int use_graph = 0;          // opt-in: replay the CG inner loop from a captured hipGraph.  Measured: no gain (the small
+                                // configs are bound by kernel time, not launches) and rocprofv3 7.2 crashes on graph launches
+    int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
     int k2_grid_mult = 2;       // K2: workgroups per CU (few, deep streams beat many shallow ones on mixed R/W)
     std::string err;
     char name[256] = {0};
@@ -149,6 +152,29 @@ struct StencilArgs {
 enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_COUNT = 8 };
 
 struct LaunchInfo { int grid = 0; int block = 256; };
+
+// hipGraph of an even number of CG iterations (the p ping-pong returns to its starting buffer), replayed from
+// the context stream.  `key` = the tunables the captured launches depend on.
+struct CgGraph {
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    int iters = 0;
+    int pcur = -1;
+    long long key = -1;
+    void reset() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr;
+        graph = nullptr;
+        iters = 0;
+        pcur = -1;
+        key = -1;
+    }
+};
+inline long long tunable_key(const pdegpu_ctx* c) {
+    return ((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 8 + c->k2_variant) * 128 + c->grid_mult) * 128 +
+            c->k2_grid_mult) * 4 + c->cg_variant;
+}
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 bool stencil_fast_supported(const GridDev& g, int element_mode);

@@ -524,7 +524,11 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     s->mu = el->E / (2.0 * (1.0 + el->nu));
     if (grid->dim == 2 && el->plane_stress) s->lam = el->E * el->nu / (1.0 - el->nu * el->nu);         // :1660-1661
     else s->lam = el->E * el->nu / ((1.0 + el->nu) * (1.0 - 2.0 * el->nu));                           // :1664-1665, :1813-1814
-    s->nblk = flat_grid(ctx, (long long)s->g.nkl * s->g.PP);
+    {
+        long long nb = ((long long)s->g.nkl * s->g.PP + 255) / 256;
+        const long long cap = (long long)ctx->el_grid_mult * ctx->num_cu;
+        s->nblk = (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
+    }
     PG_HIP(ctx, hipMalloc(&s->tab, 27 * PG_NOFF15 * 9 * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->dinv, 81 * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->scal, ESC_COUNT * sizeof(double)));

@@ -31,6 +31,8 @@ struct pdegpu_session {
     double* d_dense = nullptr;
     double* h_pin = nullptr;       // pinned host scalars
     std::vector<hipEvent_t> events;
+    CgGraph cg_graph;
+    long long eager_iters = 0;     // iterations launched eagerly so far (occupancy queries etc. are done)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -235,7 +237,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -253,6 +255,8 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "grid_mult")) return &ctx->grid_mult;
     if (!strcmp(key, "k2_grid_mult")) return &ctx->k2_grid_mult;
     if (!strcmp(key, "cg_variant")) return &ctx->cg_variant;
+    if (!strcmp(key, "use_graph")) return &ctx->use_graph;
+    if (!strcmp(key, "el_grid_mult")) return &ctx->el_grid_mult;
     return nullptr;
 }
 }  // namespace
@@ -261,7 +265,7 @@ extern "C" int pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return PDEGPU_EINVAL;
     int* slot = tunable_slot(ctx, key);
     if (!slot) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown tunable '%s'", key);
-    if ((!strcmp(key, "grid_mult") || !strcmp(key, "k2_grid_mult")) && (value < 1 || value > 64)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "grid_mult must be 1..64");
+    if ((!strcmp(key, "grid_mult") || !strcmp(key, "k2_grid_mult") || !strcmp(key, "el_grid_mult")) && (value < 1 || value > 64)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "grid_mult must be 1..64");
     *slot = value;
     return PDEGPU_OK;
 }
@@ -295,6 +299,7 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     if (s->d_dense) (void)hipFree(s->d_dense);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    s->cg_graph.reset();
     delete s;
 }
 
@@ -382,7 +387,7 @@ extern "C" int pdegpu_session_residual(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     PG_TRY(op_residual(s, s->x.v, s->b.v, s->r.v, &li));
-    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 0);
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 1);
 }
 
 extern "C" int pdegpu_session_k1(pdegpu_session* s) {
@@ -390,7 +395,7 @@ extern "C" int pdegpu_session_k1(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     PG_TRY(op_k1(s, &li));
-    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 0, 0);
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 0, 1);
 }
 
 extern "C" int pdegpu_session_k2(pdegpu_session* s) {
@@ -398,10 +403,11 @@ extern "C" int pdegpu_session_k2(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     PG_TRY(op_k2(s, &li));
-    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 0);
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 1);
 }
 
-// single-slab convenience: local -> global (the multi-GPU host all-reduces instead)
+// k1 / k2 / residual already leave this slab's sum in BOTH the local and the global slot (the multi-GPU host then
+// all-reduces the global slot in place); this re-copies local -> global, e.g. to undo an all-reduce in tests
 extern "C" int pdegpu_session_reduce_local(pdegpu_session* s, int which, int copy_to_global) {
     if (!s || (which != 0 && which != 1)) return PDEGPU_EINVAL;
     if (!copy_to_global) return PDEGPU_OK;
@@ -419,6 +425,42 @@ extern "C" int pdegpu_session_flush(pdegpu_session* s) {
     return PDEGPU_OK;
 }
 
+namespace {
+constexpr int kGraphIters = 8;     // iterations per captured graph (even)
+
+int cg_one_iteration(pdegpu_session* s, LaunchInfo* l1, LaunchInfo* l2) {
+    PG_TRY(op_k1(s, l1));
+    PG_TRY(vec_reduce(s->ctx, s->d_part, l1->grid, s->d_scal, 0, 1));
+    PG_TRY(op_k2(s, l2));
+    return vec_reduce(s->ctx, s->d_part, l2->grid, s->d_scal, 1, 1);
+}
+
+// capture kGraphIters iterations on the context stream (nothing executes; host-side pcur ends where it started)
+int cg_graph_prepare(pdegpu_session* s) {
+    pdegpu_ctx* ctx = s->ctx;
+    CgGraph& g = s->cg_graph;
+    const long long key = tunable_key(ctx);
+    if (g.exec && g.key == key && g.pcur == s->pcur) return PDEGPU_OK;
+    g.reset();
+    PG_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = PDEGPU_OK;
+    LaunchInfo l1, l2;
+    for (int it = 0; it < kGraphIters && rc == PDEGPU_OK; ++it) rc = cg_one_iteration(s, &l1, &l2);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != PDEGPU_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc != PDEGPU_OK ? rc : pdegpu_set_err(ctx, PDEGPU_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    }
+    g.graph = graph;
+    PG_HIP(ctx, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    g.iters = kGraphIters;
+    g.pcur = s->pcur;
+    g.key = key;
+    return PDEGPU_OK;
+}
+}  // namespace
+
 extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_kernels, pdegpu_stats* stats) {
     if (!s || iters < 0) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;
@@ -430,7 +472,23 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
         s->events.push_back(e);
     }
     LaunchInfo l1, l2;
-    for (int it = 0; it < iters; ++it) {
+    int done = 0;
+    // launch-bound grids: replay the inner loop from a captured hipGraph (after two eager iterations, which
+    // also run the one-time occupancy queries).  Timed runs stay eager: every launch is bracketed by events.
+    if (!time_kernels && ctx->use_graph && ctx->stream != nullptr) {
+        while (s->eager_iters < 2 && done < iters) {
+            PG_TRY(cg_one_iteration(s, &l1, &l2));
+            ++done;
+            ++s->eager_iters;
+        }
+        if (iters - done >= kGraphIters && cg_graph_prepare(s) == PDEGPU_OK) {
+            while (iters - done >= kGraphIters) {
+                PG_HIP(ctx, hipGraphLaunch(s->cg_graph.exec, ctx->stream));
+                done += kGraphIters;
+            }
+        }
+    }
+    for (int it = done; it < iters; ++it) {
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 0], ctx->stream));
         PG_TRY(op_k1(s, &l1));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 1], ctx->stream));
@@ -439,6 +497,7 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
         PG_TRY(op_k2(s, &l2));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
         PG_TRY(vec_reduce(ctx, s->d_part, l2.grid, s->d_scal, 1, 1));
+        ++s->eager_iters;
     }
     if (stats) {
         stats->cg_iterations += iters;

@@ -106,6 +106,21 @@ _lock = threading.Lock()
 _ctx_cache = {}
 
 
+def _bind_single_hip_runtime() -> None:
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64.so.7 next to the system
+    one in /opt/rocm (same SONAME): if libpdegpu.so pulls in the system copy first and torch is imported later,
+    torch finds "no ROCm-capable device" (measured on the MI355X pool, tools/order_probe.py).  Importing torch
+    first makes libpdegpu.so resolve its NEEDED libamdhip64.so.7 to the copy torch already loaded, which is the
+    combination bench.py, the multi-GPU driver and the test-suite run.  Without torch installed the system
+    runtime is used."""
+    if os.environ.get("PDEGPU_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def load_library() -> C.CDLL:
     """dlopen the in-tree HIP library; fails loudly when it has not been built."""
     global _lib
@@ -115,6 +130,7 @@ def load_library() -> C.CDLL:
                 raise PdeGpuError(ENODEV, f"{LIB_PATH} is missing — build it with `python -c 'import "
                                           f"__graft_entry__ as g; g.build()'` or `make -C {PKG_ROOT}`; "
                                           "there is no CPU fallback")
+            _bind_single_hip_runtime()
             lib = C.CDLL(str(LIB_PATH))
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(lib, name)          # AttributeError if the header and the library disagree

@@ -90,7 +90,7 @@ class GpuSlabEngine:
         self._ck(self.lib.pdegpu_session_flush(self.s))
 
     def local_to_global(self, which: int):
-        self._ck(self.lib.pdegpu_session_reduce_local(self.s, which, 1))
+        pass            # residual / k1 / k2 already left the slab's sum in the global slot (no extra device op)
 
     def scalars(self) -> torch.Tensor:
         return self._scal

@@ -199,3 +199,11 @@ def test_elasticity_block_tables_match_oracle_assembly(lib, dim, n, Ls):
             seen[row * dim:(row + 1) * dim, col * dim:(col + 1) * dim] = True
         # the 15 offsets are ALL the couplings of this row
         assert np.abs(K[row * dim:(row + 1) * dim][~seen[row * dim:(row + 1) * dim]]).max() < 1e-12 * scale
+
+
+def test_loader_binds_one_hip_runtime(lib):
+    """after load_library() the process maps exactly one libamdhip64 (torch's copy when torch is installed), so
+    importing torch before or after pdegpu cannot end with two HIP runtimes"""
+    maps = open("/proc/self/maps").read()
+    paths = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
+    assert len(paths) == 1, paths
