@@ -370,3 +370,28 @@ def test_rccl_backend_on_library_owned_memory(lib, gpu_ctx):
             eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_random_shapes_fast_and_general_apply(lib, gpu_ctx):
+    """seeded sweep over ragged 3-D shapes and anisotropic cells: tile edges of the z-marching kernels (x-tiles of
+    128, y-tiles of 2 rows, z-chunks) and every boundary class of the general kernels vs the assembled matrices"""
+    from pdegpu import _lib
+    rng = np.random.default_rng(2026)
+    shapes = [(int(rng.integers(2, 300)), int(rng.integers(2, 14)), int(rng.integers(2, 40))) for _ in range(10)]
+    shapes += [(127, 3, 9), (128, 4, 9), (129, 5, 8), (256, 2, 17), (257, 3, 3), (3, 3, 97)]
+    for n in shapes:
+        Ls = tuple(float(v) for v in rng.uniform(0.2, 2.0, 3))
+        c, cells = o.box_mesh(*Ls, *n)
+        K, M, _ = o.assemble_scalar(c, cells)
+        x = rng.uniform(-1, 1, c.shape[0])
+        mask, _ = o.box_dirichlet(*n, T_boundary=0.0)
+        g = _lib.make_grid(3, n, Ls)
+        for cM, cK in ((0.0, 1.0), (1.0, 0.013)):
+            ref = cM * (M @ x) + cK * (K @ x)
+            y = np.empty_like(x)
+            _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, g, cM, cK, _lib.dptr(x), _lib.dptr(y), None, 0))
+            assert rel_err(y, ref) < 1e-13, (n, cM, "general")
+            _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, g, cM, cK, _lib.dptr(x), _lib.dptr(y), None, 1))
+            refm = ref.copy()
+            refm[mask] = 0.0
+            assert np.all(y[mask] == 0.0) and rel_err(y, refm) < 1e-13, (n, cM, "fast")

@@ -20,14 +20,22 @@ prof = ROOT / "gpurun_out" / "prof"
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 
-stats = glob.glob(str(prof / "stats" / "*" / "*_kernel_stats.csv"))
+import os
+
+
+def newest(pattern):
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)      # gpurun merges every run into the same folders
+    return files[-1:] if files else []
+
+
+stats = newest(str(prof / "stats" / "*" / "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], out / f"{rnd}{tag}_kernel_stats.csv")
 
 
 def counters(kind, name):
     acc = collections.defaultdict(list)
-    files = glob.glob(str(prof / kind / "*" / "*_counter_collection.csv"))
+    files = newest(str(prof / kind / "*" / "*_counter_collection.csv"))
     if not files:
         return acc
     for row in csv.DictReader(open(files[0])):
