@@ -134,6 +134,26 @@ int pdegpu_heat_num_snapshots(const pdegpu_heat* h);
 int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat,
                       const double* u0, double* values_out, double* times_out, pdegpu_stats* stats);
 
+/* ---- curvilinear heat tools (_solve_heat_1d_cylindrical_raw :769, _1d_spherical :925, _2d_cylindrical :1063,
+ *      _2d_spherical :1195, _3d_spherical :1333): the same P1 discretisation on IntervalMesh / RectangleMesh / BoxMesh
+ *      in COORDINATE space [origin, origin + L] with one scalar weight w multiplying the mass and the stiffness
+ *      form; w enters as the P1 / P2 interpolant of an Expression of degree 1 / 2 and is integrated exactly.
+ *      Constant initial condition only (:872-875). */
+#define PDEGPU_WEIGHT_R     1      /* w = x0            Expression("x[0]", degree=1)               (:802, :1100) */
+#define PDEGPU_WEIGHT_R2    2      /* w = x0^2          Expression("x[0] * x[0]", degree=2)        (:965)        */
+#define PDEGPU_WEIGHT_R2SIN 3      /* w = x0^2 sin(x1)  Expression("x[0] * x[0] * sin(x[1])", 2)   (:1230, :1371) */
+typedef struct pdegpu_weight {
+    int32_t kind;               /* PDEGPU_WEIGHT_* */
+    int32_t reserved;
+    double  origin[3];          /* lower corner of the mesh in coordinate space (r_inner, 0, 0) */
+} pdegpu_weight;
+int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
+                               const pdegpu_heat* heat, double* values_out, double* times_out, pdegpu_stats* stats);
+/* host twin of the per-node weighted assembly (CPU tests): rowsK / rowsM [N][15] (15-offset order
+ * {0, -x, +x, -y, +y, -z, +z, -(xy), +(xy), -(xz), +(xz), -(yz), +(yz), -(xyz), +(xyz)}), load [N] */
+int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const double* origin, int kind, double* rowsK, double* rowsM,
+                              double* load);
+
 /* ---- project(f, V) with a consistent mass matrix (:284, :415, :679, :1542, :1714, :1862):
  *      solves M s = rhs on the device, rhs[N] is the assembled load vector int f phi_i. */
 int pdegpu_mass_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const double* rhs, double* s_out,

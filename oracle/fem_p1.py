@@ -437,3 +437,186 @@ def solve_elasticity_3d(Lx, Ly, Lz, nx, ny, nz, E, nu, body_fx=0.0, body_fy=0.0,
             "pde": "elasticity_3d", "Lx": Lx, "Ly": Ly, "Lz": Lz, "E": E, "nu": nu, "body_fx": body_fx,
             "body_fy": body_fy, "body_fz": body_fz, "quantity": quantity}
     return OracleField(coords, s[None, :], np.array([0.0]), 3, meta, {"displacement": u, "cell_vm": vm, "proj_rhs": r})
+
+
+# ----------------------------------------------------------------------------------------------
+# curvilinear heat tools (:769-1464): P1 on a box mesh in COORDINATE space with one scalar weight w
+# multiplying both forms,  a = w u v dx + dt kappa w grad(u).grad(v) dx,  L = w u_n v dx + dt w f v dx.
+# w is an Expression of degree 1 or 2, i.e. it enters the forms as its P1 / P2 interpolant on every cell
+# and the products are integrated exactly (the form compiler picks the quadrature degree from the
+# polynomial degrees).   kind: "r" = x0 (degree 1; :802, 1100), "r2" = x0^2 (degree 2; :965),
+# "r2sin" = x0^2 sin(x1) (degree 2; :1230, 1371).
+# ----------------------------------------------------------------------------------------------
+WEIGHTS = {
+    "r": (1, lambda X: X[:, 0]),
+    "r2": (2, lambda X: X[:, 0] ** 2),
+    "r2sin": (2, lambda X: X[:, 0] ** 2 * np.sin(X[:, 1])),
+}
+
+
+def _mono(d, idxs):
+    """int over a unit-volume d-simplex of prod_{i in idxs} lambda_i = d! prod p! / (sum p + d)!"""
+    counts = {}
+    for i in idxs:
+        counts[i] = counts.get(i, 0) + 1
+    num = math.factorial(d)
+    for p in counts.values():
+        num *= math.factorial(p)
+    return num / math.factorial(len(idxs) + d)
+
+
+def _weight_terms(coords, cells, kind):
+    """the interpolated weight of every cell as a list of (coefficient[nc], barycentric index tuple):
+    degree 1: sum_v w_v l_v;  degree 2: sum_v w_v (2 l_v^2 - l_v) + sum_e w_e 4 l_a l_b"""
+    degree, fn = WEIGHTS[kind]
+    d = coords.shape[1]
+    m = d + 1
+    P = coords[cells]
+    Xv = P.reshape(-1, d)
+    if d < 2:                                   # the weight functions index x1 only for "r2sin" (d >= 2)
+        Xv2 = np.concatenate([Xv, np.zeros((Xv.shape[0], 1))], axis=1)
+    else:
+        Xv2 = Xv
+    wv = fn(Xv2).reshape(-1, m)
+    terms = []
+    if degree == 1:
+        for v in range(m):
+            terms.append((wv[:, v], (v,)))
+        return terms
+    for v in range(m):
+        terms.append((2.0 * wv[:, v], (v, v)))
+        terms.append((-wv[:, v], (v,)))
+    for a, b in itertools.combinations(range(m), 2):
+        mid = 0.5 * (P[:, a] + P[:, b])
+        if d < 2:
+            mid = np.concatenate([mid, np.zeros((mid.shape[0], 1))], axis=1)
+        terms.append((4.0 * fn(mid), (a, b)))
+    return terms
+
+
+def assemble_weighted(coords, cells, kind):
+    """K_w, M_w, load_w with the interpolated weight integrated exactly"""
+    n, d = coords.shape
+    m = d + 1
+    vol, grads = simplex_geometry(coords, cells)
+    terms = _weight_terms(coords, cells, kind)
+    w_int = sum(c * _mono(d, idx) for c, idx in terms) * vol                      # int_T w
+    Ke = w_int[:, None, None] * np.einsum("cad,cbd->cab", grads, grads)
+    Me = np.zeros((cells.shape[0], m, m))
+    le = np.zeros((cells.shape[0], m))
+    for i in range(m):
+        le[:, i] = sum(c * _mono(d, idx + (i,)) for c, idx in terms) * vol
+        for j in range(m):
+            Me[:, i, j] = sum(c * _mono(d, idx + (i, j)) for c, idx in terms) * vol
+    K = _coo(cells, Ke, n)
+    M = _coo(cells, Me, n)
+    load = np.zeros(n)
+    np.add.at(load, cells.ravel(), le.ravel())
+    return K, M, load
+
+
+def _weighted_heat_core(coords, cells, kind, dir_mask, dir_vals, kappa, T_initial, dt, num_steps, steady, source_type,
+                        source_value):
+    K, M, load = assemble_weighted(coords, cells, kind)
+    f = float(source_value) if source_type == "constant" else 0.0
+    if steady:
+        return solve_dirichlet(kappa * K, f * load, dir_mask, dir_vals)[None, :], np.array([0.0])
+    u_n = np.where(dir_mask, dir_vals, float(T_initial))                          # constant IC only (:872-875)
+    snaps, times = [u_n.copy()], [0.0]
+    A = (M + dt * kappa * K).tocsr()
+    for n in range(num_steps):
+        u_n = solve_dirichlet(A, M @ u_n + dt * f * load, dir_mask, dir_vals)     # re-factorised every step
+        snaps.append(u_n.copy())
+        times.append((n + 1) * dt)
+    return np.array(snaps), np.array(times)
+
+
+def _radial_1d(kind, r_inner, r_outer, nr, diffusivity, T_inner, T_outer, T_initial, dt, num_steps, steady, source_type,
+               source_value, coord_sys, geom_names):
+    coords, cells = interval_mesh(nr, r_inner, r_outer)
+    n = nr + 1
+    dir_mask = np.zeros(n, bool)
+    dir_vals = np.zeros(n)
+    if r_inner > 1e-10:                                                           # :811-815, :968-972
+        dir_mask[0], dir_vals[0] = True, T_inner
+    dir_mask[-1], dir_vals[-1] = True, T_outer
+    vals, times = _weighted_heat_core(coords, cells, kind, dir_mask, dir_vals, diffusivity, T_initial, dt, num_steps,
+                                      steady, source_type, source_value)
+    c3 = np.zeros((n, 3))
+    c3[:, 0] = coords[:, 0]
+    meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": coord_sys,
+            "geometry_type": geom_names[0] if r_inner < 1e-10 else geom_names[1], "r_inner": r_inner, "r_outer": r_outer,
+            "source_type": source_type, "source_value": source_value, "steady": steady}
+    return OracleField(c3, vals, times, 1, meta)
+
+
+def solve_heat_1d_cylindrical(r_inner, r_outer, nr, diffusivity, T_inner, T_outer, T_initial, dt, num_steps, steady=False,
+                              source_type="none", source_value=0.0, initial_type="constant", initial_amplitude=1.0):
+    """_solve_heat_1d_cylindrical_raw, fenics_mcp_server.py:769-922 (w = r, degree 1)"""
+    return _radial_1d("r", r_inner, r_outer, nr, diffusivity, T_inner, T_outer, T_initial, dt, num_steps, steady, source_type,
+                      source_value, "cylindrical", ("cylinder", "annulus"))
+
+
+def solve_heat_1d_spherical(r_inner, r_outer, nr, diffusivity, T_inner, T_outer, T_initial, dt, num_steps, steady=False,
+                            source_type="none", source_value=0.0, initial_type="constant", initial_amplitude=1.0):
+    """_solve_heat_1d_spherical_raw, :925-1060 (w = r^2, degree 2)"""
+    return _radial_1d("r2", r_inner, r_outer, nr, diffusivity, T_inner, T_outer, T_initial, dt, num_steps, steady, source_type,
+                      source_value, "spherical", ("sphere", "spherical_shell"))
+
+
+def shifted_rectangle_mesh(x0, x1, y0, y1, nx, ny):
+    c, cells = rectangle_mesh(x1 - x0, y1 - y0, nx, ny)
+    return c + np.array([x0, y0]), cells
+
+
+def solve_heat_2d_cylindrical(r_inner, r_outer, z_length, nr, nz, diffusivity, T_boundary, T_initial, dt, num_steps,
+                              steady=False, source_type="none", source_value=0.0, initial_type="constant",
+                              initial_amplitude=1.0):
+    """_solve_heat_2d_cylindrical_raw, :1063-1192: RectangleMesh((r_inner,0),(r_outer,z_length)), w = r; coords (r,0,z)"""
+    coords, cells = shifted_rectangle_mesh(r_inner, r_outer, 0.0, z_length, nr, nz)
+    n = coords.shape[0]
+    ix, iy = np.arange(n) % (nr + 1), np.arange(n) // (nr + 1)
+    dir_mask = (ix == 0) | (ix == nr) | (iy == 0) | (iy == nz)
+    vals, times = _weighted_heat_core(coords, cells, "r", dir_mask, np.full(n, float(T_boundary)), diffusivity, T_initial, dt,
+                                      num_steps, steady, source_type, source_value)
+    c3 = np.stack([coords[:, 0], np.zeros(n), coords[:, 1]], axis=1)
+    meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cylindrical",
+            "geometry_type": "cylinder" if r_inner < 1e-10 else "annular_cylinder", "r_inner": r_inner, "r_outer": r_outer,
+            "z_length": z_length, "source_type": source_type, "source_value": source_value, "steady": steady}
+    return OracleField(c3, vals, times, 2, meta)
+
+
+def solve_heat_2d_spherical(r_inner, r_outer, nr, ntheta, diffusivity, T_boundary, T_initial, dt, num_steps, steady=False,
+                            source_type="none", source_value=0.0, initial_type="constant", initial_amplitude=1.0):
+    """_solve_heat_2d_spherical_raw, :1195-1330: RectangleMesh((r_inner,0),(r_outer,pi)), w = r^2 sin(theta);
+    coords (r sin t, 0, r cos t)"""
+    coords, cells = shifted_rectangle_mesh(r_inner, r_outer, 0.0, np.pi, nr, ntheta)
+    n = coords.shape[0]
+    ix, iy = np.arange(n) % (nr + 1), np.arange(n) // (nr + 1)
+    dir_mask = (ix == 0) | (ix == nr) | (iy == 0) | (iy == ntheta)
+    vals, times = _weighted_heat_core(coords, cells, "r2sin", dir_mask, np.full(n, float(T_boundary)), diffusivity, T_initial,
+                                      dt, num_steps, steady, source_type, source_value)
+    r, t = coords[:, 0], coords[:, 1]
+    c3 = np.stack([r * np.sin(t), np.zeros(n), r * np.cos(t)], axis=1)
+    meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "spherical",
+            "geometry_type": "sphere" if r_inner < 1e-10 else "spherical_shell", "r_inner": r_inner, "r_outer": r_outer,
+            "source_type": source_type, "source_value": source_value, "steady": steady}
+    return OracleField(c3, vals, times, 2, meta)
+
+
+def solve_heat_3d_spherical(r_inner, r_outer, nr, ntheta, nphi, diffusivity, T_boundary, T_initial, dt, num_steps,
+                            steady=False, source_type="none", source_value=0.0, initial_type="constant",
+                            initial_amplitude=1.0):
+    """_solve_heat_3d_spherical_raw, :1333-1464: BoxMesh((r_inner,0,0),(r_outer,pi,2pi)), w = r^2 sin(theta)"""
+    coords, cells = box_mesh(r_outer - r_inner, np.pi, 2.0 * np.pi, nr, ntheta, nphi)
+    coords = coords + np.array([r_inner, 0.0, 0.0])
+    dir_mask, _ = box_dirichlet(nr, ntheta, nphi, T_boundary=T_boundary)
+    n = coords.shape[0]
+    vals, times = _weighted_heat_core(coords, cells, "r2sin", dir_mask, np.full(n, float(T_boundary)), diffusivity, T_initial,
+                                      dt, num_steps, steady, source_type, source_value)
+    r, t, ph = coords[:, 0], coords[:, 1], coords[:, 2]
+    c3 = np.stack([r * np.sin(t) * np.cos(ph), r * np.sin(t) * np.sin(ph), r * np.cos(t)], axis=1)
+    meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "spherical",
+            "geometry_type": "sphere" if r_inner < 1e-10 else "spherical_shell", "r_inner": r_inner, "r_outer": r_outer,
+            "source_type": source_type, "source_value": source_value, "steady": steady}
+    return OracleField(c3, vals, times, 3, meta)

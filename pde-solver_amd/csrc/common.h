@@ -146,6 +146,8 @@ struct StencilArgs {
     double* partials;         // per-workgroup partial dot products
     int mask_dirichlet;       // 1: Dirichlet rows give 0 (P applied to the output)
     int npt;                  // 7 or 15 (fast path)
+    const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
+    long long ell_stride;
 };
 
 // device scalar block used by the CG kernels
@@ -191,6 +193,11 @@ int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p
 int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const double* scal, double* partials, LaunchInfo* li);
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
+// weighted.hip
+int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const double* origin, const double* h, int kind, double cM, double cK,
+                      double* ellA, double* ellM, double* dinv, long long stride);
+int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, const double* scal,
+              double* partials, int use_alpha, LaunchInfo* li);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense

@@ -33,6 +33,12 @@ struct pdegpu_session {
     std::vector<hipEvent_t> events;
     CgGraph cg_graph;
     long long eager_iters = 0;     // iterations launched eagerly so far (occupancy queries etc. are done)
+    // weighted (curvilinear) operators: per-node coefficients + Jacobi-PCG
+    bool weighted = false;
+    double *ellA = nullptr, *ellM = nullptr, *dinv = nullptr;   // origins (same indexing as the vectors)
+    double *ell_base[3] = {nullptr, nullptr, nullptr};
+    DevVec z;
+    long long ell_stride = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -127,6 +133,10 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     a.mask_dirichlet = mask;
     const double* htab = which == 0 ? s->hA : s->tabs.h_tabM;
     a.tabA = which == 0 ? s->tabs.d_tabA : s->tabs.d_tabM;
+    if (s->weighted) {
+        a.ell = which == 0 ? s->ellA : s->ellM;
+        a.ell_stride = s->ell_stride;
+    }
     if (s->fast) {
         fast_weights(htab, a.w);
         a.npt = is_seven_point(a.w) ? 7 : 15;
@@ -145,6 +155,10 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     a.partials = s->d_part;
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
+    if (s->weighted) {
+        a.ell = s->ellA;
+        a.ell_stride = s->ell_stride;
+    }
     if (s->fast) {
         fast_weights(s->hA, a.w);
         a.npt = s->npt;
@@ -160,7 +174,11 @@ bool k2_is_stencil(const pdegpu_session* s) { return s->fast && s->ctx->cg_varia
 int op_k1(pdegpu_session* s, LaunchInfo* li) {
     StencilArgs a{};
     a.g = s->g;
-    a.in = s->r.v;
+    a.in = s->weighted ? s->z.v : s->r.v;          // PCG: p = z + beta p with z = D^-1 r
+    if (s->weighted) {
+        a.ell = s->ellA;
+        a.ell_stride = s->ell_stride;
+    }
     a.p_old = s->p[s->pcur].v;
     a.p_new = s->p[1 - s->pcur].v;
     a.x = s->x.v;
@@ -196,7 +214,14 @@ int op_k2(pdegpu_session* s, LaunchInfo* li) {
         a.npt = s->npt;
         return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
     }
+    if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 1, li);
     return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, li);
+}
+
+// after a RESIDUAL pass: PCG needs z = D^-1 r and rho = r.z in place of r.r
+int residual_finish(pdegpu_session* s, LaunchInfo* li) {
+    if (s->weighted) PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 0, li));
+    return vec_reduce(s->ctx, s->d_part, li->grid, s->d_scal, 1, 1);
 }
 
 // x (including the ghost planes that lie inside the global domain) = Dirichlet values / fill / nodal
@@ -300,6 +325,9 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     s->cg_graph.reset();
+    for (double* b0 : s->ell_base)
+        if (b0) (void)hipFree(b0);
+    vec_free(&s->z);
     delete s;
 }
 
@@ -666,13 +694,13 @@ int linear_solve(pdegpu_session* s, bool x_is_lift_only, pdegpu_stats* st) {
         PG_TRY(vec_zero(ctx, s->g, &s->q));
         PG_TRY(set_bc_ext(s, s->q.v, 0.0, nullptr, 0));
         PG_TRY(op_residual(s, s->q.v, s->b.v, s->r.v, &li));
-        PG_TRY(vec_reduce(ctx, s->d_part, li.grid, s->d_scal, 1, 1));
+        PG_TRY(residual_finish(s, &li));
         PG_TRY(pdegpu_session_rr(s, &bnorm2));
         PG_TRY(vec_zero(ctx, s->g, &s->q));
         PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
     }
     PG_TRY(op_residual(s, s->x.v, s->b.v, s->r.v, &li));
-    PG_TRY(vec_reduce(ctx, s->d_part, li.grid, s->d_scal, 1, 1));
+    PG_TRY(residual_finish(s, &li));
     if (x_is_lift_only) PG_TRY(pdegpu_session_rr(s, &bnorm2));
     int iters = 0;
     double rel = 0;
@@ -688,12 +716,53 @@ int linear_solve(pdegpu_session* s, bool x_is_lift_only, pdegpu_stats* st) {
 // ---------------------------------------------------------------------------------------------
 // one-shot heat solve (single GPU)
 // ---------------------------------------------------------------------------------------------
+namespace {
+// weighted (curvilinear) operators: per-node coefficients A = cM M_w + cK K_w, M_w, Jacobi diagonal, z vector
+int session_make_weighted(pdegpu_session* s, const pdegpu_weight* w) {
+    pdegpu_ctx* ctx = s->ctx;
+    const long long n = (long long)s->g.nkl * s->g.PP;
+    const size_t sizes[3] = {(size_t)15 * n, (size_t)15 * n, (size_t)n};
+    for (int i = 0; i < 3; ++i) PG_HIP(ctx, hipMalloc(&s->ell_base[i], sizes[i] * sizeof(double)));
+    s->ellA = s->ell_base[0];
+    s->ellM = s->ell_base[1];
+    s->dinv = s->ell_base[2];
+    s->ell_stride = n;
+    PG_TRY(vec_alloc(ctx, s->g, &s->z));
+    double h[3] = {1, 1, 1};
+    for (int r = 0; r < s->grid.dim; ++r) h[r] = s->grid.L[r] / s->grid.n[r];
+    PG_TRY(weighted_assemble(ctx, s->g, w->origin, h, w->kind, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride));
+    s->weighted = true;
+    return PDEGPU_OK;
+}
+
+int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat_in, const pdegpu_weight* weight,
+                    const double* u0, double* values_out, double* times_out, pdegpu_stats* stats);
+}  // namespace
+
 extern "C" int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat_in, const double* u0,
                                  double* values_out, double* times_out, pdegpu_stats* stats) {
+    return heat_solve_impl(ctx, grid, heat_in, nullptr, u0, values_out, times_out, stats);
+}
+
+// curvilinear tools (:769-1464): the same backward-Euler / steady loop on the weighted forms
+extern "C" int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
+                                          const pdegpu_heat* heat_in, double* values_out, double* times_out, pdegpu_stats* stats) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!weight) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null weight");
+    if (weight->kind < 1 || weight->kind > 3) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
+    if (grid && weight->kind == 3 && grid->dim < 2) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weight r^2 sin(theta) needs dim >= 2");
+    if (grid && grid->element_mode != PDEGPU_ELEM_P1SPLIT) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted forms use the P1 split only");
+    return heat_solve_impl(ctx, grid, heat_in, weight, nullptr, values_out, times_out, stats);
+}
+
+namespace {
+int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat_in, const pdegpu_weight* weight,
+                    const double* u0, double* values_out, double* times_out, pdegpu_stats* stats) {
     if (!ctx) return PDEGPU_EINVAL;
     if (!heat_in || !values_out || !times_out) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
     PG_TRY(validate_grid(ctx, grid));
     pdegpu_heat heat = *heat_in;
+    if (weight) heat.fast_path = 0;
     if (heat.rtol <= 0) heat.rtol = 1e-10;
     if (heat.max_iter <= 0) heat.max_iter = 100000;
     if (heat.snapshot_stride < 1) heat.snapshot_stride = 1;
@@ -704,6 +773,13 @@ extern "C" int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const
     const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
     pdegpu_session* s = nullptr;
     PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));
+    if (weight) {
+        const int rcw = session_make_weighted(s, weight);
+        if (rcw != PDEGPU_OK) {
+            pdegpu_session_destroy(s);
+            return rcw;
+        }
+    }
     const size_t N = (size_t)pdegpu_grid_num_nodes(grid);
     st.n_nodes = (int64_t)N;
     st.path = s->fast ? 1 : 0;
@@ -782,6 +858,7 @@ extern "C" int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const
     st.solve_ms = ms;
     return fail(rc);
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // project(): consistent-mass solve M s = rhs, no Dirichlet rows

@@ -53,12 +53,14 @@ __device__ __forceinline__ void cg_scalars(const double* __restrict__ scal, doub
 // ---------------------------------------------------------------------------------------------
 // general path
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool ELL>
 __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
-    __shared__ double sTab[27 * 27];
+    __shared__ double sTab[ELL ? 1 : 27 * 27];
     __shared__ double sRed[4];
-    for (int e = threadIdx.x; e < 27 * 27; e += 256) sTab[e] = a.tabA[e];
-    __syncthreads();
+    if (!ELL) {
+        for (int e = threadIdx.x; e < 27 * 27; e += 256) sTab[e] = a.tabA[e];
+        __syncthreads();
+    }
 
     const GridDev& g = a.g;
     const long long total = (long long)g.nkl * g.PP;
@@ -84,7 +86,23 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
             if (alpha_prev != 0.0) a.x[idx] += alpha_prev * po;
         }
         double s = 0.0;
-        if (real && !dir) {
+        if (ELL && real && !dir) {
+            // per-node coefficients (weighted / curvilinear operators): 15 coupling weights read from HBM
+#pragma unroll
+            for (int q = 0; q < 15; ++q) {
+                constexpr int kOff[15] = {13, 12, 14, 10, 16, 4, 22, 9, 17, 3, 23, 1, 25, 0, 26};
+                const int o = kOff[q];
+                const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+                const double wo = a.ell[q * a.ell_stride + idx];
+                if (wo != 0.0) {
+                    const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
+                    double v;
+                    if (MODE == APPLY_CG_K1) v = a.in[nb] + beta * a.p_old[nb];
+                    else v = a.in[nb] + a.in_shift;
+                    s += wo * v;
+                }
+            }
+        } else if (real && !dir) {
             const int cls = pg_axis_class(i, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
                             9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
             const double* w = &sTab[cls * 27];
@@ -450,10 +468,18 @@ int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo*
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     if (li) { li->grid = (int)nb; li->block = 256; }
-    switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL(k_general<APPLY_PLAIN>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL(k_general<APPLY_RESIDUAL>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(k_general<APPLY_CG_K1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+    if (a.ell) {
+        switch (mode) {
+            case APPLY_PLAIN: hipLaunchKernelGGL((k_general<APPLY_PLAIN, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+            case APPLY_RESIDUAL: hipLaunchKernelGGL((k_general<APPLY_RESIDUAL, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((k_general<APPLY_CG_K1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+        }
+    } else {
+        switch (mode) {
+            case APPLY_PLAIN: hipLaunchKernelGGL((k_general<APPLY_PLAIN, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+            case APPLY_RESIDUAL: hipLaunchKernelGGL((k_general<APPLY_RESIDUAL, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((k_general<APPLY_CG_K1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+        }
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;

@@ -237,3 +237,119 @@ __host__ __device__ inline void fold_elasticity_block(int dim, const double* h, 
         for (int e = 0; e < 9; ++e) blk[e] += b1[e];
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// weighted (curvilinear) heat forms, fenics_mcp_server.py:769-1464:  a = w u v + dt kappa w grad u . grad v with
+// w an Expression of degree 1 or 2 = its P1 / P2 interpolant on every simplex, integrated exactly.
+// The operator is no longer translation invariant, so every node gets its own 15 coupling weights.
+// ---------------------------------------------------------------------------------------------
+
+__host__ __device__ inline double pg_weight_eval(int kind, const double* x) {
+    if (kind == PDEGPU_WEIGHT_R) return x[0];
+    if (kind == PDEGPU_WEIGHT_R2) return x[0] * x[0];
+    return x[0] * x[0] * sin(x[1]);
+}
+__host__ __device__ inline int pg_weight_degree(int kind) { return kind == PDEGPU_WEIGHT_R ? 1 : 2; }
+
+// position q in the 15-offset list of offset id o (or -1)
+__host__ __device__ inline int pg_q_of_o(int o) {
+    constexpr int kQ[27] = {13, 11, -1, 9, 5, -1, -1, -1, -1, 7, 3, -1, 1, 0, 2, -1, 4, 8, -1, -1, -1, -1, 6, 10, -1, 12, 14};
+    return kQ[o];
+}
+
+// int over a unit-volume d-simplex of prod lambda_i^{e_i} = d! prod e_i! / (sum e_i + d)!
+__host__ __device__ inline double pg_mono(int d, const int* e) {
+    constexpr double kFact[10] = {1, 1, 2, 6, 24, 120, 720, 5040, 40320, 362880};
+    int s = 0;
+    double num = kFact[d];
+    for (int i = 0; i <= d; ++i) {
+        s += e[i];
+        num *= kFact[e[i]];
+    }
+    return num / kFact[s + d];
+}
+
+// row of node (i, j, k): rowK[15], rowM[15] (positions of the 15-offset list) and the load entry int w phi_i
+__host__ __device__ inline void weighted_row(int dim, const int* nn /*node counts*/, const double* origin, const double* h, int kind,
+                                             int i, int j, int k, double* rowK, double* rowM, double* load) {
+    for (int q = 0; q < PG_NOFF15; ++q) { rowK[q] = 0.0; rowM[q] = 0.0; }
+    *load = 0.0;
+    const int idx3[3] = {i, j, k};
+    const int deg = pg_weight_degree(kind);
+    const int ns = pg_num_simplices(dim);
+    for (int s = 0; s < (1 << dim); ++s) {               // incident cell: node is local vertex `s` of cell (idx - bits(s))
+        int c0[3] = {0, 0, 0};
+        bool ok = true;
+        for (int r = 0; r < dim; ++r) {
+            c0[r] = idx3[r] - ((s >> r) & 1);
+            ok &= (c0[r] >= 0) & (c0[r] < nn[r] - 1);
+        }
+        if (!ok) continue;
+        for (int t = 0; t < ns; ++t) {
+            int verts[4];
+            pg_simplex_verts(dim, t, verts);
+            int pa = -1;
+            for (int p = 0; p <= dim; ++p)
+                if (verts[p] == s) pa = p;
+            if (pa < 0) continue;
+            double g[4][3], vol;
+            simplex_grads(dim, verts, h, g, &vol);
+            // vertex coordinates and the interpolated weight as sum_t coef_t * prod lambda^{exp_t}
+            double X[4][3];
+            for (int p = 0; p <= dim; ++p)
+                for (int r = 0; r < 3; ++r) X[p][r] = r < dim ? origin[r] + (c0[r] + ((verts[p] >> r) & 1)) * h[r] : 0.0;
+            double coef[14];
+            int expo[14][4];
+            int nt = 0;
+            for (int p = 0; p <= dim; ++p) {
+                const double wv = pg_weight_eval(kind, X[p]);
+                if (deg == 1) {
+                    coef[nt] = wv;
+                    for (int e = 0; e < 4; ++e) expo[nt][e] = (e == p);
+                    ++nt;
+                } else {                                  // vertex basis of P2: 2 l^2 - l
+                    coef[nt] = 2.0 * wv;
+                    for (int e = 0; e < 4; ++e) expo[nt][e] = 2 * (e == p);
+                    ++nt;
+                    coef[nt] = -wv;
+                    for (int e = 0; e < 4; ++e) expo[nt][e] = (e == p);
+                    ++nt;
+                }
+            }
+            if (deg == 2)
+                for (int a = 0; a <= dim; ++a)
+                    for (int b = a + 1; b <= dim; ++b) {   // edge basis of P2: 4 l_a l_b, value at the edge midpoint
+                        double mid[3];
+                        for (int r = 0; r < 3; ++r) mid[r] = 0.5 * (X[a][r] + X[b][r]);
+                        coef[nt] = 4.0 * pg_weight_eval(kind, mid);
+                        for (int e = 0; e < 4; ++e) expo[nt][e] = (e == a) + (e == b);
+                        ++nt;
+                    }
+            double w_int = 0.0, w_a = 0.0;
+            for (int u = 0; u < nt; ++u) {
+                int e[4] = {expo[u][0], expo[u][1], expo[u][2], expo[u][3]};
+                w_int += coef[u] * pg_mono(dim, e);
+                e[pa] += 1;
+                w_a += coef[u] * pg_mono(dim, e);
+            }
+            *load += vol * w_a;
+            for (int p = 0; p <= dim; ++p) {
+                int o = 13;                               // offset id of vertex p relative to this node
+                const int mult[3] = {1, 3, 9};
+                for (int r = 0; r < dim; ++r) o += mult[r] * (((verts[p] >> r) & 1) - ((s >> r) & 1));
+                const int q = pg_q_of_o(o);
+                double gg = 0.0;
+                for (int r = 0; r < dim; ++r) gg += g[pa][r] * g[p][r];
+                double w_ab = 0.0;
+                for (int u = 0; u < nt; ++u) {
+                    int e[4] = {expo[u][0], expo[u][1], expo[u][2], expo[u][3]};
+                    e[pa] += 1;
+                    e[p] += 1;
+                    w_ab += coef[u] * pg_mono(dim, e);
+                }
+                rowK[q] += vol * w_int * gg;
+                rowM[q] += vol * w_ab;
+            }
+        }
+    }
+}

@@ -1,0 +1,129 @@
+// weighted.hip — per-node assembled 15-point operators for the reference's curvilinear heat tools
+// (_solve_heat_{1d,2d}_{cylindrical,spherical}_raw, _solve_heat_3d_spherical_raw, fenics_mcp_server.py:769-1464).
+//
+// Those forms multiply mass and stiffness by one coordinate weight w (r, r^2 or r^2 sin(theta)), entered as an
+// Expression of degree 1 / 2 = its P1 / P2 interpolant per simplex, integrated exactly.  The stencil is no
+// longer translation invariant, so one kernel integrates, for every node, the weighted element matrices of its
+// incident simplices (node-centric gather: deterministic, no atomics) into 15 coupling weights stored
+// offset-major in HBM (coalesced), plus the Jacobi diagonal.  The class-table kernels then read their weights
+// from that array (k_general<..., ELL>), and CG becomes Jacobi-PCG because r^2 sin(theta) spans orders of
+// magnitude across the grid.
+#include "common.h"
+#include "tables_math.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+struct WeightGeom { double origin[3], h[3]; };
+
+__global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom wg, int kind, double cM, double cK,
+                                                            double* __restrict__ ellA, double* __restrict__ ellM,
+                                                            double* __restrict__ dinv, long long stride) {
+    const long long total = (long long)g.nkl * g.PP;
+    const int nn[3] = {g.NX, g.NY, g.NZ};
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int i = (int)(idx % g.PX);
+        const long long row = idx / g.PX;
+        const int j = (int)(row % g.NY);
+        const int k = g.k0 + (int)(row / g.NY);
+        double rowK[PG_NOFF15], rowM[PG_NOFF15], ld = 0.0;
+        if (i < g.NX) {
+            weighted_row(g.dim, nn, wg.origin, wg.h, kind, i, j, k, rowK, rowM, &ld);
+        } else {
+            for (int q = 0; q < PG_NOFF15; ++q) rowK[q] = rowM[q] = 0.0;
+        }
+        for (int q = 0; q < PG_NOFF15; ++q) {
+            ellA[q * stride + idx] = cM * rowM[q] + cK * rowK[q];
+            ellM[q * stride + idx] = rowM[q];
+        }
+        const double d = cM * rowM[0] + cK * rowK[0];
+        dinv[idx] = d > 0.0 ? 1.0 / d : 0.0;
+    }
+}
+
+// r -= alpha q;  z = D^-1 r;  partial r.z    (use_alpha == 0: z and the sum only)
+__global__ __launch_bounds__(256) void k_k2_pc(double* __restrict__ r, const double* __restrict__ q, double* __restrict__ z,
+                                                const double* __restrict__ dinv, long long n, const double* __restrict__ scal,
+                                                double* __restrict__ partials, int use_alpha) {
+    __shared__ double sRed[4];
+    double alpha = 0.0;
+    if (use_alpha) {
+        const double pq = scal[SC_PQ], rr = scal[SC_RR];
+        alpha = (pq > 0.0) ? rr / pq : 0.0;
+    }
+    double acc = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        double rv = r[e];
+        if (use_alpha) {
+            rv -= alpha * q[e];
+            r[e] = rv;
+        }
+        const double zv = dinv[e] * rv;
+        z[e] = zv;
+        acc += rv * zv;
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
+    long long nb = (n + 255) / 256;
+    const long long cap = (long long)ctx->grid_mult * ctx->num_cu;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const double* origin, const double* h, int kind, double cM, double cK,
+                      double* ellA, double* ellM, double* dinv, long long stride) {
+    WeightGeom wg{};
+    for (int r = 0; r < 3; ++r) { wg.origin[r] = origin[r]; wg.h[r] = h[r]; }
+    const long long total = (long long)g.nkl * g.PP;
+    hipLaunchKernelGGL(k_weighted_assemble, dim3(flat_grid(ctx, total)), dim3(256), 0, ctx->stream, g, wg, kind, cM, cK, ellA, ellM,
+                       dinv, stride);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, const double* scal,
+              double* partials, int use_alpha, LaunchInfo* li) {
+    const long long n = (long long)g.nkl * g.PP;
+    const int nb = flat_grid(ctx, n);
+    if (li) { li->grid = nb; li->block = 256; }
+    hipLaunchKernelGGL(k_k2_pc, dim3(nb), dim3(256), 0, ctx->stream, r, q, z, dinv, n, scal, partials, use_alpha);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+// host twin of k_weighted_assemble (CPU test-suite): rowsK / rowsM [N][15] in node order (x fastest), load [N]
+extern "C" int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const double* origin, int kind, double* rowsK, double* rowsM,
+                                         double* load) {
+    if (!grid || !origin || !rowsK || !rowsM || !load || grid->dim < 1 || grid->dim > 3) return PDEGPU_EINVAL;
+    if (kind < PDEGPU_WEIGHT_R || kind > PDEGPU_WEIGHT_R2SIN) return PDEGPU_EINVAL;
+    if (kind == PDEGPU_WEIGHT_R2SIN && grid->dim < 2) return PDEGPU_EINVAL;
+    double h[3] = {1, 1, 1};
+    int nn[3] = {1, 1, 1};
+    for (int r = 0; r < grid->dim; ++r) {
+        if (grid->n[r] < 1 || !(grid->L[r] > 0)) return PDEGPU_EINVAL;
+        h[r] = grid->L[r] / grid->n[r];
+        nn[r] = grid->n[r] + 1;
+    }
+    long long idx = 0;
+    for (int k = 0; k < nn[2]; ++k)
+        for (int j = 0; j < nn[1]; ++j)
+            for (int i = 0; i < nn[0]; ++i, ++idx) weighted_row(grid->dim, nn, origin, h, kind, i, j, k, rowsK + idx * 15, rowsM + idx * 15, load + idx);
+    return PDEGPU_OK;
+}

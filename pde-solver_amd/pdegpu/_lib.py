@@ -37,6 +37,13 @@ class Heat(C.Structure):
                 ("rtol", C.c_double), ("max_iter", C.c_int32), ("fast_path", C.c_int32)]
 
 
+class Weight(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("origin", C.c_double * 3)]
+
+
+WEIGHT_R, WEIGHT_R2, WEIGHT_R2SIN = 1, 2, 3
+
+
 class Elasticity(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("area", C.c_double), ("body", C.c_double * 3),
                 ("plane_stress", C.c_int32), ("quantity", C.c_int32), ("rtol", C.c_double),
@@ -71,6 +78,8 @@ SYMBOLS = {
     "pdegpu_set_tunable": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "pdegpu_heat_num_snapshots": (C.c_int, [C.POINTER(Heat)]),
     "pdegpu_heat_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
+    "pdegpu_heat_solve_weighted": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.POINTER(Heat), _dp, _dp, C.POINTER(Stats)]),
+    "pdegpu_weighted_rows_host": (C.c_int, [C.POINTER(Grid), _dp, C.c_int, _dp, _dp, _dp]),
     "pdegpu_mass_solve": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, C.c_double, C.c_int, C.POINTER(Stats)]),
     "pdegpu_heat_apply": (C.c_int, [_vp, C.POINTER(Grid), C.c_double, C.c_double, _dp, _dp, _dp, C.c_int]),
     "pdegpu_heat_tables": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, _dp]),

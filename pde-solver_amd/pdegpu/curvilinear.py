@@ -1,0 +1,144 @@
+"""Host-side mirror of the reference's curvilinear heat solvers — same names, arguments and outputs as
+`_solve_heat_1d_cylindrical_raw` (fenics_mcp_server.py:769-922), `_solve_heat_1d_spherical_raw` (:925-1060),
+`_solve_heat_2d_cylindrical_raw` (:1063-1192), `_solve_heat_2d_spherical_raw` (:1195-1330) and
+`_solve_heat_3d_spherical_raw` (:1333-1464).  Each is P1 on a box mesh in coordinate space with one weight
+(r, r^2 or r^2 sin(theta)) multiplying both forms; the DOLFIN block is one C-ABI call, pdegpu_heat_solve_weighted."""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+
+from . import _lib as L
+from .fields import TimeSeriesField
+
+
+def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady, source_type, source_value, T_initial,
+                 bc_mode, bc_value, bc_present, rtol=None, max_iter=None, snapshot_stride=None, device=None):
+    lib = L.load_library()
+    ctx = L.context(device)
+    grid = L.make_grid(dim, n, lengths, L.ELEM_P1SPLIT)
+    N = int(lib.pdegpu_grid_num_nodes(grid))
+    if N < 0:
+        raise L.PdeGpuError(L.EINVAL, f"invalid grid dim={dim} n={tuple(n)} lengths={tuple(lengths)}")
+    w = L.Weight()
+    w.kind = kind
+    for r in range(3):
+        w.origin[r] = float(origin[r]) if r < len(origin) else 0.0
+    h = L.Heat()
+    h.kappa, h.dt, h.num_steps, h.steady = float(kappa), float(dt), int(num_steps), 1 if steady else 0
+    h.source = float(source_value) if source_type == "constant" else 0.0
+    h.ic_type, h.ic_value = L.IC_CONSTANT, float(T_initial)          # every initial_type assigns the constant (:872-875)
+    h.bc_mode = bc_mode
+    for r in range(3):
+        h.bc_value[r], h.bc_present[r] = float(bc_value[r]), int(bc_present[r])
+    h.snapshot_stride = int(snapshot_stride if snapshot_stride is not None else os.environ.get("PDEGPU_SNAPSHOT_STRIDE", 1))
+    h.rtol = float(rtol if rtol is not None else os.environ.get("PDEGPU_RTOL", 1e-10))
+    h.max_iter = int(max_iter if max_iter is not None else os.environ.get("PDEGPU_MAX_ITER", 400000))
+    h.fast_path = 0
+    n_snap = lib.pdegpu_heat_num_snapshots(h)
+    values, times = np.empty((n_snap, N)), np.empty(n_snap)
+    st = L.Stats()
+    L.check(ctx, lib.pdegpu_heat_solve_weighted(ctx, grid, w, h, L.dptr(values), L.dptr(times), st))
+    return values, times, st.as_dict()
+
+
+def _axes(n, origin, lengths):
+    return [origin[r] + lengths[r] * np.arange(n[r] + 1) / n[r] for r in range(len(n))]
+
+
+def _meta(coord_sys, geom, r_inner, r_outer, source_type, source_value, steady, st, **extra):
+    m = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": coord_sys, "geometry_type": geom,
+         "r_inner": r_inner, "r_outer": r_outer}
+    m.update(extra)
+    m.update({"source_type": source_type, "source_value": source_value, "steady": steady})
+    m.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"])})
+    return m
+
+
+def _radial_1d(kind, coord_sys, names, r_inner, r_outer, nr, diffusivity, T_inner, T_outer, T_initial, dt, num_steps, steady,
+               source_type, source_value, **opts):
+    inner = 1 if r_inner > 1e-10 else 0                               # inner BC only for r_inner > 0 (:811, :968)
+    values, times, st = run_weighted(1, (nr,), (r_outer - r_inner,), (r_inner,), kind, kappa=diffusivity, dt=dt,
+                                     num_steps=num_steps, steady=steady, source_type=source_type, source_value=source_value,
+                                     T_initial=T_initial, bc_mode=L.BC_DIRECTIONAL, bc_value=(T_inner, T_outer, 0.0),
+                                     bc_present=(inner, 1, 0), **opts)
+    r = _axes((nr,), (r_inner,), (r_outer - r_inner,))[0]
+    coords = np.stack([r, np.zeros_like(r), np.zeros_like(r)], axis=1)
+    meta = _meta(coord_sys, names[0] if r_inner < 1e-10 else names[1], r_inner, r_outer, source_type, source_value, steady, st)
+    return TimeSeriesField(coords=coords, values=values, times=times, dim=1, meta=meta)
+
+
+def _solve_heat_1d_cylindrical_raw(r_inner: float, r_outer: float, nr: int, diffusivity: float, T_inner: float, T_outer: float,
+                                   T_initial: float, dt: float, num_steps: int, steady: bool = False, source_type: str = "none",
+                                   source_value: float = 0.0, initial_type: str = "constant", initial_amplitude: float = 1.0,
+                                   **opts) -> TimeSeriesField:
+    """fenics_mcp_server.py:769-922: IntervalMesh(nr, r_inner, r_outer), weight r"""
+    return _radial_1d(L.WEIGHT_R, "cylindrical", ("cylinder", "annulus"), r_inner, r_outer, nr, diffusivity, T_inner, T_outer,
+                      T_initial, dt, num_steps, steady, source_type, source_value, **opts)
+
+
+def _solve_heat_1d_spherical_raw(r_inner: float, r_outer: float, nr: int, diffusivity: float, T_inner: float, T_outer: float,
+                                 T_initial: float, dt: float, num_steps: int, steady: bool = False, source_type: str = "none",
+                                 source_value: float = 0.0, initial_type: str = "constant", initial_amplitude: float = 1.0,
+                                 **opts) -> TimeSeriesField:
+    """fenics_mcp_server.py:925-1060: weight r^2"""
+    return _radial_1d(L.WEIGHT_R2, "spherical", ("sphere", "spherical_shell"), r_inner, r_outer, nr, diffusivity, T_inner,
+                      T_outer, T_initial, dt, num_steps, steady, source_type, source_value, **opts)
+
+
+def _uniform(dim, n, lengths, origin, kind, diffusivity, T_boundary, T_initial, dt, num_steps, steady, source_type, source_value,
+             **opts):
+    return run_weighted(dim, n, lengths, origin, kind, kappa=diffusivity, dt=dt, num_steps=num_steps, steady=steady,
+                        source_type=source_type, source_value=source_value, T_initial=T_initial, bc_mode=L.BC_UNIFORM,
+                        bc_value=(T_boundary, 0.0, 0.0), bc_present=(1, 0, 0), **opts)
+
+
+def _solve_heat_2d_cylindrical_raw(r_inner: float, r_outer: float, z_length: float, nr: int, nz: int, diffusivity: float,
+                                   T_boundary: float, T_initial: float, dt: float, num_steps: int, steady: bool = False,
+                                   source_type: str = "none", source_value: float = 0.0, initial_type: str = "constant",
+                                   initial_amplitude: float = 1.0, **opts) -> TimeSeriesField:
+    """fenics_mcp_server.py:1063-1192: RectangleMesh((r_inner,0),(r_outer,z_length)), weight r, coords (r, 0, z)"""
+    values, times, st = _uniform(2, (nr, nz), (r_outer - r_inner, z_length), (r_inner, 0.0), L.WEIGHT_R, diffusivity, T_boundary,
+                                 T_initial, dt, num_steps, steady, source_type, source_value, **opts)
+    r, z = _axes((nr, nz), (r_inner, 0.0), (r_outer - r_inner, z_length))
+    Z, R = np.meshgrid(z, r, indexing="ij")
+    coords = np.stack([R.ravel(), np.zeros(R.size), Z.ravel()], axis=1)
+    meta = _meta("cylindrical", "cylinder" if r_inner < 1e-10 else "annular_cylinder", r_inner, r_outer, source_type,
+                 source_value, steady, st, z_length=z_length)
+    return TimeSeriesField(coords=coords, values=values, times=times, dim=2, meta=meta)
+
+
+def _solve_heat_2d_spherical_raw(r_inner: float, r_outer: float, nr: int, ntheta: int, diffusivity: float, T_boundary: float,
+                                 T_initial: float, dt: float, num_steps: int, steady: bool = False, source_type: str = "none",
+                                 source_value: float = 0.0, initial_type: str = "constant", initial_amplitude: float = 1.0,
+                                 **opts) -> TimeSeriesField:
+    """fenics_mcp_server.py:1195-1330: RectangleMesh((r_inner,0),(r_outer,pi)), weight r^2 sin(theta); coords
+    (r sin t, 0, r cos t)"""
+    values, times, st = _uniform(2, (nr, ntheta), (r_outer - r_inner, math.pi), (r_inner, 0.0), L.WEIGHT_R2SIN, diffusivity,
+                                 T_boundary, T_initial, dt, num_steps, steady, source_type, source_value, **opts)
+    r, t = _axes((nr, ntheta), (r_inner, 0.0), (r_outer - r_inner, math.pi))
+    T, R = np.meshgrid(t, r, indexing="ij")
+    R, T = R.ravel(), T.ravel()
+    coords = np.stack([R * np.sin(T), np.zeros(R.size), R * np.cos(T)], axis=1)
+    meta = _meta("spherical", "sphere" if r_inner < 1e-10 else "spherical_shell", r_inner, r_outer, source_type, source_value,
+                 steady, st)
+    return TimeSeriesField(coords=coords, values=values, times=times, dim=2, meta=meta)
+
+
+def _solve_heat_3d_spherical_raw(r_inner: float, r_outer: float, nr: int, ntheta: int, nphi: int, diffusivity: float,
+                                 T_boundary: float, T_initial: float, dt: float, num_steps: int, steady: bool = False,
+                                 source_type: str = "none", source_value: float = 0.0, initial_type: str = "constant",
+                                 initial_amplitude: float = 1.0, **opts) -> TimeSeriesField:
+    """fenics_mcp_server.py:1333-1464: BoxMesh((r_inner,0,0),(r_outer,pi,2pi)), weight r^2 sin(theta)"""
+    values, times, st = _uniform(3, (nr, ntheta, nphi), (r_outer - r_inner, math.pi, 2.0 * math.pi), (r_inner, 0.0, 0.0),
+                                 L.WEIGHT_R2SIN, diffusivity, T_boundary, T_initial, dt, num_steps, steady, source_type,
+                                 source_value, **opts)
+    r, t, ph = _axes((nr, ntheta, nphi), (r_inner, 0.0, 0.0), (r_outer - r_inner, math.pi, 2.0 * math.pi))
+    PH, T, R = np.meshgrid(ph, t, r, indexing="ij")
+    R, T, PH = R.ravel(), T.ravel(), PH.ravel()
+    coords = np.stack([R * np.sin(T) * np.cos(PH), R * np.sin(T) * np.sin(PH), R * np.cos(T)], axis=1)
+    meta = _meta("spherical", "sphere" if r_inner < 1e-10 else "spherical_shell", r_inner, r_outer, source_type, source_value,
+                 steady, st)
+    return TimeSeriesField(coords=coords, values=values, times=times, dim=3, meta=meta)

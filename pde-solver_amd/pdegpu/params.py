@@ -175,6 +175,78 @@ def heat_3d_kwargs(p: Mapping, geometry: str = "box") -> Dict[str, Any]:
     return out
 
 
+def _curvilinear_common(p, nr_default):
+    """fields shared by the five curvilinear builders (dispatcher_agent.py:775-977): plain `x or default` defaults,
+    no characteristic-time logic"""
+    return {
+        "diffusivity": p.get("diffusivity") or 1.0,
+        "T_initial": _val(p, "initial_value", 20.0),
+        "dt": p.get("dt") or 0.01,
+        "num_steps": p.get("num_steps") or 50,
+        "data_dir": "data",
+        "steady": _val(p, "steady", False),
+        "source_type": p.get("source_type") or "none",
+        "source_value": _val(p, "source_value", 0.0),
+        "initial_type": p.get("initial_type") or "constant",
+        "initial_amplitude": _val(p, "initial_amplitude", 1.0),
+    }
+
+
+def _radii(p, radius_key):
+    gp = p.get("geometry_params") or {}
+    return gp.get("r_inner") or 0.0, _truthy(gp, ("r_outer", radius_key, "radius"), 1.0)
+
+
+def _order(d, keys):
+    return {k: d[k] for k in keys}
+
+
+def heat_1d_radial_kwargs(p: Mapping, radius_key: str) -> Dict[str, Any]:
+    """dispatcher_agent.py:775-812 (cylindrical, radius_key "cylinder_radius") and :814-851 (spherical, "sphere_radius")"""
+    bc = p.get("bc_values") or {}
+    r_inner, r_outer = _radii(p, radius_key)
+    out = {"r_inner": r_inner, "r_outer": r_outer, "nr": p.get("nx") or 50,
+           "T_inner": _truthy(bc, ("t_inner", "T_inner", "t_boundary", "T_boundary"), 100.0),
+           "T_outer": _truthy(bc, ("t_outer", "T_outer", "t_boundary", "T_boundary"), 20.0)}
+    out.update(_curvilinear_common(p, 50))
+    return _order(out, ("r_inner", "r_outer", "nr", "diffusivity", "T_inner", "T_outer", "T_initial", "dt", "num_steps",
+                        "data_dir", "steady", "source_type", "source_value", "initial_type", "initial_amplitude"))
+
+
+def heat_2d_cylindrical_kwargs(p: Mapping) -> Dict[str, Any]:
+    """dispatcher_agent.py:853-894"""
+    dom = p.get("domain_size") or {}
+    bc = p.get("bc_values") or {}
+    r_inner, r_outer = _radii(p, "cylinder_radius")
+    out = {"r_inner": r_inner, "r_outer": r_outer, "z_length": _truthy(dom, ("Lx", "length", "L"), 2.0),
+           "nr": p.get("nx") or 30, "nz": p.get("ny") or 30, "T_boundary": _truthy(bc, ("t_boundary", "T_boundary"), 20.0)}
+    out.update(_curvilinear_common(p, 30))
+    return _order(out, ("r_inner", "r_outer", "z_length", "nr", "nz", "diffusivity", "T_boundary", "T_initial", "dt", "num_steps",
+                        "data_dir", "steady", "source_type", "source_value", "initial_type", "initial_amplitude"))
+
+
+def heat_2d_spherical_kwargs(p: Mapping) -> Dict[str, Any]:
+    """dispatcher_agent.py:896-934"""
+    bc = p.get("bc_values") or {}
+    r_inner, r_outer = _radii(p, "sphere_radius")
+    out = {"r_inner": r_inner, "r_outer": r_outer, "nr": p.get("nx") or 30, "ntheta": p.get("ny") or 30,
+           "T_boundary": _truthy(bc, ("t_boundary", "T_boundary"), 20.0)}
+    out.update(_curvilinear_common(p, 30))
+    return _order(out, ("r_inner", "r_outer", "nr", "ntheta", "diffusivity", "T_boundary", "T_initial", "dt", "num_steps",
+                        "data_dir", "steady", "source_type", "source_value", "initial_type", "initial_amplitude"))
+
+
+def heat_3d_spherical_kwargs(p: Mapping) -> Dict[str, Any]:
+    """dispatcher_agent.py:936-977"""
+    bc = p.get("bc_values") or {}
+    r_inner, r_outer = _radii(p, "sphere_radius")
+    out = {"r_inner": r_inner, "r_outer": r_outer, "nr": p.get("nx") or 20, "ntheta": p.get("ny") or 20,
+           "nphi": p.get("nz") or 20, "T_boundary": _truthy(bc, ("t_boundary", "T_boundary"), 20.0)}
+    out.update(_curvilinear_common(p, 20))
+    return _order(out, ("r_inner", "r_outer", "nr", "ntheta", "nphi", "diffusivity", "T_boundary", "T_initial", "dt",
+                        "num_steps", "data_dir", "steady", "source_type", "source_value", "initial_type", "initial_amplitude"))
+
+
 def _quantity(mp):
     q = mp.get("quantity") or "stress"
     return q if q in ("stress", "strain") else "stress"
@@ -234,16 +306,23 @@ def route(params) -> Tuple[str, Dict[str, Any]]:
     p = _as_dict(params)
     pde, dim = p.get("pde_type", "heat"), p.get("dim", 1)
     if pde == "heat":
-        geom = geometry_of(p)
-        if geom in ("cylinder", "sphere"):
-            raise NotImplementedError(f"{geom} geometries route to the curvilinear / mshr tools of the reference, "
-                                      "which are outside the accelerated box path (SURVEY.md §2 rows 8-9)")
+        geom = geometry_of(p)                                      # dispatcher_agent.py:148-175
         if dim == 1:
+            if geom == "cylinder":
+                return "solve_heat_1D_cylindrical", heat_1d_radial_kwargs(p, "cylinder_radius")
+            if geom == "sphere":
+                return "solve_heat_1D_spherical", heat_1d_radial_kwargs(p, "sphere_radius")
             return "solve_heat_1D", heat_1d_kwargs(p)
         if dim == 2:
+            if geom == "cylinder":
+                return "solve_heat_2D_cylindrical", heat_2d_cylindrical_kwargs(p)
+            if geom == "sphere":
+                return "solve_heat_2D_spherical", heat_2d_spherical_kwargs(p)
             return "solve_heat_2D", heat_2d_kwargs(p)
         if dim == 3:
-            return "solve_heat_3D", heat_3d_kwargs(p, "box")
+            if geom == "sphere":
+                return "solve_heat_3D_spherical", heat_3d_spherical_kwargs(p)
+            return "solve_heat_3D", heat_3d_kwargs(p, geom if geom == "cylinder" else "box")
         raise ValueError(f"Unsupported dimension: {dim}")
     if pde == "elasticity":
         if dim == 1:

@@ -12,6 +12,7 @@ from typing import Any, Dict, Optional
 
 import numpy as np
 
+from . import curvilinear as _cv
 from . import elasticity as _el
 from . import heat as _heat
 from . import params as _params
@@ -69,6 +70,76 @@ def solve_heat_3D(Lx: float = 1.0, Ly: float = 1.0, Lz: float = 1.0, nx: int = 1
                                      cylinder_radius=cylinder_radius, T_left=T_left, T_right=T_right, T_side=T_side,
                                      core_radius=core_radius, core_diffusivity=core_diffusivity)
     return _store(field, data_dir, "heat_3d")
+
+
+def solve_heat_3D_spherical(r_inner: float = 0.1, r_outer: float = 1.0, nr: int = 20, ntheta: int = 20, nphi: int = 20,
+                            diffusivity: float = 1.0, T_boundary: float = 20.0, T_initial: float = 20.0, dt: float = 0.01,
+                            num_steps: int = 50, data_dir: str = "data", steady: bool = False, source_type: str = "none",
+                            source_value: float = 0.0, initial_type: str = "constant",
+                            initial_amplitude: float = 1.0) -> SolveResult:
+    """fenics_mcp_server.py:2044-2119"""
+    field = _cv._solve_heat_3d_spherical_raw(r_inner=r_inner, r_outer=r_outer, nr=nr, ntheta=ntheta, nphi=nphi,
+                                             diffusivity=diffusivity, T_boundary=T_boundary, T_initial=T_initial, dt=dt,
+                                             num_steps=num_steps, steady=steady, source_type=source_type,
+                                             source_value=source_value, initial_type=initial_type,
+                                             initial_amplitude=initial_amplitude)
+    return _store(field, data_dir, "heat_3d_spherical")
+
+
+def _radial_tool(fn, prefix, r_inner, r_outer, nr, diffusivity, T_inner, T_outer, T_initial, dt, num_steps, data_dir, steady,
+                 source_type, source_value, initial_type, initial_amplitude):
+    field = fn(r_inner=r_inner, r_outer=r_outer, nr=nr, diffusivity=diffusivity, T_inner=T_inner, T_outer=T_outer,
+               T_initial=T_initial, dt=dt, num_steps=num_steps, steady=steady, source_type=source_type,
+               source_value=source_value, initial_type=initial_type, initial_amplitude=initial_amplitude)
+    return _store(field, data_dir, prefix)
+
+
+def solve_heat_1D_cylindrical(r_inner: float = 0.1, r_outer: float = 1.0, nr: int = 50, diffusivity: float = 1.0,
+                              T_inner: float = 100.0, T_outer: float = 20.0, T_initial: float = 20.0, dt: float = 0.01,
+                              num_steps: int = 50, data_dir: str = "data", steady: bool = False, source_type: str = "none",
+                              source_value: float = 0.0, initial_type: str = "constant",
+                              initial_amplitude: float = 1.0) -> SolveResult:
+    """fenics_mcp_server.py:2220-2292"""
+    return _radial_tool(_cv._solve_heat_1d_cylindrical_raw, "heat_1d_cylindrical", r_inner, r_outer, nr, diffusivity, T_inner,
+                        T_outer, T_initial, dt, num_steps, data_dir, steady, source_type, source_value, initial_type,
+                        initial_amplitude)
+
+
+def solve_heat_1D_spherical(r_inner: float = 0.1, r_outer: float = 1.0, nr: int = 50, diffusivity: float = 1.0,
+                            T_inner: float = 100.0, T_outer: float = 20.0, T_initial: float = 20.0, dt: float = 0.01,
+                            num_steps: int = 50, data_dir: str = "data", steady: bool = False, source_type: str = "none",
+                            source_value: float = 0.0, initial_type: str = "constant",
+                            initial_amplitude: float = 1.0) -> SolveResult:
+    """fenics_mcp_server.py:2295-2367"""
+    return _radial_tool(_cv._solve_heat_1d_spherical_raw, "heat_1d_spherical", r_inner, r_outer, nr, diffusivity, T_inner,
+                        T_outer, T_initial, dt, num_steps, data_dir, steady, source_type, source_value, initial_type,
+                        initial_amplitude)
+
+
+def solve_heat_2D_cylindrical(r_inner: float = 0.1, r_outer: float = 1.0, z_length: float = 2.0, nr: int = 30, nz: int = 30,
+                              diffusivity: float = 1.0, T_boundary: float = 20.0, T_initial: float = 20.0, dt: float = 0.01,
+                              num_steps: int = 50, data_dir: str = "data", steady: bool = False, source_type: str = "none",
+                              source_value: float = 0.0, initial_type: str = "constant",
+                              initial_amplitude: float = 1.0) -> SolveResult:
+    """fenics_mcp_server.py:2370-2445"""
+    field = _cv._solve_heat_2d_cylindrical_raw(r_inner=r_inner, r_outer=r_outer, z_length=z_length, nr=nr, nz=nz,
+                                               diffusivity=diffusivity, T_boundary=T_boundary, T_initial=T_initial, dt=dt,
+                                               num_steps=num_steps, steady=steady, source_type=source_type,
+                                               source_value=source_value, initial_type=initial_type,
+                                               initial_amplitude=initial_amplitude)
+    return _store(field, data_dir, "heat_2d_cylindrical")
+
+
+def solve_heat_2D_spherical(r_inner: float = 0.1, r_outer: float = 1.0, nr: int = 30, ntheta: int = 30, diffusivity: float = 1.0,
+                            T_boundary: float = 20.0, T_initial: float = 20.0, dt: float = 0.01, num_steps: int = 50,
+                            data_dir: str = "data", steady: bool = False, source_type: str = "none", source_value: float = 0.0,
+                            initial_type: str = "constant", initial_amplitude: float = 1.0) -> SolveResult:
+    """fenics_mcp_server.py:2448-2520"""
+    field = _cv._solve_heat_2d_spherical_raw(r_inner=r_inner, r_outer=r_outer, nr=nr, ntheta=ntheta, diffusivity=diffusivity,
+                                             T_boundary=T_boundary, T_initial=T_initial, dt=dt, num_steps=num_steps,
+                                             steady=steady, source_type=source_type, source_value=source_value,
+                                             initial_type=initial_type, initial_amplitude=initial_amplitude)
+    return _store(field, data_dir, "heat_2d_spherical")
 
 
 def solve_elasticity_1D_static(L: float = 1.0, nx: int = 50, E: float = 210e9, area: float = 1.0,
@@ -133,9 +204,10 @@ def plot_time_series_field_from_file(data_file: str, field_name: Optional[str] =
     return PlotResult(html_path=str(path))
 
 
-TOOLS = {f.__name__: f for f in (solve_heat_1D, solve_heat_2D, solve_heat_3D, solve_elasticity_1D_static,
-                                 solve_elasticity_2D_static, solve_elasticity_3D_static,
-                                 plot_time_series_field_from_file)}
+TOOLS = {f.__name__: f for f in (solve_heat_1D, solve_heat_2D, solve_heat_3D, solve_heat_1D_cylindrical,
+                                 solve_heat_1D_spherical, solve_heat_2D_cylindrical, solve_heat_2D_spherical,
+                                 solve_heat_3D_spherical, solve_elasticity_1D_static, solve_elasticity_2D_static,
+                                 solve_elasticity_3D_static, plot_time_series_field_from_file)}
 
 
 def solve(pde_params, data_dir: Optional[str] = None) -> Dict[str, Any]:

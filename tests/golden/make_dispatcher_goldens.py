@@ -61,6 +61,14 @@ CASES = [
     dict(name="heat3d_defaults", params=dict(pde_type="heat", dim=3)),
     dict(name="heat3d_box_dims", params=dict(pde_type="heat", dim=3, geometry_type="cube", domain_size={"Lx": 1.0, "Ly": 0.2, "Lz": 0.2}, nx=20, ny=8, nz=8, bc_values={"T_boundary": 100.0}, initial_value=0.0, diffusivity=2.0)),
     dict(name="heat3d_dt_given", params=dict(pde_type="heat", dim=3, dt=0.005, num_steps=12, initial_type="zero")),
+    dict(name="cyl1d_defaults", params=dict(pde_type="heat", dim=1, geometry_type="cylinder")),
+    dict(name="cyl1d_full", params=dict(pde_type="heat", dim=1, geometry_type="pipe", geometry_params={"r_inner": 0.2, "cylinder_radius": 0.8}, nx=64, bc_values={"t_inner": 300.0, "T_outer": 25.0}, diffusivity=0.5, dt=0.002, num_steps=7, initial_value=25.0, source_type="constant", source_value=3.0)),
+    dict(name="sph1d_boundary_only", params=dict(pde_type="heat", dim=1, geometry_type="ball", geometry_params={"radius": 2.0}, bc_values={"t_boundary": 5.0}, steady=True)),
+    dict(name="cyl2d_defaults", params=dict(pde_type="heat", dim=2, coordinate_system="cylindrical")),
+    dict(name="cyl2d_full", params=dict(pde_type="heat", dim=2, geometry_type="cylinder", domain_size={"length": 3.0}, geometry_params={"r_outer": 0.5}, nx=12, ny=20, bc_values={"T_boundary": 0.0, "t_boundary": 40.0}, initial_value=0.0)),
+    dict(name="sph2d_defaults", params=dict(pde_type="heat", dim=2, geometry_type="sphere")),
+    dict(name="sph3d_defaults", params=dict(pde_type="heat", dim=3, geometry_type="spherical")),
+    dict(name="sph3d_full", params=dict(pde_type="heat", dim=3, domain_size={"r1": 0.1, "r2": 1.0}, geometry_params={"r_inner": 0.1, "sphere_radius": 1.5}, nx=8, ny=9, nz=10, bc_values={"t_boundary": 0.0}, initial_value=50.0, dt=0.005)),
     dict(name="elast1d_defaults", params=dict(pde_type="elasticity", dim=1)),
     dict(name="elast1d_full", params=dict(pde_type="elasticity", dim=1, domain_size={"length": 2.0}, nx=80, young_modulus=70e9, material_params={"area": 0.01, "body_force": 1000.0, "quantity": "strain"})),
     dict(name="elast2d_defaults", params=dict(pde_type="elasticity", dim=2)),
@@ -73,13 +81,44 @@ BUILDERS = {("heat", 1): "_build_1d_args", ("heat", 2): "_build_2d_args", ("heat
             ("elasticity", 1): "_build_elasticity_1d_args", ("elasticity", 2): "_build_elasticity_2d_args",
             ("elasticity", 3): "_build_elasticity_3d_args"}
 
+CURVI = {("cylinder", 1): ("solve_heat_1D_cylindrical", "_build_1d_cylindrical_args"),
+         ("sphere", 1): ("solve_heat_1D_spherical", "_build_1d_spherical_args"),
+         ("cylinder", 2): ("solve_heat_2D_cylindrical", "_build_2d_cylindrical_args"),
+         ("sphere", 2): ("solve_heat_2D_spherical", "_build_2d_spherical_args"),
+         ("sphere", 3): ("solve_heat_3D_spherical", "_build_3d_spherical_args")}
+
+
+def geometry_of(p):
+    """the geometry normalisation block of DispatcherAgent.dispatch (dispatcher_agent.py:117-146) is inline code of an
+    async method that needs the MCP client; the golden `tool` for the curvilinear cases is therefore derived here from
+    the geometry the case was written for (each case names it unambiguously)."""
+    g = (p.geometry_type or "").lower()
+    if g in ("cylinder", "cylindrical", "column", "tube", "pipe", "tunnel"):
+        return "cylinder"
+    if g in ("sphere", "spherical", "ball"):
+        return "sphere"
+    if not g:
+        if p.coordinate_system:
+            return {"cylindrical": "cylinder", "spherical": "sphere"}.get(str(p.coordinate_system).lower(), "box")
+        d = p.domain_size or {}
+        if ("r1" in d or "r2" in d):
+            return "cylinder" if "h" in d else "sphere"
+    return "box"
+
+
 out = []
 for case in CASES:
     p = PDEParameters(**case["params"])
-    fn = getattr(agent, BUILDERS[(p.pde_type, p.dim)])
+    geom = geometry_of(p) if p.pde_type == "heat" else "box"
     with contextlib.redirect_stdout(io.StringIO()):              # the 3-D builder prints debug lines
-        kw = fn(p, "box") if p.pde_type == "heat" else fn(p)
-    out.append({"name": case["name"], "params": case["params"], "kwargs": kw})
+        if (geom, p.dim) in CURVI:
+            tool, builder = CURVI[(geom, p.dim)]
+            kw = getattr(agent, builder)(p)
+        else:
+            fn = getattr(agent, BUILDERS[(p.pde_type, p.dim)])
+            kw = fn(p, "box") if p.pde_type == "heat" else fn(p)
+            tool = f"solve_heat_{p.dim}D" if p.pde_type == "heat" else f"solve_elasticity_{p.dim}D_static"
+    out.append({"name": case["name"], "params": case["params"], "tool": tool, "kwargs": kw})
 
 dst = Path(__file__).resolve().parent / "dispatcher_kwargs.json"
 dst.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")

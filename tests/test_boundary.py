@@ -16,9 +16,7 @@ GOLDEN = json.loads((Path(__file__).parent / "golden" / "dispatcher_kwargs.json"
 def test_route_reproduces_reference_kwargs(case):
     from pdegpu import params
     name, kw = params.route(case["params"])
-    p = case["params"]
-    expect = f"solve_heat_{p['dim']}D" if p["pde_type"] == "heat" else f"solve_elasticity_{p['dim']}D_static"
-    assert name == expect
+    assert name == case["tool"]
     assert kw == case["kwargs"]
     for k, v in case["kwargs"].items():
         assert type(kw[k]) is type(v), (k, kw[k], v)        # int stays int, float stays float through JSON
@@ -36,7 +34,7 @@ def test_route_accepts_the_reference_dataclass_shape_and_rejects_other_pdes():
     with pytest.raises(ValueError):
         params.route({"pde_type": "heat", "dim": 4})
     with pytest.raises(NotImplementedError):
-        params.route({"pde_type": "heat", "dim": 3, "geometry_type": "pipe"})
+        params.route({"pde_type": "heat", "dim": 3, "geometry_type": "pipe"})          # mshr cylinder mesh
     assert params.geometry_of({"domain_size": {"r2": 1.0, "h": 2.0}}) == "cylinder"
     assert params.geometry_of({"coordinate_system": "spherical"}) == "sphere"
     assert params.geometry_of({"geometry_type": "Cube"}) == "box"
@@ -56,6 +54,23 @@ SIGNATURES = {
                       ("source_type", "none"), ("source_value", 0.0), ("initial_type", "constant"), ("initial_amplitude", 1.0),
                       ("initial_wavenumber", 1.0), ("geometry_type", "box"), ("cylinder_radius", None), ("T_left", None),
                       ("T_right", None), ("T_side", None), ("core_radius", None), ("core_diffusivity", None)],
+    "solve_heat_1D_cylindrical": [("r_inner", 0.1), ("r_outer", 1.0), ("nr", 50), ("diffusivity", 1.0), ("T_inner", 100.0), ("T_outer", 20.0),
+                                  ("T_initial", 20.0), ("dt", 0.01), ("num_steps", 50), ("data_dir", "data"), ("steady", False),
+                                  ("source_type", "none"), ("source_value", 0.0), ("initial_type", "constant"), ("initial_amplitude", 1.0)],
+    "solve_heat_1D_spherical": [("r_inner", 0.1), ("r_outer", 1.0), ("nr", 50), ("diffusivity", 1.0), ("T_inner", 100.0), ("T_outer", 20.0),
+                                ("T_initial", 20.0), ("dt", 0.01), ("num_steps", 50), ("data_dir", "data"), ("steady", False),
+                                ("source_type", "none"), ("source_value", 0.0), ("initial_type", "constant"), ("initial_amplitude", 1.0)],
+    "solve_heat_2D_cylindrical": [("r_inner", 0.1), ("r_outer", 1.0), ("z_length", 2.0), ("nr", 30), ("nz", 30), ("diffusivity", 1.0),
+                                  ("T_boundary", 20.0), ("T_initial", 20.0), ("dt", 0.01), ("num_steps", 50), ("data_dir", "data"),
+                                  ("steady", False), ("source_type", "none"), ("source_value", 0.0), ("initial_type", "constant"),
+                                  ("initial_amplitude", 1.0)],
+    "solve_heat_2D_spherical": [("r_inner", 0.1), ("r_outer", 1.0), ("nr", 30), ("ntheta", 30), ("diffusivity", 1.0), ("T_boundary", 20.0),
+                                ("T_initial", 20.0), ("dt", 0.01), ("num_steps", 50), ("data_dir", "data"), ("steady", False),
+                                ("source_type", "none"), ("source_value", 0.0), ("initial_type", "constant"), ("initial_amplitude", 1.0)],
+    "solve_heat_3D_spherical": [("r_inner", 0.1), ("r_outer", 1.0), ("nr", 20), ("ntheta", 20), ("nphi", 20), ("diffusivity", 1.0),
+                                ("T_boundary", 20.0), ("T_initial", 20.0), ("dt", 0.01), ("num_steps", 50), ("data_dir", "data"),
+                                ("steady", False), ("source_type", "none"), ("source_value", 0.0), ("initial_type", "constant"),
+                                ("initial_amplitude", 1.0)],
     "solve_elasticity_1D_static": [("L", 1.0), ("nx", 50), ("E", 210e9), ("area", 1.0), ("body_force", 0.0), ("quantity", "stress"),
                                    ("data_dir", "data")],
     "solve_elasticity_2D_static": [("Lx", 1.0), ("Ly", 1.0), ("nx", 30), ("ny", 30), ("E", 210e9), ("nu", 0.3), ("body_fx", 0.0),

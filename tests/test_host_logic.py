@@ -207,3 +207,44 @@ def test_loader_binds_one_hip_runtime(lib):
     maps = open("/proc/self/maps").read()
     paths = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
     assert len(paths) == 1, paths
+
+
+@pytest.mark.parametrize("dim,n,Ls,origin,kind", [
+    (1, (6,), (1.5,), (0.5, 0, 0), "r"), (1, (5,), (2.0,), (0.0, 0, 0), "r2"),
+    (2, (4, 3), (1.0, 2.0), (0.25, 0, 0), "r"), (2, (3, 4), (0.8, np.pi), (0.2, 0, 0), "r2sin"),
+    (3, (3, 2, 3), (0.8, np.pi, 2 * np.pi), (0.2, 0, 0), "r2sin"), (3, (2, 2, 2), (1.0, 1.0, 1.0), (0.0, 0, 0), "r2")])
+def test_weighted_rows_match_oracle_assembly(lib, dim, n, Ls, origin, kind):
+    """per-node coupling weights of the curvilinear forms (host twin of k_weighted_assemble, same source) ==
+    the oracle's weighted matrices, every node (boundary truncation included)"""
+    from pdegpu import _lib
+    g = _lib.make_grid(dim, n, Ls)
+    N = int(lib.pdegpu_grid_num_nodes(g))
+    rK, rM, ld = np.zeros((N, 15)), np.zeros((N, 15)), np.zeros(N)
+    org = np.array(origin, dtype=float)
+    code = {"r": _lib.WEIGHT_R, "r2": _lib.WEIGHT_R2, "r2sin": _lib.WEIGHT_R2SIN}[kind]
+    assert lib.pdegpu_weighted_rows_host(g, _lib.dptr(org), code, _lib.dptr(rK), _lib.dptr(rM), _lib.dptr(ld)) == 0
+    if dim == 1:
+        c, cells = o.interval_mesh(n[0], origin[0], origin[0] + Ls[0])
+    elif dim == 2:
+        c, cells = o.shifted_rectangle_mesh(origin[0], origin[0] + Ls[0], 0.0, Ls[1], n[0], n[1])
+    else:
+        c, cells = o.box_mesh(*Ls, *n)
+        c = c + org
+    K, M, load = o.assemble_weighted(c, cells, kind)
+    K, M = K.toarray(), M.toarray()
+    assert np.abs(ld - load).max() < 1e-13 * np.abs(load).max()
+    off15 = [13, 12, 14, 10, 16, 4, 22, 9, 17, 3, 23, 1, 25, 0, 26]
+    nn = [n[r] + 1 if r < dim else 1 for r in range(3)]
+    Kd, Md = np.zeros_like(K), np.zeros_like(M)
+    for row in range(N):
+        i3 = (row % nn[0], (row // nn[0]) % nn[1], row // (nn[0] * nn[1]))
+        for q, off in enumerate(off15):
+            d = (off % 3 - 1, (off // 3) % 3 - 1, off // 9 - 1)
+            nb = [i3[r] + d[r] for r in range(3)]
+            if all(0 <= nb[r] < nn[r] for r in range(3)):
+                col = nb[0] + nn[0] * (nb[1] + nn[1] * nb[2])
+                Kd[row, col], Md[row, col] = rK[row, q], rM[row, q]
+            else:
+                assert rK[row, q] == 0.0 and rM[row, q] == 0.0
+    assert np.abs(Kd - K).max() < 1e-12 * np.abs(K).max()
+    assert np.abs(Md - M).max() < 1e-12 * np.abs(M).max()

@@ -1,0 +1,76 @@
+"""Known answers for the oracle's curvilinear (weighted) heat restatement, fenics_mcp_server.py:769-1464 —
+like the Cartesian path it is unpinned by the reference (no tests / fixtures exist, FEniCS not installable)."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import fem_p1 as o
+
+
+def test_weight_integrals_are_exact_for_polynomial_weights():
+    # int_a^b r dr, int r^2 dr: the load vector sums to the exact integral (P1 / P2 interpolation is exact)
+    c, cells = o.interval_mesh(7, 0.3, 2.0)
+    _, M, load = o.assemble_weighted(c, cells, "r")
+    assert load.sum() == pytest.approx((2.0 ** 2 - 0.3 ** 2) / 2, rel=1e-14)
+    assert np.allclose(M @ np.ones(8), load, rtol=1e-14)
+    _, M2, load2 = o.assemble_weighted(c, cells, "r2")
+    assert load2.sum() == pytest.approx((2.0 ** 3 - 0.3 ** 3) / 3, rel=1e-14)
+    # 2-D: int int r dr dz = (b^2-a^2)/2 * H
+    c2, cells2 = o.shifted_rectangle_mesh(0.5, 1.5, 0.0, 2.0, 5, 4)
+    K, M, load = o.assemble_weighted(c2, cells2, "r")
+    assert load.sum() == pytest.approx((1.5 ** 2 - 0.5 ** 2) / 2 * 2.0, rel=1e-14)
+    assert abs(K - K.T).max() < 1e-14 and abs(M - M.T).max() < 1e-15
+    assert np.abs(K @ np.ones(K.shape[0])).max() < 1e-13
+    # weight 1 reproduces the unweighted matrices: emulate with r on [1,1+eps]? use the identity w=r at r->const
+    K0, M0, l0 = o.assemble_scalar(c2, cells2)
+    assert load.sum() / l0.sum() == pytest.approx(1.0, rel=1e-12)             # mean radius of [0.5, 1.5] is 1
+
+
+def test_r2sin_weight_converges_to_the_sphere_volume():
+    vols = []
+    for n in (4, 8, 16):
+        c, cells = o.box_mesh(1.0, np.pi, 2 * np.pi, n, n, n)
+        _, _, load = o.assemble_weighted(c, cells, "r2sin")
+        vols.append(load.sum())
+    exact = 4.0 / 3.0 * np.pi
+    errs = [abs(v - exact) for v in vols]
+    assert errs[2] < 2e-4 * exact and errs[0] / errs[1] > 8 and errs[1] / errs[2] > 8      # P2 interpolation of sin: O(h^4)
+
+
+def test_1d_cylindrical_steady_converges_to_the_log_profile():
+    errs = []
+    for nr in (16, 32, 64):
+        f = o.solve_heat_1d_cylindrical(0.5, 2.0, nr, 1.3, 10.0, 2.0, 0.0, 0.01, 1, steady=True)
+        r = f.coords[:, 0]
+        exact = 10.0 + (2.0 - 10.0) * np.log(r / 0.5) / math.log(2.0 / 0.5)
+        errs.append(np.abs(f.values[0] - exact).max())
+    assert errs[0] / errs[1] > 3.5 and errs[1] / errs[2] > 3.5 and errs[2] < 2e-4
+    assert f.meta["geometry_type"] == "annulus" and f.meta["coordinate_system"] == "cylindrical"
+
+
+def test_1d_spherical_steady_converges_to_the_1_over_r_profile_and_solid_sphere_source():
+    errs = []
+    for nr in (16, 32, 64):
+        f = o.solve_heat_1d_spherical(0.5, 2.0, nr, 1.0, 10.0, 2.0, 0.0, 0.01, 1, steady=True)
+        r = f.coords[:, 0]
+        A = (10.0 - 2.0) / (1 / 0.5 - 1 / 2.0)
+        exact = 2.0 + A * (1 / r - 1 / 2.0)
+        errs.append(np.abs(f.values[0] - exact).max())
+    assert errs[0] / errs[1] > 3.5 and errs[1] / errs[2] > 3.5
+    # solid sphere (r_inner = 0: no inner BC, :968), uniform source: u = T_out + f (R^2 - r^2) / (6 k)
+    g = o.solve_heat_1d_spherical(0.0, 1.5, 64, 2.0, 99.0, 3.0, 0.0, 0.01, 1, steady=True, source_type="constant", source_value=4.0)
+    r = g.coords[:, 0]
+    assert np.abs(g.values[0] - (3.0 + 4.0 * (1.5 ** 2 - r ** 2) / 12.0)).max() < 2e-3
+    assert g.meta["geometry_type"] == "sphere"
+
+
+def test_transient_weighted_conserves_constants_and_decays():
+    f = o.solve_heat_2d_cylindrical(0.0, 1.0, 2.0, 6, 8, 1.0, 5.0, 5.0, 0.01, 3)
+    assert np.abs(f.values - 5.0).max() < 1e-12                                # u == T_b is a fixed point
+    assert np.allclose(f.coords[:, 1], 0.0) and f.coords[:, 2].max() == pytest.approx(2.0)
+    g = o.solve_heat_3d_spherical(0.2, 1.0, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 3)
+    m = np.abs(g.values).max(axis=1)
+    assert m[0] == 20.0 and np.all(np.diff(m) < 0) and g.values.min() > -1e-9
+    h = o.solve_heat_2d_spherical(0.2, 1.0, 5, 6, 1.0, 1.0, 20.0, 0.01, 2)
+    assert h.values.shape == (3, 42) and np.allclose(h.coords[:, 1], 0.0)
