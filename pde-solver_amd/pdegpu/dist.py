@@ -61,6 +61,7 @@ class GpuSlabEngine:
         self.s = C.c_void_p()
         L.check(self.ctx, self.lib.pdegpu_session_create(self.ctx, grid, heat, k0, nk, C.byref(self.s)))
         self.plane = int(self.lib.pdegpu_session_plane_doubles(self.s))
+        self._planes = {}            # device pointer -> zero-copy tensor view (pointers are fixed for the session's life)
         self._scal = torch.as_tensor(_DevArray(self.lib.pdegpu_session_scalars(self.s), 8), device=f"cuda:{device}")
 
     def close(self):
@@ -99,7 +100,10 @@ class GpuSlabEngine:
         ptr = self.lib.pdegpu_session_plane_ptr(self.s, vec, which)
         if not ptr:
             raise L.PdeGpuError(L.EINVAL, f"no plane {which} of vector {vec}")
-        return torch.as_tensor(_DevArray(ptr, self.plane), device=f"cuda:{self.device}")
+        t = self._planes.get(ptr)
+        if t is None:
+            t = self._planes[ptr] = torch.as_tensor(_DevArray(ptr, self.plane), device=f"cuda:{self.device}")
+        return t
 
     def needs_p_halo(self) -> bool:
         return bool(self.lib.pdegpu_session_needs_p_halo(self.s))
