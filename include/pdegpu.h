@@ -142,16 +142,19 @@ int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_hea
 #define PDEGPU_WEIGHT_R     1      /* w = x0            Expression("x[0]", degree=1)               (:802, :1100) */
 #define PDEGPU_WEIGHT_R2    2      /* w = x0^2          Expression("x[0] * x[0]", degree=2)        (:965)        */
 #define PDEGPU_WEIGHT_R2SIN 3      /* w = x0^2 sin(x1)  Expression("x[0] * x[0] * sin(x[1])", 2)   (:1230, :1371) */
+#define PDEGPU_WEIGHT_RCYL  4      /* w = sqrt(x1^2+x2^2), degree 2: the BoxMesh fallback of the 3-D cylinder (:523-529, :645) */
 typedef struct pdegpu_weight {
     int32_t kind;               /* PDEGPU_WEIGHT_* */
     int32_t reserved;
     double  origin[3];          /* lower corner of the mesh in coordinate space (r_inner, 0, 0) */
+    double  core_radius;        /* composite core (:537-572): a simplex whose vertices and midpoint all lie within   */
+    double  core_ratio;         /* core_radius of the x-axis has diffusivity core_ratio * kappa; core_radius <= 0: none */
 } pdegpu_weight;
 int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
                                const pdegpu_heat* heat, double* values_out, double* times_out, pdegpu_stats* stats);
 /* host twin of the per-node weighted assembly (CPU tests): rowsK / rowsM [N][15] (15-offset order
  * {0, -x, +x, -y, +y, -z, +z, -(xy), +(xy), -(xz), +(xz), -(yz), +(yz), -(xyz), +(xyz)}), load [N] */
-int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const double* origin, int kind, double* rowsK, double* rowsM,
+int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const pdegpu_weight* weight, double* rowsK, double* rowsM,
                               double* load);
 
 /* ---- project(f, V) with a consistent mass matrix (:284, :415, :679, :1542, :1714, :1862):

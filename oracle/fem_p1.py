@@ -451,6 +451,7 @@ WEIGHTS = {
     "r": (1, lambda X: X[:, 0]),
     "r2": (2, lambda X: X[:, 0] ** 2),
     "r2sin": (2, lambda X: X[:, 0] ** 2 * np.sin(X[:, 1])),
+    "rcyl": (2, lambda X: np.sqrt(X[:, 1] ** 2 + X[:, 2] ** 2)),   # Expression("sqrt(x[1]*x[1] + x[2]*x[2])", degree=2) (:645)
 }
 
 
@@ -494,13 +495,16 @@ def _weight_terms(coords, cells, kind):
     return terms
 
 
-def assemble_weighted(coords, cells, kind):
-    """K_w, M_w, load_w with the interpolated weight integrated exactly"""
+def assemble_weighted(coords, cells, kind, kcell=None):
+    """K_w, M_w, load_w with the interpolated weight integrated exactly; kcell = per-cell factor of the stiffness
+    form (DG0 diffusivity of the composite core, :554-572)"""
     n, d = coords.shape
     m = d + 1
     vol, grads = simplex_geometry(coords, cells)
     terms = _weight_terms(coords, cells, kind)
     w_int = sum(c * _mono(d, idx) for c, idx in terms) * vol                      # int_T w
+    if kcell is not None:
+        w_int = w_int * kcell
     Ke = w_int[:, None, None] * np.einsum("cad,cbd->cab", grads, grads)
     Me = np.zeros((cells.shape[0], m, m))
     le = np.zeros((cells.shape[0], m))
@@ -516,8 +520,8 @@ def assemble_weighted(coords, cells, kind):
 
 
 def _weighted_heat_core(coords, cells, kind, dir_mask, dir_vals, kappa, T_initial, dt, num_steps, steady, source_type,
-                        source_value):
-    K, M, load = assemble_weighted(coords, cells, kind)
+                        source_value, kcell=None):
+    K, M, load = assemble_weighted(coords, cells, kind, kcell)
     f = float(source_value) if source_type == "constant" else 0.0
     if steady:
         return solve_dirichlet(kappa * K, f * load, dir_mask, dir_vals)[None, :], np.array([0.0])
@@ -620,3 +624,53 @@ def solve_heat_3d_spherical(r_inner, r_outer, nr, ntheta, nphi, diffusivity, T_b
             "geometry_type": "sphere" if r_inner < 1e-10 else "spherical_shell", "r_inner": r_inner, "r_outer": r_outer,
             "source_type": source_type, "source_value": source_value, "steady": steady}
     return OracleField(c3, vals, times, 3, meta)
+
+
+def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_initial, dt, num_steps, cylinder_radius,
+                                    steady=False, source_type="none", source_value=0.0, T_left=None, T_right=None, T_side=None,
+                                    core_radius=None, core_diffusivity=None, Ly=1.0, Lz=1.0):
+    """_solve_heat_3d_raw with geometry_type="cylinder" when mshr is not installed (it is in neither the reference's
+    Dockerfile nor its requirements.txt, so this IS what the reference runs): fenics_mcp_server.py:523-529 BoxMesh
+    (0,-R,-R)-(Lx,R,R) with int(ny*2R) x int(nz*2R) cells across, :642-645 weight sqrt(y^2+z^2) as a degree-2
+    Expression, :537-572 DG0 diffusivity (a cell is core when all its vertices and its midpoint lie within
+    core_radius of the axis — SubDomain.mark), :582-604 directional BCs.  On this box mesh no boundary facet has all
+    its vertices at distance exactly R from the axis, so the `T_side` condition (:590-594, topological DirichletBC)
+    constrains nothing; without directional values every boundary node gets T_boundary (:626-628).
+    Constant initial condition; the trig ICs of the box branch are not restated for this branch."""
+    R = float(cylinder_radius)
+    ny2, nz2 = int(ny * R * 2), int(nz * R * 2)
+    if ny2 < 1 or nz2 < 1:
+        raise ValueError("BoxMesh needs at least one cell per axis (int(ny*2R), int(nz*2R))")
+    coords, cells = box_mesh(Lx, 2 * R, 2 * R, nx, ny2, nz2)
+    coords = coords + np.array([0.0, -R, -R])
+    n = coords.shape[0]
+    directional = T_left is not None or T_right is not None or T_side is not None
+    if directional:
+        dir_mask, dir_vals = box_dirichlet(nx, ny2, nz2, T_left=T_left, T_right=T_right, T_side=None)
+    else:
+        dir_mask, dir_vals = box_dirichlet(nx, ny2, nz2, T_boundary=T_boundary)
+    kcell = None
+    composite = core_radius is not None and core_diffusivity is not None
+    if composite:
+        P = coords[cells]
+        rv = np.sqrt(P[:, :, 1] ** 2 + P[:, :, 2] ** 2)
+        mid = P.mean(axis=1)
+        rm = np.sqrt(mid[:, 1] ** 2 + mid[:, 2] ** 2)
+        core = (rv < core_radius).all(axis=1) & (rm < core_radius)
+        kcell = np.where(core, core_diffusivity / diffusivity, 1.0)
+    vals, times = _weighted_heat_core(coords, cells, "rcyl", dir_mask, dir_vals, diffusivity, T_initial, dt, num_steps, steady,
+                                      source_type, source_value, kcell)
+    meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cylindrical", "Lx": Lx, "Ly": R * 2,
+            "Lz": R * 2, "geometry_type": "cylinder", "source_type": source_type, "source_value": source_value, "steady": steady,
+            "cylinder_radius": R}
+    if directional:
+        for k, v in (("T_left", T_left), ("T_right", T_right), ("T_side", T_side)):
+            if v is not None:
+                meta[k] = v
+    else:
+        meta["T_boundary"] = T_boundary
+    if composite:
+        meta.update({"core_radius": core_radius, "core_diffusivity": core_diffusivity, "base_diffusivity": diffusivity})
+    else:
+        meta["diffusivity"] = diffusivity
+    return OracleField(coords, vals, times, 3, meta)

@@ -194,7 +194,7 @@ int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const 
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
 // weighted.hip
-int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const double* origin, const double* h, int kind, double cM, double cK,
+int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, double cM, double cK,
                       double* ellA, double* ellM, double* dinv, long long stride);
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, const double* scal,
               double* partials, int use_alpha, LaunchInfo* li);

@@ -730,7 +730,7 @@ int session_make_weighted(pdegpu_session* s, const pdegpu_weight* w) {
     PG_TRY(vec_alloc(ctx, s->g, &s->z));
     double h[3] = {1, 1, 1};
     for (int r = 0; r < s->grid.dim; ++r) h[r] = s->grid.L[r] / s->grid.n[r];
-    PG_TRY(weighted_assemble(ctx, s->g, w->origin, h, w->kind, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride));
+    PG_TRY(weighted_assemble(ctx, s->g, w, h, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride));
     s->weighted = true;
     return PDEGPU_OK;
 }
@@ -749,8 +749,10 @@ extern "C" int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* gr
                                           const pdegpu_heat* heat_in, double* values_out, double* times_out, pdegpu_stats* stats) {
     if (!ctx) return PDEGPU_EINVAL;
     if (!weight) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null weight");
-    if (weight->kind < 1 || weight->kind > 3) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
+    if (weight->kind < 1 || weight->kind > 4) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
     if (grid && weight->kind == 3 && grid->dim < 2) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weight r^2 sin(theta) needs dim >= 2");
+    if (grid && weight->kind == 4 && grid->dim < 3) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weight sqrt(y^2+z^2) needs dim == 3");
+    if (weight->core_radius > 0.0 && !(weight->core_ratio > 0.0)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "core_ratio must be > 0");
     if (grid && grid->element_mode != PDEGPU_ELEM_P1SPLIT) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted forms use the P1 split only");
     return heat_solve_impl(ctx, grid, heat_in, weight, nullptr, values_out, times_out, stats);
 }

@@ -247,6 +247,7 @@ __host__ __device__ inline void fold_elasticity_block(int dim, const double* h, 
 __host__ __device__ inline double pg_weight_eval(int kind, const double* x) {
     if (kind == PDEGPU_WEIGHT_R) return x[0];
     if (kind == PDEGPU_WEIGHT_R2) return x[0] * x[0];
+    if (kind == PDEGPU_WEIGHT_RCYL) return sqrt(x[1] * x[1] + x[2] * x[2]);
     return x[0] * x[0] * sin(x[1]);
 }
 __host__ __device__ inline int pg_weight_degree(int kind) { return kind == PDEGPU_WEIGHT_R ? 1 : 2; }
@@ -271,7 +272,8 @@ __host__ __device__ inline double pg_mono(int d, const int* e) {
 
 // row of node (i, j, k): rowK[15], rowM[15] (positions of the 15-offset list) and the load entry int w phi_i
 __host__ __device__ inline void weighted_row(int dim, const int* nn /*node counts*/, const double* origin, const double* h, int kind,
-                                             int i, int j, int k, double* rowK, double* rowM, double* load) {
+                                             double core_radius, double core_ratio, int i, int j, int k, double* rowK,
+                                             double* rowM, double* load) {
     for (int q = 0; q < PG_NOFF15; ++q) { rowK[q] = 0.0; rowM[q] = 0.0; }
     *load = 0.0;
     const int idx3[3] = {i, j, k};
@@ -325,6 +327,18 @@ __host__ __device__ inline void weighted_row(int dim, const int* nn /*node count
                         for (int e = 0; e < 4; ++e) expo[nt][e] = (e == a) + (e == b);
                         ++nt;
                     }
+            // composite core: DG0 diffusivity, a simplex is core iff all vertices and the midpoint are inside (:541-550)
+            double kfac = 1.0;
+            if (core_radius > 0.0) {
+                bool core = true;
+                double mid[3] = {0, 0, 0};
+                for (int p = 0; p <= dim; ++p) {
+                    core &= sqrt(X[p][1] * X[p][1] + X[p][2] * X[p][2]) < core_radius;
+                    for (int r = 0; r < 3; ++r) mid[r] += X[p][r] / (dim + 1);
+                }
+                core &= sqrt(mid[1] * mid[1] + mid[2] * mid[2]) < core_radius;
+                if (core) kfac = core_ratio;
+            }
             double w_int = 0.0, w_a = 0.0;
             for (int u = 0; u < nt; ++u) {
                 int e[4] = {expo[u][0], expo[u][1], expo[u][2], expo[u][3]};
@@ -347,7 +361,7 @@ __host__ __device__ inline void weighted_row(int dim, const int* nn /*node count
                     e[p] += 1;
                     w_ab += coef[u] * pg_mono(dim, e);
                 }
-                rowK[q] += vol * w_int * gg;
+                rowK[q] += kfac * vol * w_int * gg;
                 rowM[q] += vol * w_ab;
             }
         }

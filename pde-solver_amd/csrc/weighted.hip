@@ -25,7 +25,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-struct WeightGeom { double origin[3], h[3]; };
+struct WeightGeom { double origin[3], h[3], core_radius, core_ratio; };
 
 __global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom wg, int kind, double cM, double cK,
                                                             double* __restrict__ ellA, double* __restrict__ ellM,
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom
         const int k = g.k0 + (int)(row / g.NY);
         double rowK[PG_NOFF15], rowM[PG_NOFF15], ld = 0.0;
         if (i < g.NX) {
-            weighted_row(g.dim, nn, wg.origin, wg.h, kind, i, j, k, rowK, rowM, &ld);
+            weighted_row(g.dim, nn, wg.origin, wg.h, kind, wg.core_radius, wg.core_ratio, i, j, k, rowK, rowM, &ld);
         } else {
             for (int q = 0; q < PG_NOFF15; ++q) rowK[q] = rowM[q] = 0.0;
         }
@@ -87,10 +87,13 @@ inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
 
 }  // namespace
 
-int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const double* origin, const double* h, int kind, double cM, double cK,
+int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, double cM, double cK,
                       double* ellA, double* ellM, double* dinv, long long stride) {
     WeightGeom wg{};
-    for (int r = 0; r < 3; ++r) { wg.origin[r] = origin[r]; wg.h[r] = h[r]; }
+    for (int r = 0; r < 3; ++r) { wg.origin[r] = w->origin[r]; wg.h[r] = h[r]; }
+    wg.core_radius = w->core_radius;
+    wg.core_ratio = w->core_ratio;
+    const int kind = w->kind;
     const long long total = (long long)g.nkl * g.PP;
     hipLaunchKernelGGL(k_weighted_assemble, dim3(flat_grid(ctx, total)), dim3(256), 0, ctx->stream, g, wg, kind, cM, cK, ellA, ellM,
                        dinv, stride);
@@ -109,11 +112,14 @@ int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, dou
 }
 
 // host twin of k_weighted_assemble (CPU test-suite): rowsK / rowsM [N][15] in node order (x fastest), load [N]
-extern "C" int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const double* origin, int kind, double* rowsK, double* rowsM,
+extern "C" int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const pdegpu_weight* weight, double* rowsK, double* rowsM,
                                          double* load) {
-    if (!grid || !origin || !rowsK || !rowsM || !load || grid->dim < 1 || grid->dim > 3) return PDEGPU_EINVAL;
-    if (kind < PDEGPU_WEIGHT_R || kind > PDEGPU_WEIGHT_R2SIN) return PDEGPU_EINVAL;
+    if (!grid || !weight || !rowsK || !rowsM || !load || grid->dim < 1 || grid->dim > 3) return PDEGPU_EINVAL;
+    const int kind = weight->kind;
+    const double* origin = weight->origin;
+    if (kind < PDEGPU_WEIGHT_R || kind > PDEGPU_WEIGHT_RCYL) return PDEGPU_EINVAL;
     if (kind == PDEGPU_WEIGHT_R2SIN && grid->dim < 2) return PDEGPU_EINVAL;
+    if (kind == PDEGPU_WEIGHT_RCYL && grid->dim < 3) return PDEGPU_EINVAL;
     double h[3] = {1, 1, 1};
     int nn[3] = {1, 1, 1};
     for (int r = 0; r < grid->dim; ++r) {
@@ -124,6 +130,8 @@ extern "C" int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const double* 
     long long idx = 0;
     for (int k = 0; k < nn[2]; ++k)
         for (int j = 0; j < nn[1]; ++j)
-            for (int i = 0; i < nn[0]; ++i, ++idx) weighted_row(grid->dim, nn, origin, h, kind, i, j, k, rowsK + idx * 15, rowsM + idx * 15, load + idx);
+            for (int i = 0; i < nn[0]; ++i, ++idx)
+                weighted_row(grid->dim, nn, origin, h, kind, weight->core_radius, weight->core_ratio, i, j, k, rowsK + idx * 15, rowsM + idx * 15,
+                             load + idx);
     return PDEGPU_OK;
 }

@@ -38,10 +38,11 @@ class Heat(C.Structure):
 
 
 class Weight(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("origin", C.c_double * 3)]
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("origin", C.c_double * 3), ("core_radius", C.c_double),
+                ("core_ratio", C.c_double)]
 
 
-WEIGHT_R, WEIGHT_R2, WEIGHT_R2SIN = 1, 2, 3
+WEIGHT_R, WEIGHT_R2, WEIGHT_R2SIN, WEIGHT_RCYL = 1, 2, 3, 4
 
 
 class Elasticity(C.Structure):
@@ -79,7 +80,7 @@ SYMBOLS = {
     "pdegpu_heat_num_snapshots": (C.c_int, [C.POINTER(Heat)]),
     "pdegpu_heat_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_heat_solve_weighted": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.POINTER(Heat), _dp, _dp, C.POINTER(Stats)]),
-    "pdegpu_weighted_rows_host": (C.c_int, [C.POINTER(Grid), _dp, C.c_int, _dp, _dp, _dp]),
+    "pdegpu_weighted_rows_host": (C.c_int, [C.POINTER(Grid), C.POINTER(Weight), _dp, _dp, _dp]),
     "pdegpu_mass_solve": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, C.c_double, C.c_int, C.POINTER(Stats)]),
     "pdegpu_heat_apply": (C.c_int, [_vp, C.POINTER(Grid), C.c_double, C.c_double, _dp, _dp, _dp, C.c_int]),
     "pdegpu_heat_tables": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, _dp]),

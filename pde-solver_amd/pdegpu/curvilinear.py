@@ -15,7 +15,8 @@ from .fields import TimeSeriesField
 
 
 def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady, source_type, source_value, T_initial,
-                 bc_mode, bc_value, bc_present, rtol=None, max_iter=None, snapshot_stride=None, device=None):
+                 bc_mode, bc_value, bc_present, core_radius=0.0, core_ratio=1.0, rtol=None, max_iter=None,
+                 snapshot_stride=None, device=None):
     lib = L.load_library()
     ctx = L.context(device)
     grid = L.make_grid(dim, n, lengths, L.ELEM_P1SPLIT)
@@ -26,6 +27,7 @@ def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady,
     w.kind = kind
     for r in range(3):
         w.origin[r] = float(origin[r]) if r < len(origin) else 0.0
+    w.core_radius, w.core_ratio = float(core_radius), float(core_ratio)
     h = L.Heat()
     h.kappa, h.dt, h.num_steps, h.steady = float(kappa), float(dt), int(num_steps), 1 if steady else 0
     h.source = float(source_value) if source_type == "constant" else 0.0
@@ -141,4 +143,50 @@ def _solve_heat_3d_spherical_raw(r_inner: float, r_outer: float, nr: int, ntheta
     coords = np.stack([R * np.sin(T) * np.cos(PH), R * np.sin(T) * np.sin(PH), R * np.cos(T)], axis=1)
     meta = _meta("spherical", "sphere" if r_inner < 1e-10 else "spherical_shell", r_inner, r_outer, source_type, source_value,
                  steady, st)
+    return TimeSeriesField(coords=coords, values=values, times=times, dim=3, meta=meta)
+
+
+def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_initial, dt, num_steps, cylinder_radius,
+                                    steady=False, source_type="none", source_value=0.0, T_left=None, T_right=None, T_side=None,
+                                    core_radius=None, core_diffusivity=None, **opts) -> TimeSeriesField:
+    """`_solve_heat_3d_raw(geometry_type="cylinder")` as the reference runs it without mshr (which is in neither its
+    Dockerfile nor its requirements): fenics_mcp_server.py:523-529 BoxMesh (0,-R,-R)-(Lx,R,R) with int(ny*2R) x
+    int(nz*2R) cells across, :645 weight sqrt(y^2+z^2) (degree 2), :537-572 per-cell core diffusivity, :582-604
+    directional conditions (on this mesh the `T_side` predicate matches no boundary facet), else T_boundary on the
+    whole box boundary (:626-628).  Constant initial condition."""
+    R = float(cylinder_radius)
+    ny2, nz2 = int(ny * R * 2), int(nz * R * 2)
+    if ny2 < 1 or nz2 < 1:
+        raise L.PdeGpuError(L.EINVAL, f"BoxMesh fallback needs int(ny*2R) >= 1 and int(nz*2R) >= 1 (got {ny2}, {nz2})")
+    directional = T_left is not None or T_right is not None or T_side is not None
+    if directional:
+        bc_mode = L.BC_DIRECTIONAL
+        bc_value = (0.0 if T_left is None else T_left, 0.0 if T_right is None else T_right, 0.0)
+        bc_present = (0 if T_left is None else 1, 0 if T_right is None else 1, 0)
+    else:
+        bc_mode, bc_value, bc_present = L.BC_UNIFORM, (T_boundary, 0.0, 0.0), (1, 0, 0)
+    composite = core_radius is not None and core_diffusivity is not None
+    values, times, st = run_weighted(3, (nx, ny2, nz2), (Lx, 2 * R, 2 * R), (0.0, -R, -R), L.WEIGHT_RCYL, kappa=diffusivity, dt=dt,
+                                     num_steps=num_steps, steady=steady, source_type=source_type, source_value=source_value,
+                                     T_initial=T_initial, bc_mode=bc_mode, bc_value=bc_value, bc_present=bc_present,
+                                     core_radius=core_radius if composite else 0.0,
+                                     core_ratio=core_diffusivity / diffusivity if composite else 1.0, **opts)
+    x, y, z = _axes((nx, ny2, nz2), (0.0, -R, -R), (Lx, 2 * R, 2 * R))
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cylindrical", "Lx": Lx, "Ly": R * 2,
+            "Lz": R * 2, "geometry_type": "cylinder", "source_type": source_type, "source_value": source_value, "steady": steady,
+            "cylinder_radius": R}                                                   # :721-736
+    if directional:
+        for k, v in (("T_left", T_left), ("T_right", T_right), ("T_side", T_side)):
+            if v is not None:
+                meta[k] = v
+    else:
+        meta["T_boundary"] = T_boundary
+    if composite:
+        meta.update({"core_radius": core_radius, "core_diffusivity": core_diffusivity, "base_diffusivity": diffusivity})
+    else:
+        meta["diffusivity"] = diffusivity
+    meta.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"]),
+                 "mesh": "BoxMesh fallback (no mshr)"})
     return TimeSeriesField(coords=coords, values=values, times=times, dim=3, meta=meta)

@@ -158,12 +158,26 @@ def heat_2d_kwargs(p: Mapping) -> Dict[str, Any]:
 
 
 def heat_3d_kwargs(p: Mapping, geometry: str = "box") -> Dict[str, Any]:
-    """dispatcher_agent.py:537-773, box branch.  Cylinder kwargs (:574-596, 692-760) belong to the unstructured
-    mshr path, which is outside this build."""
-    if geometry == "cylinder":
-        raise NotImplementedError("3-D cylinder geometry (mshr mesh) is outside the structured-grid path")
+    """dispatcher_agent.py:537-773: box branch and the cylinder branch (:574-596 lengths, :692-760 radius, directional
+    boundary values, composite core)."""
     dom = p.get("domain_size") or {}
-    Lx, Ly, Lz = _box_lengths(dom, (_LX, _LY, _LZ))
+    gp = p.get("geometry_params") or {}
+    cyl_notation = ("r1" in dom or "r2" in dom) and "h" in dom
+    if "domain_size" in dom and isinstance(dom["domain_size"], (int, float)):
+        Lx = Ly = Lz = float(dom["domain_size"])
+    elif geometry == "cylinder":
+        if cyl_notation:
+            if dom.get("r2") is None:
+                raise ValueError("For cylindrical geometry, domain_size must contain 'r2' (outer radius)")
+            if dom.get("h") is None:
+                raise ValueError("For cylindrical geometry, domain_size must contain 'h' (height)")
+            Lx, Ly, Lz = float(dom["h"]), float(dom["r2"] * 2), float(dom["r2"] * 2)
+        else:
+            Lx = dom.get("Lx") or 2.0
+            r2 = _truthy(gp, ("cylinder_radius", "r2", "r_outer"), 0.5)
+            Ly = Lz = float(r2 * 2)
+    else:
+        Lx, Ly, Lz = _box_lengths(dom, (_LX, _LY, _LZ))
     kappa = p.get("diffusivity") or 1.0
     bc = p.get("bc_values") or {}
     out = {"Lx": Lx, "Ly": Ly, "Lz": Lz, "nx": p.get("nx") or 10, "ny": p.get("ny") or 10, "nz": p.get("nz") or 10,
@@ -171,7 +185,28 @@ def heat_3d_kwargs(p: Mapping, geometry: str = "box") -> Dict[str, Any]:
     dt, num_steps = _time_grid(p, (Lx + Ly + Lz) / 3, kappa)
     out["dt"], out["num_steps"] = dt or 0.01, num_steps or 200
     out.update(_common_heat_tail(p, 20.0))
-    out["geometry_type"] = "box"          # T_left/T_right/T_side are forwarded for cylinders only (:713-720)
+    if geometry != "cylinder":
+        out["geometry_type"] = "box"      # T_left/T_right/T_side are forwarded for cylinders only (:713-720)
+        return out
+    out["geometry_type"] = "cylinder"
+    r1 = r2 = None
+    if cyl_notation:
+        r1, r2 = dom.get("r1", 0.0), dom.get("r2")
+        out["Lx"] = float(dom["h"])
+        out["cylinder_radius"] = float(r2)
+    else:
+        out["cylinder_radius"] = r2 = _truthy(gp, ("cylinder_radius", "r_outer", "r2", "radius"), 0.5)
+    for key in ("left", "right", "side"):                          # :713-720: `bc.get("t_x") or bc.get("T_x")`
+        if f"t_{key}" in bc or f"T_{key}" in bc:
+            out[f"T_{key}"] = bc.get(f"t_{key}") or bc.get(f"T_{key}")
+    if p.get("core_diffusivity") is not None:                      # :722-754
+        if p.get("core_radius") is not None:
+            out["core_radius"] = float(p["core_radius"])
+        elif cyl_notation and r1 is not None:
+            out["core_radius"] = float(r1) if r1 > 0.0 else (float(r2) * 0.3 if r2 is not None else 0.1)
+        else:
+            out["core_radius"] = 0.1
+        out["core_diffusivity"] = float(p["core_diffusivity"])
     return out
 
 

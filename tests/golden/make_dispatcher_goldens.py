@@ -69,6 +69,10 @@ CASES = [
     dict(name="sph2d_defaults", params=dict(pde_type="heat", dim=2, geometry_type="sphere")),
     dict(name="sph3d_defaults", params=dict(pde_type="heat", dim=3, geometry_type="spherical")),
     dict(name="sph3d_full", params=dict(pde_type="heat", dim=3, domain_size={"r1": 0.1, "r2": 1.0}, geometry_params={"r_inner": 0.1, "sphere_radius": 1.5}, nx=8, ny=9, nz=10, bc_values={"t_boundary": 0.0}, initial_value=50.0, dt=0.005)),
+    dict(name="cyl3d_defaults", params=dict(pde_type="heat", dim=3, geometry_type="cylinder")),
+    dict(name="cyl3d_notation_core", params=dict(pde_type="heat", dim=3, geometry_type="tube", domain_size={"r1": 0.1, "r2": 0.4, "h": 1.5}, nx=12, ny=10, nz=10, bc_values={"t_left": 100.0, "T_right": 20.0, "t_side": 30.0}, core_diffusivity=25.0, initial_value=20.0)),
+    dict(name="cyl3d_solid_core_default", params=dict(pde_type="heat", dim=3, geometry_type="cylinder", domain_size={"r2": 0.5, "h": 2.0}, core_diffusivity=10.0, bc_values={"T_boundary": 5.0})),
+    dict(name="cyl3d_geom_params", params=dict(pde_type="heat", dim=3, geometry_type="pipe", domain_size={"Lx": 3.0}, geometry_params={"radius": 0.25}, core_radius=0.1, core_diffusivity=4.0)),
     dict(name="elast1d_defaults", params=dict(pde_type="elasticity", dim=1)),
     dict(name="elast1d_full", params=dict(pde_type="elasticity", dim=1, domain_size={"length": 2.0}, nx=80, young_modulus=70e9, material_params={"area": 0.01, "body_force": 1000.0, "quantity": "strain"})),
     dict(name="elast2d_defaults", params=dict(pde_type="elasticity", dim=2)),
@@ -116,7 +120,7 @@ for case in CASES:
             kw = getattr(agent, builder)(p)
         else:
             fn = getattr(agent, BUILDERS[(p.pde_type, p.dim)])
-            kw = fn(p, "box") if p.pde_type == "heat" else fn(p)
+            kw = fn(p, geom if (p.dim == 3 and geom == "cylinder") else "box") if p.pde_type == "heat" else fn(p)
             tool = f"solve_heat_{p.dim}D" if p.pde_type == "heat" else f"solve_elasticity_{p.dim}D_static"
     out.append({"name": case["name"], "params": case["params"], "tool": tool, "kwargs": kw})
 

@@ -33,8 +33,7 @@ def test_route_accepts_the_reference_dataclass_shape_and_rejects_other_pdes():
         params.route({"pde_type": "wave", "dim": 1})
     with pytest.raises(ValueError):
         params.route({"pde_type": "heat", "dim": 4})
-    with pytest.raises(NotImplementedError):
-        params.route({"pde_type": "heat", "dim": 3, "geometry_type": "pipe"})          # mshr cylinder mesh
+    assert params.route({"pde_type": "heat", "dim": 3, "geometry_type": "pipe"})[1]["geometry_type"] == "cylinder"
     assert params.geometry_of({"domain_size": {"r2": 1.0, "h": 2.0}}) == "cylinder"
     assert params.geometry_of({"coordinate_system": "spherical"}) == "sphere"
     assert params.geometry_of({"geometry_type": "Cube"}) == "box"

@@ -78,3 +78,38 @@ def test_curvilinear_tools_through_the_params_boundary(lib, gpu_ctx, tmp_path):
         f = pickle.load(open(out["data_file"], "rb"))
         assert f.values.shape[0] == 3 and np.isfinite(f.values).all()
         assert f.meta["coordinate_system"] in ("cylindrical", "spherical")
+
+
+@pytest.mark.parametrize("case", [
+    dict(),                                                                      # uniform T_boundary on the whole box boundary
+    dict(T_left=100.0, T_right=20.0, T_side=55.0),                               # directional; T_side matches no facet on the fallback mesh
+    dict(T_left=100.0),                                                          # everything else natural
+    dict(core_radius=0.3, core_diffusivity=40.0),                                # composite core, DG0 diffusivity
+    dict(core_radius=0.3, core_diffusivity=40.0, T_left=80.0, T_right=10.0, steady=True, source_type="constant", source_value=5.0),
+])
+def test_3d_cylinder_boxmesh_fallback(lib, gpu_ctx, case):
+    """solve_heat_3D(geometry_type="cylinder") as the reference runs it without mshr (:523-529, :645, :537-604)"""
+    from pdegpu import heat
+    kw = dict(Lx=1.0, nx=7, ny=8, nz=6, diffusivity=1.0, T_boundary=20.0, T_initial=60.0, dt=0.01, num_steps=3,
+              cylinder_radius=0.5)
+    kw.update(case)
+    ref = o.solve_heat_3d_cylinder_fallback(**kw)
+    got = heat._solve_heat_3d_raw(Ly=1.0, Lz=1.0, geometry_type="cylinder", rtol=1e-12, **kw)
+    _check(got, ref)
+
+
+def test_cylinder_through_the_tool_and_params(lib, gpu_ctx, tmp_path):
+    import pickle
+    from pdegpu import server
+    out = server.solve({"pde_type": "heat", "dim": 3, "geometry_type": "tube", "domain_size": {"r1": 0.1, "r2": 0.4, "h": 1.5},
+                        "nx": 6, "ny": 10, "nz": 10, "bc_values": {"t_left": 100.0, "T_right": 20.0}, "core_diffusivity": 25.0,
+                        "initial_value": 20.0, "num_steps": 2, "dt": 0.01}, data_dir=str(tmp_path))
+    assert "error" not in out, out
+    f = pickle.load(open(out["data_file"], "rb"))
+    assert out["solver"] == "solve_heat_3D" and f.meta["geometry_type"] == "cylinder" and f.meta["core_radius"] == 0.1
+    assert f.values.shape == (3, 7 * 9 * 9) and np.isfinite(f.values).all()
+    kw = dict(out["solver_args"])
+    ref = o.solve_heat_3d_cylinder_fallback(kw["Lx"], kw["nx"], kw["ny"], kw["nz"], kw["diffusivity"], kw["T_boundary"], kw["T_initial"],
+                                            kw["dt"], kw["num_steps"], kw["cylinder_radius"], T_left=kw["T_left"], T_right=kw["T_right"],
+                                            core_radius=kw["core_radius"], core_diffusivity=kw["core_diffusivity"])
+    assert rel_err(f.values, ref.values) < TOL

@@ -199,8 +199,8 @@ def test_trivial_and_edge_cases(lib, gpu_ctx):
         heat._solve_heat_3d_raw(1, 1, 1, 0, 4, 4, 1.0, 0.0, 20.0, 0.01, 1)
     with pytest.raises(_lib.PdeGpuError):
         heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, -1.0, 0.0, 20.0, 0.01, 1)
-    with pytest.raises(NotImplementedError):
-        heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 1, geometry_type="cylinder", cylinder_radius=0.5)
+    with pytest.raises(NotImplementedError):                       # composite core on the plain box branch is not restated
+        heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 1, core_radius=0.2, core_diffusivity=5.0)
 
 
 def test_q1_mode_differs_by_h2(lib, gpu_ctx):

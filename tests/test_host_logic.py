@@ -212,7 +212,8 @@ def test_loader_binds_one_hip_runtime(lib):
 @pytest.mark.parametrize("dim,n,Ls,origin,kind", [
     (1, (6,), (1.5,), (0.5, 0, 0), "r"), (1, (5,), (2.0,), (0.0, 0, 0), "r2"),
     (2, (4, 3), (1.0, 2.0), (0.25, 0, 0), "r"), (2, (3, 4), (0.8, np.pi), (0.2, 0, 0), "r2sin"),
-    (3, (3, 2, 3), (0.8, np.pi, 2 * np.pi), (0.2, 0, 0), "r2sin"), (3, (2, 2, 2), (1.0, 1.0, 1.0), (0.0, 0, 0), "r2")])
+    (3, (3, 2, 3), (0.8, np.pi, 2 * np.pi), (0.2, 0, 0), "r2sin"), (3, (2, 2, 2), (1.0, 1.0, 1.0), (0.0, 0, 0), "r2"),
+    (3, (2, 4, 3), (1.0, 1.0, 1.0), (0.0, -0.5, -0.5), "rcyl")])
 def test_weighted_rows_match_oracle_assembly(lib, dim, n, Ls, origin, kind):
     """per-node coupling weights of the curvilinear forms (host twin of k_weighted_assemble, same source) ==
     the oracle's weighted matrices, every node (boundary truncation included)"""
@@ -221,8 +222,11 @@ def test_weighted_rows_match_oracle_assembly(lib, dim, n, Ls, origin, kind):
     N = int(lib.pdegpu_grid_num_nodes(g))
     rK, rM, ld = np.zeros((N, 15)), np.zeros((N, 15)), np.zeros(N)
     org = np.array(origin, dtype=float)
-    code = {"r": _lib.WEIGHT_R, "r2": _lib.WEIGHT_R2, "r2sin": _lib.WEIGHT_R2SIN}[kind]
-    assert lib.pdegpu_weighted_rows_host(g, _lib.dptr(org), code, _lib.dptr(rK), _lib.dptr(rM), _lib.dptr(ld)) == 0
+    w = _lib.Weight()
+    w.kind = {"r": _lib.WEIGHT_R, "r2": _lib.WEIGHT_R2, "r2sin": _lib.WEIGHT_R2SIN, "rcyl": _lib.WEIGHT_RCYL}[kind]
+    for r in range(3):
+        w.origin[r] = org[r]
+    assert lib.pdegpu_weighted_rows_host(g, w, _lib.dptr(rK), _lib.dptr(rM), _lib.dptr(ld)) == 0
     if dim == 1:
         c, cells = o.interval_mesh(n[0], origin[0], origin[0] + Ls[0])
     elif dim == 2:
@@ -248,3 +252,24 @@ def test_weighted_rows_match_oracle_assembly(lib, dim, n, Ls, origin, kind):
                 assert rK[row, q] == 0.0 and rM[row, q] == 0.0
     assert np.abs(Kd - K).max() < 1e-12 * np.abs(K).max()
     assert np.abs(Md - M).max() < 1e-12 * np.abs(M).max()
+
+
+def test_weighted_rows_with_composite_core_match_oracle(lib):
+    """per-simplex core diffusivity (DG0, all vertices + midpoint inside the core radius) in the shared row math"""
+    from pdegpu import _lib
+    n, R, rc, ratio = (3, 6, 6), 0.5, 0.3, 40.0
+    g = _lib.make_grid(3, n, (1.0, 2 * R, 2 * R))
+    N = int(lib.pdegpu_grid_num_nodes(g))
+    w = _lib.Weight()
+    w.kind, w.core_radius, w.core_ratio = _lib.WEIGHT_RCYL, rc, ratio
+    w.origin[1] = w.origin[2] = -R
+    rK, rM, ld = np.zeros((N, 15)), np.zeros((N, 15)), np.zeros(N)
+    assert lib.pdegpu_weighted_rows_host(g, w, _lib.dptr(rK), _lib.dptr(rM), _lib.dptr(ld)) == 0
+    c, cells = o.box_mesh(1.0, 2 * R, 2 * R, *n)
+    c = c + np.array([0.0, -R, -R])
+    P = c[cells]
+    core = (np.sqrt(P[:, :, 1] ** 2 + P[:, :, 2] ** 2) < rc).all(axis=1) & (np.hypot(*P.mean(axis=1)[:, 1:].T) < rc)
+    assert core.any() and not core.all()
+    K, M, load = o.assemble_weighted(c, cells, "rcyl", np.where(core, ratio, 1.0))
+    assert np.allclose(rK[:, 0], K.diagonal(), rtol=1e-12) and np.allclose(rM[:, 0], M.diagonal(), rtol=1e-12)
+    assert np.allclose(rK.sum(axis=1), 0.0, atol=1e-12 * np.abs(rK).max())

@@ -74,3 +74,33 @@ def test_transient_weighted_conserves_constants_and_decays():
     assert m[0] == 20.0 and np.all(np.diff(m) < 0) and g.values.min() > -1e-9
     h = o.solve_heat_2d_spherical(0.2, 1.0, 5, 6, 1.0, 1.0, 20.0, 0.01, 2)
     assert h.values.shape == (3, 42) and np.allclose(h.coords[:, 1], 0.0)
+
+
+def test_cylinder_fallback_restatement():
+    # the weight integrates sqrt(y^2+z^2) over the box: converges to the exact value of int int r dy dz on [-R,R]^2
+    R = 0.5
+    vals = []
+    for n in (4, 8, 16):
+        c, cells = o.box_mesh(1.0, 2 * R, 2 * R, 2, n, n)
+        c = c + np.array([0.0, -R, -R])
+        _, _, load = o.assemble_weighted(c, cells, "rcyl")
+        vals.append(load.sum())
+    a = 2 * R
+    exact = a ** 3 / 6 * (math.sqrt(2) + math.log(1 + math.sqrt(2)))            # int over a square of side a centred at 0 of r
+    errs = [abs(v - exact) for v in vals]
+    assert errs[2] < 1e-3 * exact and errs[0] > errs[1] > errs[2]
+    # composite core: the per-cell factor only touches cells entirely inside the core
+    f = o.solve_heat_3d_cylinder_fallback(1.0, 6, 8, 8, 1.0, 20.0, 100.0, 0.01, 2, cylinder_radius=0.5, core_radius=0.3,
+                                          core_diffusivity=50.0)
+    g = o.solve_heat_3d_cylinder_fallback(1.0, 6, 8, 8, 1.0, 20.0, 100.0, 0.01, 2, cylinder_radius=0.5)
+    assert f.values.shape == g.values.shape == (3, 7 * 9 * 9) and np.abs(f.values[-1] - g.values[-1]).max() > 1e-3
+    assert f.meta["base_diffusivity"] == 1.0 and "diffusivity" not in f.meta and g.meta["diffusivity"] == 1.0
+    assert g.meta["Ly"] == 1.0 and g.meta["coordinate_system"] == "cylindrical" and g.coords[:, 1].min() == -0.5
+    # directional: T_side constrains nothing on the box fallback; left/right faces are set, the rest is natural
+    h = o.solve_heat_3d_cylinder_fallback(1.0, 4, 4, 4, 1.0, 0.0, 5.0, 0.01, 1, cylinder_radius=0.5, T_left=50.0, T_side=99.0)
+    x = h.coords[:, 0]
+    assert np.all(h.values[:, x == 0.0] == 50.0) and not np.any(h.values == 99.0)
+    assert "T_side" in h.meta and "T_boundary" not in h.meta
+    # u == T_b fixed point
+    k = o.solve_heat_3d_cylinder_fallback(2.0, 3, 4, 4, 1.0, 7.0, 7.0, 0.01, 2, cylinder_radius=0.5)
+    assert np.abs(k.values - 7.0).max() < 1e-12
