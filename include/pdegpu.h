@@ -122,7 +122,8 @@ const char* pdegpu_version(void);
  * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_wg_per_cu" (0 = occupancy API),
  * "k2_variant" (0..5), "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
  * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF), "use_graph"
- * (1 = replay the CG inner loop from a captured hipGraph).  Results do not depend on them. */
+ * (1 = replay the CG inner loop from a captured hipGraph), "inlaunch_dot" (1 = finish dot products inside the producing
+ * launch instead of a separate one-workgroup reduce launch; measured slower).  Results do not depend on them. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 
 /* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw

@@ -23,6 +23,8 @@ struct pdegpu_ctx {
     int k2_variant = 0;         // 0: grid-stride double2; 1: 4x unrolled; 2: 4x unrolled + non-temporal
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
+    int inlaunch_dot = 0;       // opt-in: finish dot products inside the producing launch (dot_finish.h).  Measured slower:
+                                // the per-workgroup agent-scope release writes back the XCD's dirty L2 in streaming kernels
     int use_graph = 0;          // opt-in: replay the CG inner loop from a captured hipGraph.  Measured: no gain (the small
                                 // configs are bound by kernel time, not launches) and rocprofv3 7.2 crashes on graph launches
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
@@ -62,6 +64,7 @@ struct GridDev {
     int bc_mode;           // PDEGPU_BC_*
     int bc_present[3];
     double bc_value[3];
+    int flat2d;            // fast-kernel view of a 2-D grid: (x, y) -> (x, z) with ONE row in the middle axis, no y-boundary
 };
 
 static constexpr int kGuard = 64;   // extra doubles (beyond one row) before/after the ghost planes
@@ -142,10 +145,12 @@ struct StencilArgs {
     const double* p_old;      // CG_K1
     double* p_new;            // CG_K1
     double* x;                // CG_K1 (updated in place)
-    const double* scal;       // CG_K1: device scalars (see Scal* below)
+    double* scal;             // device scalars (SC_*): read by K1 / K2, updated by dot_finish
     double* partials;         // per-workgroup partial dot products
     int mask_dirichlet;       // 1: Dirichlet rows give 0 (P applied to the output)
     int npt;                  // 7 or 15 (fast path)
+    unsigned* counter;        // dot_finish ticket counter (device word)
+    int dot_which;            // 0: p.q, 1: r.r (the kernel completes the dot product itself), -1: partials only
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
 };
@@ -180,6 +185,7 @@ inline long long tunable_key(const pdegpu_ctx* c) {
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 bool stencil_fast_supported(const GridDev& g, int element_mode);
+GridDev stencil_flat2d_view(const GridDev& g);
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 int stencil_max_partials(pdegpu_ctx* ctx);
 
@@ -190,14 +196,15 @@ int vec_zero(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
 // array of the slab) elsewhere
 int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const double* nodal_dense, int only_bc);
 int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal);
-int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const double* scal, double* partials, LaunchInfo* li);
+int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, unsigned* counter,
+           LaunchInfo* li);
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
 // weighted.hip
 int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, double cM, double cK,
                       double* ellA, double* ellM, double* dinv, long long stride);
-int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, const double* scal,
-              double* partials, int use_alpha, LaunchInfo* li);
+int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
+              double* partials, unsigned* counter, int use_alpha, LaunchInfo* li);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense

@@ -19,6 +19,7 @@ struct pdegpu_session {
     pdegpu_grid grid{};
     pdegpu_heat heat{};
     GridDev g{};
+    GridDev gk{};                  // the grid as the fused kernels see it (= g in 3-D; flat view of a 2-D grid)
     HeatTables tabs{};
     double cM = 0, cK = 0;
     bool fast = false;
@@ -28,6 +29,7 @@ struct pdegpu_session {
     int pcur = 0;
     double* d_scal = nullptr;
     double* d_part = nullptr;
+    unsigned* d_counter = nullptr;  // dot_finish ticket counter
     double* d_dense = nullptr;
     double* h_pin = nullptr;       // pinned host scalars
     std::vector<hipEvent_t> events;
@@ -111,10 +113,14 @@ GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t 
 
 namespace {
 
-void fast_weights(const double* tab, double* w) {
+void fast_weights(const double* tab, double* w, bool flat2d = false) {
     const double* c = tab + 13 * 27;   // interior class
     w[0] = c[13]; w[1] = c[14]; w[2] = c[16]; w[3] = c[22];
     w[4] = c[17]; w[5] = c[23]; w[6] = c[25]; w[7] = c[26];
+    if (flat2d) {                      // (x, y) -> (x, z): y-coupling moves to the z slot, the xy-diagonal to the xz slot
+        w[3] = w[2]; w[5] = w[4];
+        w[2] = w[4] = w[6] = w[7] = 0.0;
+    }
 }
 
 bool is_seven_point(const double* w) {
@@ -130,6 +136,9 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     a.in_shift = shift;
     a.out = out;
     a.partials = s->d_part;
+    a.counter = s->d_counter;
+    a.scal = s->d_scal;
+    a.dot_which = -1;
     a.mask_dirichlet = mask;
     const double* htab = which == 0 ? s->hA : s->tabs.h_tabM;
     a.tabA = which == 0 ? s->tabs.d_tabA : s->tabs.d_tabM;
@@ -138,7 +147,8 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
         a.ell_stride = s->ell_stride;
     }
     if (s->fast) {
-        fast_weights(htab, a.w);
+        a.g = s->gk;
+        fast_weights(htab, a.w, s->gk.flat2d != 0);
         a.npt = is_seven_point(a.w) ? 7 : 15;
         return stencil_fast(s->ctx, a, APPLY_PLAIN, nullptr);
     }
@@ -153,6 +163,9 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     a.rhs = rhs;
     a.out = out;
     a.partials = s->d_part;
+    a.counter = s->d_counter;
+    a.scal = s->d_scal;
+    a.dot_which = (s->weighted || !s->ctx->inlaunch_dot) ? -1 : 1;   // PCG forms rho = r.z in the follow-up k_k2_pc pass
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     if (s->weighted) {
@@ -160,7 +173,8 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
         a.ell_stride = s->ell_stride;
     }
     if (s->fast) {
-        fast_weights(s->hA, a.w);
+        a.g = s->gk;
+        fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
         return stencil_fast(s->ctx, a, APPLY_RESIDUAL, li);
     }
@@ -185,11 +199,14 @@ int op_k1(pdegpu_session* s, LaunchInfo* li) {
     a.out = k2_is_stencil(s) ? nullptr : s->q.v;     // 64-B variant: q is recomputed by K2
     a.scal = s->d_scal;
     a.partials = s->d_part;
+    a.counter = s->d_counter;
+    a.dot_which = s->ctx->inlaunch_dot ? 0 : -1;
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     int rc;
     if (s->fast) {
-        fast_weights(s->hA, a.w);
+        a.g = s->gk;
+        fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
         rc = stencil_fast(s->ctx, a, APPLY_CG_K1, li);
     } else {
@@ -209,19 +226,33 @@ int op_k2(pdegpu_session* s, LaunchInfo* li) {
         a.out = s->r.v;
         a.scal = s->d_scal;
         a.partials = s->d_part;
+        a.counter = s->d_counter;
+        a.dot_which = s->ctx->inlaunch_dot ? 1 : -1;
         a.mask_dirichlet = 1;
-        fast_weights(s->hA, a.w);
+        a.g = s->gk;
+        fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
         return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
     }
-    if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 1, li);
-    return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, li);
+    unsigned* cnt = s->ctx->inlaunch_dot ? s->d_counter : nullptr;      // nullptr: partials only, reduced by k_reduce
+    if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, cnt, 1, li);
+    return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, cnt, li);
 }
 
 // after a RESIDUAL pass: PCG needs z = D^-1 r and rho = r.z in place of r.r
+// completes the dot product of the launch described by li: by default a one-workgroup fixed-order reduce launch
+// (k_reduce); with the inlaunch_dot tunable the producing kernel has already done it (dot_finish.h) unless its grid
+// was empty (a slab without free planes), in which case the sum 0 still has to be recorded
+int empty_dot(pdegpu_session* s, const LaunchInfo& li, int which) {
+    if (s->ctx->inlaunch_dot && li.grid > 0) return PDEGPU_OK;
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, which, 1);
+}
 int residual_finish(pdegpu_session* s, LaunchInfo* li) {
-    if (s->weighted) PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 0, li));
-    return vec_reduce(s->ctx, s->d_part, li->grid, s->d_scal, 1, 1);
+    if (s->weighted) {
+        unsigned* cnt = s->ctx->inlaunch_dot ? s->d_counter : nullptr;
+        PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, cnt, 0, li));
+    }
+    return empty_dot(s, *li, 1);
 }
 
 // x (including the ghost planes that lie inside the global domain) = Dirichlet values / fill / nodal
@@ -262,7 +293,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -281,6 +312,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "k2_grid_mult")) return &ctx->k2_grid_mult;
     if (!strcmp(key, "cg_variant")) return &ctx->cg_variant;
     if (!strcmp(key, "use_graph")) return &ctx->use_graph;
+    if (!strcmp(key, "inlaunch_dot")) return &ctx->inlaunch_dot;
     if (!strcmp(key, "el_grid_mult")) return &ctx->el_grid_mult;
     return nullptr;
 }
@@ -321,6 +353,7 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     tables_free(&s->tabs);
     if (s->d_scal) (void)hipFree(s->d_scal);
     if (s->d_part) (void)hipFree(s->d_part);
+    if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_dense) (void)hipFree(s->d_dense);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
@@ -357,9 +390,10 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     int rc = tables_build(ctx, grid, &s->tabs);
     if (rc == PDEGPU_OK) rc = tables_combine(ctx, &s->tabs, s->cM, s->cK, s->tabs.d_tabA, s->hA);
     s->fast = heat->fast_path != 0 && stencil_fast_supported(s->g, grid->element_mode);
+    s->gk = (s->fast && s->g.dim == 2) ? stencil_flat2d_view(s->g) : s->g;
     if (s->fast) {
         double w[8];
-        fast_weights(s->hA, w);
+        fast_weights(s->hA, w, s->gk.flat2d != 0);
         s->npt = is_seven_point(w) ? 7 : 15;
     }
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
@@ -368,6 +402,8 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     const int npart = stencil_max_partials(ctx);
     if (rc == PDEGPU_OK && hipMalloc(&s->d_scal, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc scal");
     if (rc == PDEGPU_OK && hipMalloc(&s->d_part, npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
+    if (rc == PDEGPU_OK && (hipMalloc(&s->d_counter, 64) != hipSuccess || hipMemsetAsync(s->d_counter, 0, 64, ctx->stream) != hipSuccess))
+        rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc counter");
     if (rc == PDEGPU_OK && hipHostMalloc(&s->h_pin, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipHostMalloc");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset scal");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_part, 0, npart * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset partials");
@@ -415,7 +451,7 @@ extern "C" int pdegpu_session_residual(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     PG_TRY(op_residual(s, s->x.v, s->b.v, s->r.v, &li));
-    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 1);
+    return residual_finish(s, &li);
 }
 
 extern "C" int pdegpu_session_k1(pdegpu_session* s) {
@@ -423,7 +459,7 @@ extern "C" int pdegpu_session_k1(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     PG_TRY(op_k1(s, &li));
-    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 0, 1);
+    return empty_dot(s, li, 0);
 }
 
 extern "C" int pdegpu_session_k2(pdegpu_session* s) {
@@ -431,7 +467,7 @@ extern "C" int pdegpu_session_k2(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     PG_TRY(op_k2(s, &li));
-    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 1, 1);
+    return empty_dot(s, li, 1);
 }
 
 // k1 / k2 / residual already leave this slab's sum in BOTH the local and the global slot (the multi-GPU host then
@@ -458,9 +494,9 @@ constexpr int kGraphIters = 8;     // iterations per captured graph (even)
 
 int cg_one_iteration(pdegpu_session* s, LaunchInfo* l1, LaunchInfo* l2) {
     PG_TRY(op_k1(s, l1));
-    PG_TRY(vec_reduce(s->ctx, s->d_part, l1->grid, s->d_scal, 0, 1));
+    PG_TRY(empty_dot(s, *l1, 0));
     PG_TRY(op_k2(s, l2));
-    return vec_reduce(s->ctx, s->d_part, l2->grid, s->d_scal, 1, 1);
+    return empty_dot(s, *l2, 1);
 }
 
 // capture kGraphIters iterations on the context stream (nothing executes; host-side pcur ends where it started)
@@ -520,11 +556,11 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 0], ctx->stream));
         PG_TRY(op_k1(s, &l1));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 1], ctx->stream));
-        PG_TRY(vec_reduce(ctx, s->d_part, l1.grid, s->d_scal, 0, 1));
+        PG_TRY(empty_dot(s, l1, 0));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 2], ctx->stream));
         PG_TRY(op_k2(s, &l2));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
-        PG_TRY(vec_reduce(ctx, s->d_part, l2.grid, s->d_scal, 1, 1));
+        PG_TRY(empty_dot(s, l2, 1));
         ++s->eager_iters;
     }
     if (stats) {
@@ -939,7 +975,7 @@ extern "C" int pdegpu_heat_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, doubl
     PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));
     if (fast_path && !s->fast) {
         pdegpu_session_destroy(s);
-        return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "fast path needs a 3-D P1 grid with >= 2 cells per axis");
+        return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "fast path needs a 2-D or 3-D P1 grid with >= 2 cells per axis");
     }
     s->cM = cM;
     s->cK = cK;

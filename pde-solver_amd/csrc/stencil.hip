@@ -23,6 +23,7 @@
 // (24 B/DoF) -> 64 B/DoF per iteration.  K1 also stores p_n on the slab's ghost planes (it has r_n and p_{n-1}
 // there), so in the multi-GPU loop only r needs a halo exchange.
 #include "common.h"
+#include "dot_finish.h"
 #include <cstdlib>
 
 namespace {
@@ -43,7 +44,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);   // fixed order: bitwise reproducible
 }
 
-__device__ __forceinline__ void cg_scalars(const double* __restrict__ scal, double* alpha_prev, double* beta) {
+__device__ __forceinline__ void cg_scalars(const double* scal, double* alpha_prev, double* beta) {
     // alpha_{n-1} = rr_{n-1} / (p_{n-1}.q_{n-1}),  beta_{n-1} = rr_n / rr_{n-1};  both 0 on the first iteration
     const double pq = scal[SC_PQ], rr = scal[SC_RR], rr_prev = scal[SC_RR_PREV];
     *alpha_prev = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
         }
     }
     const double tot = block_sum_256(acc, sRed);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    __syncthreads();
+    dot_finish(tot, DotSink{a.partials, a.counter, a.scal, a.dot_which}, sRed);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -145,6 +147,7 @@ struct FastGeom {
     int nxg, nyg, nzc;     // workgroup counts along x, y; z-chunks
     int lkb, lke;          // local interior plane range [lkb, lke)
     int zlen;              // planes per z-chunk
+    int jbase, jmax;       // first / last free row of the middle axis (1 .. NY-2; 0 .. 0 for the flat 2-D view)
 };
 
 // lane l receives the value of lane l-1 (lane 0 receives 0): v_mov_b32_dpp wave_shr:1
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     const int xg = wid % fg.nxg, yg = (wid / fg.nxg) % fg.nyg, zc = wid / (fg.nxg * fg.nyg);
     const int xt = xg * fg.wxt + (wv % fg.wxt), yt = yg * fg.wyt + (wv / fg.wxt);
     const int i0 = xt * 128 + 2 * lane;
-    const int j0 = 1 + yt * RY;
+    const int j0 = fg.jbase + yt * RY;
     const int lk0 = fg.lkb + zc * fg.zlen;
     const int lk1 = min(lk0 + fg.zlen, fg.lke);
     const bool active = (xt < fg.ntx) && (yt < fg.nty) && (lk0 < lk1);
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         // K1: x += alpha p_{n-1}, store p_n for an owned row-plane
         auto own_update = [&](int lk, int j, const double2& pn, const double2& po) {
             if (K1) {
-                if (j <= g.NY - 2 && lane_ok) {
+                if (j <= fg.jmax && lane_ok) {
                     const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
                     store_pair<NT>(a.p_new + off, pn);
                     if (alpha_prev != 0.0) {
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
 #pragma unroll
                 for (int r = 1; r <= RY; ++r) {
                     const int j = j0 - 1 + r;
-                    if (j <= g.NY - 2 && lane_ok)
+                    if (j <= fg.jmax && lane_ok)
                         *reinterpret_cast<double2*>(a.p_new + (long long)lk * g.PP + (long long)j * g.PX + i0) = rows[r];
                 }
             }
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 for (int r = 0; r < RY; ++r) {
                     const int j = j0 + r;
                     RHS[r] = make_double2(a.rhs_const, a.rhs_const);
-                    if (a.rhs && j <= g.NY - 2 && lane_ok)
+                    if (a.rhs && j <= fg.jmax && lane_ok)
                         RHS[r] = load_pair(a.rhs, (long long)lk * g.PP + (long long)j * g.PX + i0);
                 }
             }
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             for (int r = 0; r < RY; ++r) {
                 const int c = r + 1;
                 const int j = j0 + r;
-                if (j <= g.NY - 2) {                                  // wave-uniform
+                if (j <= fg.jmax) {                                   // wave-uniform
                     double lC = dpp_from_lower(C[c].y), rC = dpp_from_upper(C[c].x);
                     lC = (lane == 0) ? EC[c] : lC;
                     rC = (lane == 63) ? EC[c] : rC;
@@ -387,13 +390,16 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         if (K1 && lk1 == fg.lke && lk1 == g.nkl && g.k0 + g.nkl < g.NZ) ghost_store(lk1, C);
     }
     const double tot = block_sum_256(acc, sRed);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    __syncthreads();
+    dot_finish(tot, DotSink{a.partials, a.counter, a.scal, a.dot_which}, sRed);
 }
 
 FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
     FastGeom fg{};
     fg.ntx = (g.NX - 1 + 127) / 128;
-    fg.nty = (g.NY - 2 + RY - 1) / RY;
+    fg.jbase = g.flat2d ? 0 : 1;
+    fg.jmax = g.flat2d ? 0 : g.NY - 2;
+    fg.nty = (fg.jmax - fg.jbase + 1 + RY - 1) / RY;
     fg.wxt = fg.ntx >= 4 ? 4 : (fg.ntx >= 2 ? 2 : 1);
     fg.wyt = 4 / fg.wxt;
     fg.nxg = (fg.ntx + fg.wxt - 1) / fg.wxt;
@@ -485,10 +491,28 @@ int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo*
     return PDEGPU_OK;
 }
 
-// fast path: 3-D, P1 split, every boundary node Dirichlet (uniform mode), at least one interior node per axis
+// fast path: 3-D (or 2-D through the flat view), P1 split, every boundary node Dirichlet (uniform mode), at least one
+// interior node per axis
 bool stencil_fast_supported(const GridDev& g, int element_mode) {
-    return g.dim == 3 && element_mode == PDEGPU_ELEM_P1SPLIT && g.bc_mode == PDEGPU_BC_UNIFORM && g.bc_present[0] &&
-           g.NX >= 3 && g.NY >= 3 && g.NZ >= 3;
+    if (element_mode != PDEGPU_ELEM_P1SPLIT || g.bc_mode != PDEGPU_BC_UNIFORM || !g.bc_present[0]) return false;
+    if (g.dim == 3) return g.NX >= 3 && g.NY >= 3 && g.NZ >= 3;
+    if (g.dim == 2) return g.NX >= 3 && g.NY >= 3;
+    return false;
+}
+
+// The 2-D P1 operator (5-point stiffness, 7-point mass with the +-(1,1) diagonal of the "right" triangle split) is the
+// 3-D 15-point kernel restricted to ONE row of the middle axis: (x, y) -> (x, z), weights w0, wx, wz = w_y2d,
+// wxz = w_xy2d.  Memory is unchanged: a 2-D row is one "plane" of pitch PX.
+GridDev stencil_flat2d_view(const GridDev& g) {
+    GridDev v = g;
+    v.dim = 3;
+    v.NZ = g.NY;
+    v.NY = 1;
+    v.PP = g.PX;
+    v.nkl = g.NY;
+    v.k0 = 0;
+    v.flat2d = 1;
+    return v;
 }
 
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {

@@ -5,6 +5,7 @@
 // per lane -> __shfl_down across the 64-lane wavefront -> LDS across waves -> one partial per workgroup,
 // summed in fixed order by k_reduce (bitwise reproducible, no atomics, alpha/beta never leave the device).
 #include "common.h"
+#include "dot_finish.h"
 #include <cstdarg>
 
 int pdegpu_set_err(pdegpu_ctx* ctx, int code, const char* fmt, ...) {
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_set_bc(GridDev g, double* __restrict__ 
 
 // r -= alpha q, partial r.r      (n2 = number of double2 elements)
 __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
-                                             const double* __restrict__ scal, double* __restrict__ partials) {
+                                             double* scal, double* __restrict__ partials, unsigned* counter) {
     __shared__ double sRed[4];
     const double pq = scal[SC_PQ], rr = scal[SC_RR];
     const double alpha = (pq > 0.0) ? rr / pq : 0.0;
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const doubl
         acc += rv.x * rv.x + rv.y * rv.y;
     }
     const double tot = block_sum_256(acc, sRed);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    __syncthreads();
+    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
 }
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -70,7 +72,7 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 // U independent 16-B streams per lane per trip (2U loads in flight), optionally non-temporal
 template <int NT, int U>
 __global__ __launch_bounds__(256) void k_k2_u4(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
-                                                const double* __restrict__ scal, double* __restrict__ partials) {
+                                                double* scal, double* __restrict__ partials, unsigned* counter) {
     __shared__ double sRed[4];
     const double pq = scal[SC_PQ], rr = scal[SC_RR];
     const double alpha = (pq > 0.0) ? rr / pq : 0.0;
@@ -104,12 +106,13 @@ __global__ __launch_bounds__(256) void k_k2_u4(double2* __restrict__ r, const do
         acc += rv.x * rv.x + rv.y * rv.y;
     }
     const double tot = block_sum_256(acc, sRed);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    __syncthreads();
+    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
 }
 
 // contiguous chunk per workgroup instead of a grid-stride interleave
 __global__ __launch_bounds__(256) void k_k2_chunk(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
-                                                   const double* __restrict__ scal, double* __restrict__ partials) {
+                                                   double* scal, double* __restrict__ partials, unsigned* counter) {
     __shared__ double sRed[4];
     const double pq = scal[SC_PQ], rr = scal[SC_RR];
     const double alpha = (pq > 0.0) ? rr / pq : 0.0;
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(256) void k_k2_chunk(double2* __restrict__ r, const
         acc += rv.x * rv.x + rv.y * rv.y;
     }
     const double tot = block_sum_256(acc, sRed);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    __syncthreads();
+    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
 }
 
 // in-run memory calibration (bench.py): 0 copy b=q, 1 read-only sum(r), 2 write-only b=c, 3 triad b=r+c*q,
@@ -236,7 +240,8 @@ int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const 
     return PDEGPU_OK;
 }
 
-int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const double* scal, double* partials, LaunchInfo* li) {
+int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, unsigned* counter,
+           LaunchInfo* li) {
     const long long n2 = (long long)g.nkl * g.PP / 2;
     long long nbl = (n2 + 255) / 256;
     if (nbl > (long long)ctx->k2_grid_mult * ctx->num_cu) nbl = (long long)ctx->k2_grid_mult * ctx->num_cu;
@@ -244,22 +249,22 @@ int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, const 
     if (li) { li->grid = nb; li->block = 256; }
     if (ctx->k2_variant == 4)
         hipLaunchKernelGGL((k_k2_u4<0, 8>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
     else if (ctx->k2_variant == 5)
         hipLaunchKernelGGL((k_k2_u4<1, 8>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
     else if (ctx->k2_variant == 1)
         hipLaunchKernelGGL((k_k2_u4<0, 4>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
     else if (ctx->k2_variant == 3)
         hipLaunchKernelGGL(k_k2_chunk, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
     else if (ctx->k2_variant == 2)
         hipLaunchKernelGGL((k_k2_u4<1, 4>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
     else
         hipLaunchKernelGGL(k_k2, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials);
+                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

@@ -9,6 +9,7 @@
 // from that array (k_general<..., ELL>), and CG becomes Jacobi-PCG because r^2 sin(theta) spans orders of
 // magnitude across the grid.
 #include "common.h"
+#include "dot_finish.h"
 #include "tables_math.h"
 
 namespace {
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom
 
 // r -= alpha q;  z = D^-1 r;  partial r.z    (use_alpha == 0: z and the sum only)
 __global__ __launch_bounds__(256) void k_k2_pc(double* __restrict__ r, const double* __restrict__ q, double* __restrict__ z,
-                                                const double* __restrict__ dinv, long long n, const double* __restrict__ scal,
-                                                double* __restrict__ partials, int use_alpha) {
+                                                const double* __restrict__ dinv, long long n, double* scal,
+                                                double* __restrict__ partials, unsigned* counter, int use_alpha) {
     __shared__ double sRed[4];
     double alpha = 0.0;
     if (use_alpha) {
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256) void k_k2_pc(double* __restrict__ r, const dou
         acc += rv * zv;
     }
     const double tot = block_sum_256(acc, sRed);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    __syncthreads();
+    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
 }
 
 inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
@@ -101,12 +103,12 @@ int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w,
     return PDEGPU_OK;
 }
 
-int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, const double* scal,
-              double* partials, int use_alpha, LaunchInfo* li) {
+int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
+              double* partials, unsigned* counter, int use_alpha, LaunchInfo* li) {
     const long long n = (long long)g.nkl * g.PP;
     const int nb = flat_grid(ctx, n);
     if (li) { li->grid = nb; li->block = 256; }
-    hipLaunchKernelGGL(k_k2_pc, dim3(nb), dim3(256), 0, ctx->stream, r, q, z, dinv, n, scal, partials, use_alpha);
+    hipLaunchKernelGGL(k_k2_pc, dim3(nb), dim3(256), 0, ctx->stream, r, q, z, dinv, n, scal, partials, counter, use_alpha);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

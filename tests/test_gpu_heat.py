@@ -395,3 +395,36 @@ def test_random_shapes_fast_and_general_apply(lib, gpu_ctx):
             refm = ref.copy()
             refm[mask] = 0.0
             assert np.all(y[mask] == 0.0) and rel_err(y, refm) < 1e-13, (n, cM, "fast")
+
+
+@pytest.mark.parametrize("n,Ls", [((19, 23), (1.0, 0.5)), ((130, 9), (2.0, 0.3)), ((260, 40), (1.0, 1.0)), ((2, 2), (1.0, 1.0)),
+                                  ((1024, 64), (1.0, 0.1))])
+@pytest.mark.parametrize("cM,cK", [(0.0, 1.0), (1.0, 0.0), (1.0, 0.37)])
+def test_fast_2d_view_matches_assembled_matrix(lib, gpu_ctx, n, Ls, cM, cK):
+    """2-D grids through the fused marching kernels (flat view: the 2-D P1 stencil is the 3-D 15-point kernel on a
+    single row of the middle axis) == assembled 2-D matrices on the free rows"""
+    from pdegpu import _lib
+    c, cells = o.rectangle_mesh(Ls[0], Ls[1], n[0], n[1])
+    K, M, _ = o.assemble_scalar(c, cells)
+    x = np.random.default_rng(11).uniform(-1, 1, c.shape[0])
+    y = np.empty_like(x)
+    _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, _lib.make_grid(2, n, Ls), cM, cK, _lib.dptr(x), _lib.dptr(y), None, 1))
+    idx = np.arange(c.shape[0])
+    ix, iy = idx % (n[0] + 1), idx // (n[0] + 1)
+    mask = (ix == 0) | (ix == n[0]) | (iy == 0) | (iy == n[1])
+    ref = cM * (M @ x) + cK * (K @ x)
+    ref[mask] = 0.0
+    assert np.all(y[mask] == 0.0) and rel_err(y, ref) < 1e-13
+
+
+def test_heat_2d_uses_the_fused_kernels(lib, gpu_ctx):
+    from pdegpu import heat
+    kw = dict(Lx=1.0, Ly=0.7, nx=150, ny=33, diffusivity=0.9, T_boundary=1.0, T_initial=20.0, dt=0.002, num_steps=3)
+    got = heat._solve_heat_2d_raw(**kw, rtol=1e-12)
+    slow = heat._solve_heat_2d_raw(**kw, rtol=1e-12, fast_path=False)
+    ref = o.solve_heat_2d(**kw)
+    assert got.meta["solver_path"] == "fast" and slow.meta["solver_path"] == "general"
+    assert rel_err(got.values, ref.values) < TOL and rel_err(slow.values, ref.values) < TOL
+    st = heat._solve_heat_2d_raw(**{**kw, "steady": True, "source_type": "constant", "source_value": 3.0}, rtol=1e-12)
+    assert st.meta["solver_path"] == "fast"
+    assert rel_err(st.values, o.solve_heat_2d(**{**kw, "steady": True, "source_type": "constant", "source_value": 3.0}).values) < TOL
