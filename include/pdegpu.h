@@ -190,6 +190,27 @@ int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const
 /* host twin of the device fold of the d x d block class table, tab [27 classes][15 offsets][3x3] (CPU tests) */
 int pdegpu_elasticity_tables_host(const pdegpu_grid* grid, double lam, double mu, double* tab);
 
+/* ---- slab-resident elasticity PCG session (3-D): same protocol as the heat session below.  Vectors: 0 x, 1 r,
+ *      2 p (current), 3 q, 4 z = D^-1 r; each has 3 component arrays.  Before every k1 the host exchanges the first /
+ *      last owned plane of z and p (3 components each) with the slab neighbours; after k1 it all-reduces scalars[0]
+ *      (p.q), after k2 scalars[1..2] (r.z, r.r) — in place, 8 / 16 bytes.  begin() needs no exchange (x = 0). */
+typedef struct pdegpu_el_session pdegpu_el_session;
+int     pdegpu_el_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, int64_t k0, int64_t nk,
+                                 pdegpu_el_session** out);
+void    pdegpu_el_session_destroy(pdegpu_el_session* s);
+int     pdegpu_el_session_begin(pdegpu_el_session* s);      /* b = body m; x = 0; r = P b; z; local r.z, r.r */
+int     pdegpu_el_session_k1(pdegpu_el_session* s);         /* x += a p; p = z + beta p; q = A p; local p.q */
+int     pdegpu_el_session_k2(pdegpu_el_session* s);         /* r -= a q; z = D^-1 r; local r.z, r.r */
+int     pdegpu_el_session_flush(pdegpu_el_session* s);      /* pending x += a p */
+double* pdegpu_el_session_scalars(pdegpu_el_session* s);    /* device {p.q, r.z, r.r, r.z_prev, ...} */
+int     pdegpu_el_session_scalars_host(pdegpu_el_session* s, double* out4);   /* synchronises */
+int64_t pdegpu_el_session_plane_doubles(const pdegpu_el_session* s);
+void*   pdegpu_el_session_plane_ptr(pdegpu_el_session* s, int vec, int comp, int64_t which);
+int     pdegpu_el_session_get_u(pdegpu_el_session* s, double* u_out /* host [nk * plane nodes][3] */);
+/* von Mises + project() (:1840-1866) on one GPU from a displacement field gathered on the host, disp [N][dim] */
+int     pdegpu_elasticity_postprocess(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, const double* disp,
+                                      double* field_out);
+
 /* ---- slab-resident CG session: the unit the benchmark and the multi-GPU driver step -------------
  * A session owns the device vectors of ONE slab of a 3-D (or 2-D) heat system
  *      A = cM*M + cK*K  with the Dirichlet set of `heat`,

@@ -16,7 +16,8 @@
 
 namespace {
 
-enum { ESC_PQ = 0, ESC_RZ = 1, ESC_RZ_PREV = 2, ESC_RR = 3, ESC_COUNT = 8 };
+// device scalars of the elasticity PCG; RZ and RR are adjacent so the multi-GPU host all-reduces them as one 16-byte message
+enum { ESC_PQ = 0, ESC_RZ = 1, ESC_RR = 2, ESC_RZ_PREV = 3, ESC_COUNT = 8 };
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -511,7 +512,7 @@ int el_scalars(ElSession* s, double* out8) {
     return PDEGPU_OK;
 }
 
-int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, ElSession* s) {
+int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, ElSession* s, int64_t k0 = 0, int64_t nk = -1) {
     s->ctx = ctx;
     s->D = grid->dim;
     pdegpu_heat bc{};
@@ -519,7 +520,9 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     bc.bc_present[0] = 1;
     bc.bc_value[0] = 0.0;
     const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
-    s->g = make_grid_dev(grid, &bc, 0, nslow);
+    if (nk < 0) nk = nslow;
+    if (k0 < 0 || nk < 1 || k0 + nk > nslow) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "slab outside the node planes");
+    s->g = make_grid_dev(grid, &bc, k0, nk);
     s->stride = (long long)vec_total(s->g);
     s->mu = el->E / (2.0 * (1.0 + el->nu));
     if (grid->dim == 2 && el->plane_stress) s->lam = el->E * el->nu / (1.0 - el->nu * el->nu);         // :1660-1661
@@ -549,6 +552,35 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     return PDEGPU_OK;
 }
 
+// b = body * m ; x = 0 ; r = P(b - A 0) = P b ; z = D^-1 r ; local rho and r.r  (no halo needed: x = 0)
+int el_begin(ElSession* s, const pdegpu_elasticity* el) {
+    pdegpu_ctx* ctx = s->ctx;
+    const size_t bytes = (size_t)s->D * s->stride * sizeof(double);
+    for (double* v : {s->x, s->p[0], s->p[1], s->q, s->z})
+        PG_HIP(ctx, hipMemsetAsync(v - vec_front(s->g), 0, bytes, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(s->scal, 0, ESC_COUNT * sizeof(double), ctx->stream));
+    s->pcur = 0;
+    hipLaunchKernelGGL(k_el_load, dim3(s->nblk), dim3(256), 0, ctx->stream, s->g, s->stride, s->D, s->ht.d_load, el->body[0], el->body[1],
+                       s->D == 3 ? el->body[2] : 0.0, s->b);
+    PG_HIP(ctx, hipGetLastError());
+    ElArgs a = s->args();
+    a.in = s->x;
+    a.rhs = s->b;
+    a.out = s->r;
+    PG_TRY(el_apply(s, a, APPLY_RESIDUAL));
+    return el_k2(s, 0);
+}
+
+int el_flush(ElSession* s) {
+    ElArgs a = s->args();
+    a.x = s->x;
+    if (s->D == 3) hipLaunchKernelGGL(k_el_flush<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->p[s->pcur]);
+    else hipLaunchKernelGGL(k_el_flush<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->p[s->pcur]);
+    PG_HIP(s->ctx, hipGetLastError());
+    PG_HIP(s->ctx, hipMemsetAsync(s->scal + ESC_PQ, 0, sizeof(double), s->ctx->stream));   // applied: next K1 skips it
+    return PDEGPU_OK;
+}
+
 VmGeom make_vm_geom(const pdegpu_grid* grid) {
     VmGeom vg{};
     double h[3] = {1, 1, 1};
@@ -566,6 +598,49 @@ int copy_out_component(ElSession* s, const double* comp, double* dense_dev, doub
     PG_HIP(s->ctx, hipMemcpyAsync(host, dense_dev, N * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
     PG_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
     return PDEGPU_OK;
+}
+
+// von Mises per simplex -> projection right-hand side -> consistent-mass solve; optional displacement download.
+// Needs the whole grid on this device (single slab).
+int el_postprocess(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, ElSession* sp, double* field_out,
+                   double* disp_out, pdegpu_stats* st2_out) {
+    ElSession& s = *sp;
+    const int D = s.D;
+    const size_t N = (size_t)pdegpu_grid_num_nodes(grid);
+    const int cx = s.g.NX - 1, cy = s.g.NY - 1, cz = D == 3 ? s.g.NZ - 1 : 1;
+    const long long ncell = (long long)cx * cy * cz;
+    VmGeom vg = make_vm_geom(grid);
+    double *d_vm = nullptr, *d_dense = nullptr;
+    if (hipMalloc(&d_vm, (size_t)vg.ns * ncell * sizeof(double)) != hipSuccess ||
+        hipMalloc(&d_dense, N * sizeof(double)) != hipSuccess) {
+        if (d_vm) (void)hipFree(d_vm);
+        return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc of the von Mises work arrays failed");
+    }
+    if (D == 3) {
+        hipLaunchKernelGGL(k_vm_cells<3>, dim3(flat_grid(ctx, ncell)), dim3(256), 0, ctx->stream, s.g, s.stride, s.x, vg, s.lam, s.mu,
+                           el->quantity, d_vm);
+        hipLaunchKernelGGL(k_vm_gather<3>, dim3(s.nblk), dim3(256), 0, ctx->stream, s.g, vg, d_vm, s.q);
+    } else {
+        hipLaunchKernelGGL(k_vm_cells<2>, dim3(flat_grid(ctx, ncell)), dim3(256), 0, ctx->stream, s.g, s.stride, s.x, vg, s.lam, s.mu,
+                           el->quantity, d_vm);
+        hipLaunchKernelGGL(k_vm_gather<2>, dim3(s.nblk), dim3(256), 0, ctx->stream, s.g, vg, d_vm, s.q);
+    }
+    int rc2 = hipGetLastError() == hipSuccess ? PDEGPU_OK : pdegpu_set_err(ctx, PDEGPU_EHIP, "von Mises kernels failed to launch");
+    std::vector<double> rhs(N);
+    if (rc2 == PDEGPU_OK) rc2 = copy_out_component(&s, s.q, d_dense, rhs.data(), N);
+    if (rc2 == PDEGPU_OK && disp_out) {
+        std::vector<double> comp(N);
+        for (int c = 0; c < D && rc2 == PDEGPU_OK; ++c) {
+            rc2 = copy_out_component(&s, s.x + (long long)c * s.stride, d_dense, comp.data(), N);
+            for (size_t i = 0; i < N; ++i) disp_out[i * D + c] = comp[i];
+        }
+    }
+    (void)hipFree(d_vm);
+    (void)hipFree(d_dense);
+    pdegpu_stats st2{};
+    if (rc2 == PDEGPU_OK) rc2 = pdegpu_mass_solve(ctx, grid, rhs.data(), field_out, 1e-13, 100000, &st2);
+    if (st2_out) *st2_out = st2;
+    return rc2;
 }
 
 // 1-D axial bar (:1516-1564): EA u'' = -b, u(0) = 0; eps = project(u'), sigma = project(E u')
@@ -631,18 +706,7 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     if (!whole.ok || !cgt.ok) return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipEventCreate failed");
     PG_HIP(ctx, hipEventRecord(whole.a, ctx->stream));
 
-    // b = body * m ; r = P(b - A 0) ; z = D^-1 r
-    hipLaunchKernelGGL(k_el_load, dim3(s.nblk), dim3(256), 0, ctx->stream, s.g, s.stride, D, s.ht.d_load, el->body[0], el->body[1],
-                       D == 3 ? el->body[2] : 0.0, s.b);
-    PG_HIP(ctx, hipGetLastError());
-    {
-        ElArgs a = s.args();
-        a.in = s.x;
-        a.rhs = s.b;
-        a.out = s.r;
-        PG_TRY(el_apply(&s, a, APPLY_RESIDUAL));
-    }
-    PG_TRY(el_k2(&s, 0));
+    PG_TRY(el_begin(&s, el));
     double sc[ESC_COUNT];
     PG_TRY(el_scalars(&s, sc));
     const double bnorm2 = sc[ESC_RR];
@@ -663,13 +727,7 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
         rr = sc[ESC_RR];
         if (chunk < 256) chunk *= 2;
     }
-    {
-        ElArgs a = s.args();
-        a.x = s.x;
-        if (D == 3) hipLaunchKernelGGL(k_el_flush<3>, dim3(s.nblk), dim3(256), 0, ctx->stream, a, s.p[s.pcur]);
-        else hipLaunchKernelGGL(k_el_flush<2>, dim3(s.nblk), dim3(256), 0, ctx->stream, a, s.p[s.pcur]);
-        PG_HIP(ctx, hipGetLastError());
-    }
+    PG_TRY(el_flush(&s));
     PG_HIP(ctx, hipEventRecord(cgt.b, ctx->stream));
     const float cms = cgt.elapsed();
     st.cg_iterations = it;
@@ -682,39 +740,8 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
                                               st.final_rel_residual);
     if (rc != PDEGPU_OK) st.converged = 0;
 
-    // von Mises per simplex -> projection right-hand side -> consistent-mass solve
-    const int cx = s.g.NX - 1, cy = s.g.NY - 1, cz = D == 3 ? s.g.NZ - 1 : 1;
-    const long long ncell = (long long)cx * cy * cz;
-    VmGeom vg = make_vm_geom(grid);
-    double *d_vm = nullptr, *d_dense = nullptr;
-    if (hipMalloc(&d_vm, (size_t)vg.ns * ncell * sizeof(double)) != hipSuccess ||
-        hipMalloc(&d_dense, N * sizeof(double)) != hipSuccess) {
-        if (d_vm) (void)hipFree(d_vm);
-        return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc of the von Mises work arrays failed");
-    }
-    if (D == 3) {
-        hipLaunchKernelGGL(k_vm_cells<3>, dim3(flat_grid(ctx, ncell)), dim3(256), 0, ctx->stream, s.g, s.stride, s.x, vg, s.lam, s.mu,
-                           el->quantity, d_vm);
-        hipLaunchKernelGGL(k_vm_gather<3>, dim3(s.nblk), dim3(256), 0, ctx->stream, s.g, vg, d_vm, s.q);
-    } else {
-        hipLaunchKernelGGL(k_vm_cells<2>, dim3(flat_grid(ctx, ncell)), dim3(256), 0, ctx->stream, s.g, s.stride, s.x, vg, s.lam, s.mu,
-                           el->quantity, d_vm);
-        hipLaunchKernelGGL(k_vm_gather<2>, dim3(s.nblk), dim3(256), 0, ctx->stream, s.g, vg, d_vm, s.q);
-    }
-    int rc2 = hipGetLastError() == hipSuccess ? PDEGPU_OK : pdegpu_set_err(ctx, PDEGPU_EHIP, "von Mises kernels failed to launch");
-    std::vector<double> rhs(N);
-    if (rc2 == PDEGPU_OK) rc2 = copy_out_component(&s, s.q, d_dense, rhs.data(), N);
-    if (rc2 == PDEGPU_OK && disp_out) {
-        std::vector<double> comp(N);
-        for (int c = 0; c < D && rc2 == PDEGPU_OK; ++c) {
-            rc2 = copy_out_component(&s, s.x + (long long)c * s.stride, d_dense, comp.data(), N);
-            for (size_t i = 0; i < N; ++i) disp_out[i * D + c] = comp[i];
-        }
-    }
-    (void)hipFree(d_vm);
-    (void)hipFree(d_dense);
     pdegpu_stats st2{};
-    if (rc2 == PDEGPU_OK) rc2 = pdegpu_mass_solve(ctx, grid, rhs.data(), field_out, 1e-13, 100000, &st2);
+    const int rc2 = el_postprocess(ctx, grid, el, &s, field_out, disp_out, &st2);
     st.linear_solves += st2.linear_solves;
     PG_HIP(ctx, hipEventRecord(whole.b, ctx->stream));
     st.solve_ms = whole.elapsed();
@@ -845,5 +872,119 @@ extern "C" int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* 
     (void)hipEventDestroy(e1);
     if (d_Ke) (void)hipFree(d_Ke);
     *avg_ms_out = ms / reps;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slab-resident elasticity PCG session: the unit the multi-GPU driver steps (pdegpu/dist.py), one slab of node
+// planes [k0, k0+nk) per GPU plus one ghost plane per side.  Same protocol as the heat session.
+// ---------------------------------------------------------------------------------------------
+struct pdegpu_el_session {
+    ElSession s;
+    pdegpu_elasticity el{};
+    pdegpu_grid grid{};
+};
+
+extern "C" int pdegpu_el_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, int64_t k0, int64_t nk,
+                                        pdegpu_el_session** out) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!el || !out) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    *out = nullptr;
+    PG_TRY(validate_grid(ctx, grid));
+    if (grid->dim != 3) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "slab sessions exist for 3-D elasticity");
+    if (!(el->E > 0.0) || !(el->nu > -1.0 && el->nu < 0.5)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "need E > 0 and nu in (-1, 0.5)");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    pdegpu_el_session* h = new pdegpu_el_session();
+    h->el = *el;
+    h->grid = *grid;
+    const int rc = el_create(ctx, grid, el, &h->s, k0, nk);
+    if (rc != PDEGPU_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return PDEGPU_OK;
+}
+
+extern "C" void pdegpu_el_session_destroy(pdegpu_el_session* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->s.ctx->device);
+    (void)hipStreamSynchronize(h->s.ctx->stream);
+    delete h;
+}
+
+extern "C" int pdegpu_el_session_begin(pdegpu_el_session* h) { return h ? el_begin(&h->s, &h->el) : PDEGPU_EINVAL; }
+extern "C" int pdegpu_el_session_k1(pdegpu_el_session* h) { return h ? el_k1(&h->s) : PDEGPU_EINVAL; }
+extern "C" int pdegpu_el_session_k2(pdegpu_el_session* h) { return h ? el_k2(&h->s, 1) : PDEGPU_EINVAL; }
+extern "C" int pdegpu_el_session_flush(pdegpu_el_session* h) { return h ? el_flush(&h->s) : PDEGPU_EINVAL; }
+extern "C" double* pdegpu_el_session_scalars(pdegpu_el_session* h) { return h ? h->s.scal : nullptr; }
+extern "C" int64_t pdegpu_el_session_plane_doubles(const pdegpu_el_session* h) { return h ? (int64_t)h->s.g.PP : -1; }
+
+// vec: 0 x, 1 r, 2 p (current), 3 q, 4 z;  comp in [0, 3);  which in [-1, nk]
+extern "C" void* pdegpu_el_session_plane_ptr(pdegpu_el_session* h, int vec, int comp, int64_t which) {
+    if (!h || comp < 0 || comp >= h->s.D || which < -1 || which > h->s.g.nkl) return nullptr;
+    double* base = nullptr;
+    switch (vec) {
+        case 0: base = h->s.x; break;
+        case 1: base = h->s.r; break;
+        case 2: base = h->s.p[h->s.pcur]; break;
+        case 3: base = h->s.q; break;
+        case 4: base = h->s.z; break;
+        default: return nullptr;
+    }
+    return base + (long long)comp * h->s.stride + which * h->s.g.PP;
+}
+
+// synchronises; out4 = {p.q, r.z, r.r, r.z of the previous iteration} (global values once the host has all-reduced them)
+extern "C" int pdegpu_el_session_scalars_host(pdegpu_el_session* h, double* out4) {
+    if (!h || !out4) return PDEGPU_EINVAL;
+    double sc[ESC_COUNT];
+    PG_TRY(el_scalars(&h->s, sc));
+    for (int i = 0; i < 4; ++i) out4[i] = sc[i];
+    return PDEGPU_OK;
+}
+
+// displacement of the owned planes, host [nk * (ny+1) * (nx+1)][3]
+extern "C" int pdegpu_el_session_get_u(pdegpu_el_session* h, double* u_out) {
+    if (!h || !u_out) return PDEGPU_EINVAL;
+    ElSession& s = h->s;
+    const size_t n = (size_t)s.g.nkl * s.g.NY * s.g.NX;
+    double* d_dense = nullptr;
+    PG_HIP(s.ctx, hipMalloc(&d_dense, n * sizeof(double)));
+    std::vector<double> comp(n);
+    int rc = PDEGPU_OK;
+    for (int c = 0; c < s.D && rc == PDEGPU_OK; ++c) {
+        rc = copy_out_component(&s, s.x + (long long)c * s.stride, d_dense, comp.data(), n);
+        for (size_t i = 0; i < n; ++i) u_out[i * s.D + c] = comp[i];
+    }
+    (void)hipFree(d_dense);
+    return rc;
+}
+
+// von Mises + project() from a given displacement field (host [N][dim]) on one GPU — the post-processing of
+// _solve_elasticity_{2,3}d_static (:1690-1718, :1840-1866) after a distributed solve has been gathered
+extern "C" int pdegpu_elasticity_postprocess(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, const double* disp,
+                                             double* field_out) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!el || !disp || !field_out) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    PG_TRY(validate_grid(ctx, grid));
+    if (grid->dim < 2) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "dim 2 or 3");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    ElSession s;
+    PG_TRY(el_create(ctx, grid, el, &s));
+    const size_t N = (size_t)pdegpu_grid_num_nodes(grid);
+    double* d_dense = nullptr;
+    PG_HIP(ctx, hipMalloc(&d_dense, N * sizeof(double)));
+    std::vector<double> comp(N);
+    int rc = PDEGPU_OK;
+    for (int c = 0; c < s.D && rc == PDEGPU_OK; ++c) {
+        for (size_t i = 0; i < N; ++i) comp[i] = disp[i * s.D + c];
+        if (hipMemcpyAsync(d_dense, comp.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "upload failed");
+        if (rc == PDEGPU_OK) rc = vec_unpack(ctx, s.g, d_dense, s.x + (long long)c * s.stride);
+        if (rc == PDEGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "sync failed");
+    }
+    (void)hipFree(d_dense);
+    if (rc == PDEGPU_OK) rc = el_postprocess(ctx, grid, el, &s, field_out, nullptr, nullptr);
     return rc;
 }

@@ -89,6 +89,18 @@ SYMBOLS = {
     "pdegpu_elasticity_apply": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp, C.c_int]),
     "pdegpu_elasticity_time_apply": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), C.c_int, C.c_int, _dp]),
     "pdegpu_elasticity_tables_host": (C.c_int, [C.POINTER(Grid), C.c_double, C.c_double, _dp]),
+    "pdegpu_el_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), C.c_int64, C.c_int64, C.POINTER(_vp)]),
+    "pdegpu_el_session_destroy": (None, [_vp]),
+    "pdegpu_el_session_begin": (C.c_int, [_vp]),
+    "pdegpu_el_session_k1": (C.c_int, [_vp]),
+    "pdegpu_el_session_k2": (C.c_int, [_vp]),
+    "pdegpu_el_session_flush": (C.c_int, [_vp]),
+    "pdegpu_el_session_scalars": (_vp, [_vp]),
+    "pdegpu_el_session_scalars_host": (C.c_int, [_vp, _dp]),
+    "pdegpu_el_session_plane_doubles": (C.c_int64, [_vp]),
+    "pdegpu_el_session_plane_ptr": (_vp, [_vp, C.c_int, C.c_int, C.c_int64]),
+    "pdegpu_el_session_get_u": (C.c_int, [_vp, _dp]),
+    "pdegpu_elasticity_postprocess": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp]),
     "pdegpu_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "pdegpu_session_destroy": (None, [_vp]),
     "pdegpu_session_begin": (C.c_int, [_vp, C.c_double]),

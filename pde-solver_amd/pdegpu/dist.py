@@ -108,6 +108,14 @@ class GpuSlabEngine:
     def needs_p_halo(self) -> bool:
         return bool(self.lib.pdegpu_session_needs_p_halo(self.s))
 
+    def halo_tensors(self, which: int):
+        """planes `which` of every vector the next k1 needs on the ghost planes"""
+        vecs = (VEC_R, VEC_P) if self.needs_p_halo() else (VEC_R,)
+        return [self.plane_tensor(v, which) for v in vecs]
+
+    def global_slots(self, which: int):
+        return (SC_PQ, SC_PQ + 1) if which == 0 else (SC_RR, SC_RR + 1)
+
     def iterate_native(self, iters: int, time_kernels: bool, stats=None):
         self._ck(self.lib.pdegpu_session_iterate(self.s, iters, 1 if time_kernels else 0, stats))
 
@@ -120,6 +128,86 @@ class GpuSlabEngine:
         self._ck(self.lib.pdegpu_session_sync(self.s))
 
 
+class GpuElasticitySlabEngine:
+    """pdegpu_el_session on one GPU (3-D elasticity, Jacobi-PCG): the same driver protocol as the heat engine."""
+
+    def __init__(self, grid, el, k0: int, nk: int, device: int, stream: Optional[torch.cuda.Stream] = None):
+        self.lib = L.load_library()
+        self.device, self.k0, self.nk = device, k0, nk
+        self.ctx = C.c_void_p()
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None and stream.cuda_stream else None
+        rc = self.lib.pdegpu_create(C.byref(self.ctx), device, sp)
+        if rc != 0:
+            raise L.PdeGpuError(rc, f"pdegpu_create(device={device}) failed: no usable gfx950 device (no CPU fallback)")
+        self.s = C.c_void_p()
+        L.check(self.ctx, self.lib.pdegpu_el_session_create(self.ctx, grid, el, k0, nk, C.byref(self.s)))
+        self.plane = int(self.lib.pdegpu_el_session_plane_doubles(self.s))
+        self._planes = {}
+        self._scal = torch.as_tensor(_DevArray(self.lib.pdegpu_el_session_scalars(self.s), 8), device=f"cuda:{device}")
+
+    def close(self):
+        if self.s:
+            self.lib.pdegpu_el_session_destroy(self.s)
+            self.s = None
+        if self.ctx:
+            self.lib.pdegpu_destroy(self.ctx)
+            self.ctx = None
+
+    def _ck(self, rc):
+        L.check(self.ctx, rc)
+
+    def begin(self, x_fill: float = 0.0):
+        self._ck(self.lib.pdegpu_el_session_begin(self.s))
+
+    def residual(self):
+        pass                                            # begin() already formed r = P b, z and the local sums (x = 0)
+
+    def k1(self):
+        self._ck(self.lib.pdegpu_el_session_k1(self.s))
+
+    def k2(self):
+        self._ck(self.lib.pdegpu_el_session_k2(self.s))
+
+    def flush(self):
+        self._ck(self.lib.pdegpu_el_session_flush(self.s))
+
+    def local_to_global(self, which: int):
+        pass
+
+    def scalars(self) -> torch.Tensor:
+        return self._scal
+
+    def plane_tensor(self, vec: int, comp: int, which: int) -> torch.Tensor:
+        ptr = self.lib.pdegpu_el_session_plane_ptr(self.s, vec, comp, which)
+        if not ptr:
+            raise L.PdeGpuError(L.EINVAL, f"no plane {which} of vector {vec}/{comp}")
+        t = self._planes.get(ptr)
+        if t is None:
+            t = self._planes[ptr] = torch.as_tensor(_DevArray(ptr, self.plane), device=f"cuda:{self.device}")
+        return t
+
+    def halo_tensors(self, which: int):
+        return [self.plane_tensor(v, c, which) for v in (4, 2) for c in range(3)]       # z and p, 3 components each
+
+    def global_slots(self, which: int):
+        return (0, 1) if which == 0 else (1, 3)          # p.q | r.z and r.r as one 16-byte message
+
+    def scalars_host(self):
+        out = (C.c_double * 4)()
+        self._ck(self.lib.pdegpu_el_session_scalars_host(self.s, out))
+        return list(out)                                 # [p.q, r.z, r.r, r.z_prev]
+
+    def rr(self) -> float:
+        return self.scalars_host()[2]
+
+    def get_u(self, plane_nodes: int):
+        """displacement of the owned planes, numpy [nk * plane_nodes, 3]"""
+        import numpy as np
+        u = np.empty((self.nk * plane_nodes, 3))
+        self._ck(self.lib.pdegpu_el_session_get_u(self.s, L.dptr(u)))
+        return u
+
+
 class SlabCG:
     """CG over a 1-D slab decomposition.  `engine` owns planes [k0, k0+nk) plus one ghost plane per side."""
 
@@ -128,27 +216,41 @@ class SlabCG:
         self.iterations = 0
 
     # ---- the two exchanges -------------------------------------------------------------------------
-    def exchange_halos(self, vecs=(VEC_R, VEC_P)):
+    def _halo(self, which: int):
+        """tensors of plane `which` that travel: engine.halo_tensors, or (legacy engines) planes of r and p"""
+        if hasattr(self.e, "halo_tensors"):
+            return self.e.halo_tensors(which)
+        vecs = (VEC_R, VEC_P) if getattr(self.e, "needs_p_halo", lambda: True)() else (VEC_R,)
+        return [self.e.plane_tensor(v, which) for v in vecs]
+
+    def exchange_halos(self):
+        """first / last owned plane -> the neighbours' ghost planes, all vectors in ONE batch (one ncclGroup)"""
         if self.world == 1:
             return
         ops: List[dist.P2POp] = []
         lo, hi = self.rank - 1, self.rank + 1
-        for v in vecs:
-            if lo >= 0:
-                ops.append(dist.P2POp(dist.isend, self.e.plane_tensor(v, 0), lo, self.group, tag=2 * v))
-                ops.append(dist.P2POp(dist.irecv, self.e.plane_tensor(v, -1), lo, self.group, tag=2 * v + 1))
-            if hi < self.world:
-                ops.append(dist.P2POp(dist.isend, self.e.plane_tensor(v, self.e.nk - 1), hi, self.group, tag=2 * v + 1))
-                ops.append(dist.P2POp(dist.irecv, self.e.plane_tensor(v, self.e.nk), hi, self.group, tag=2 * v))
+        nk = self.e.nk
+        if lo >= 0:
+            for t, (snd, rcv) in enumerate(zip(self._halo(0), self._halo(-1))):
+                ops.append(dist.P2POp(dist.isend, snd, lo, self.group, tag=2 * t))
+                ops.append(dist.P2POp(dist.irecv, rcv, lo, self.group, tag=2 * t + 1))
+        if hi < self.world:
+            for t, (snd, rcv) in enumerate(zip(self._halo(nk - 1), self._halo(nk))):
+                ops.append(dist.P2POp(dist.isend, snd, hi, self.group, tag=2 * t + 1))
+                ops.append(dist.P2POp(dist.irecv, rcv, hi, self.group, tag=2 * t))
         for w in dist.batch_isend_irecv(ops):
             w.wait()          # stream-ordered for NCCL (no host block); completes the copy for gloo
 
     def allreduce(self, which: int):
-        """local partial -> global scalar (sum over ranks); which: 0 = p.q, 1 = r.r"""
+        """local partial -> global scalar(s) (sum over ranks), in place; which: 0 after k1, 1 after k2"""
         self.e.local_to_global(which)
         if self.world > 1:
-            slot = SC_PQ if which == 0 else SC_RR
-            dist.all_reduce(self.e.scalars()[slot:slot + 1], op=dist.ReduceOp.SUM, group=self.group)
+            if hasattr(self.e, "global_slots"):
+                a, b = self.e.global_slots(which)
+            else:
+                a = SC_PQ if which == 0 else SC_RR
+                b = a + 1
+            dist.all_reduce(self.e.scalars()[a:b], op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- CG ---------------------------------------------------------------------------------------
     def start(self, x_fill: float = 0.0):
@@ -160,10 +262,9 @@ class SlabCG:
         self.iterations = 0
 
     def iterate(self, iters: int):
-        # K1 needs r_n and p_{n-1} on the ghost planes; engines whose K1 maintains p there itself only exchange r
-        vecs = (VEC_R, VEC_P) if getattr(self.e, "needs_p_halo", lambda: True)() else (VEC_R,)
+        # K1 needs r_n (z_n) and p_{n-1} on the ghost planes; engines whose K1 maintains p there itself only exchange r
         for _ in range(iters):
-            self.exchange_halos(vecs)
+            self.exchange_halos()
             self.e.k1()
             self.allreduce(0)
             self.e.k2()
@@ -172,3 +273,43 @@ class SlabCG:
 
     def finish(self):
         self.e.flush()
+
+
+def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int = 400000, group=None):
+    """3-D static elasticity (config 5) over the ranks of the default process group, one z-slab per GPU:
+    Jacobi-PCG with halo exchange of z, p and 8-/16-byte all-reduces; every rank returns the iteration count, rank 0
+    additionally the gathered displacement [N,3] and the projected von Mises field [N] (post-processing on its GPU)."""
+    import numpy as np
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    local = int(L.os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    nx, ny, nz = n_cells
+    k0, nk = slab_range(nz + 1, world, rank)
+    stream = torch.cuda.Stream(device=local)
+    with torch.cuda.stream(stream):
+        eng = GpuElasticitySlabEngine(grid, el, k0, nk, local, stream)
+        cg = SlabCG(eng, rank, world, group)
+        cg.start(0.0)
+        rr0 = eng.rr()
+        it, chunk = 0, 16
+        rr = rr0
+        while rr > rtol * rtol * rr0 and it < max_iter:
+            cg.iterate(chunk)
+            it += chunk
+            rr = eng.rr()                       # the only host synchronisation: once per chunk
+            chunk = min(2 * chunk, 256)
+        cg.finish()
+        u_local = eng.get_u((nx + 1) * (ny + 1))
+        parts = [u_local]
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, u_local, group=group)
+        out = {"iterations": it, "rel_residual": (rr / rr0) ** 0.5 if rr0 > 0 else 0.0}
+        if rank == 0:
+            u = np.ascontiguousarray(np.concatenate(parts, axis=0))
+            field = np.empty(u.shape[0])
+            ctx = eng.ctx
+            L.check(ctx, eng.lib.pdegpu_elasticity_postprocess(ctx, grid, el, L.dptr(u), L.dptr(field)))
+            out.update(displacement=u, field=field)
+        eng.close()
+    return out

@@ -105,5 +105,12 @@ class NumpySlabEngine:
         t = {0: self.x, 1: self.r, 2: self.p[self.pcur], 3: self.q}[vec]
         return t[which + 1].view(-1)                             # contiguous plane, shares storage
 
+    # the generalised driver protocol (same as GpuSlabEngine / GpuElasticitySlabEngine)
+    def halo_tensors(self, which):
+        return [self.plane_tensor(1, which), self.plane_tensor(2, which)]
+
+    def global_slots(self, which):
+        return (SC_PQ, SC_PQ + 1) if which == 0 else (SC_RR, SC_RR + 1)
+
     def owned_x(self):
         return self.x.numpy()[self.own].copy()

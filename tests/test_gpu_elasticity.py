@@ -103,3 +103,79 @@ def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
         elasticity._solve_elasticity_3d_static(1, 1, 1, 4, 4, 4, 210e9, 0.5, body_fz=-1.0)   # incompressible limit
     with pytest.raises(_lib.PdeGpuError):
         elasticity._solve_elasticity_2d_static(1, 1, 0, 4, 210e9, 0.3)
+
+
+@pytest.mark.parametrize("nslabs", [1, 2, 3])
+def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs):
+    """the multi-GPU elasticity path on ONE GPU: slab sessions (ghost planes, global boundary classes), halo exchange of
+    z and p (3 components each) and the scalar all-reduces done by device copies in the order pdegpu.dist.SlabCG uses;
+    then von Mises + project() from the gathered displacement.  Must reproduce the oracle."""
+    import torch
+    from pdegpu import _lib
+    from pdegpu.dist import GpuElasticitySlabEngine, slab_range
+    n, Ls = (14, 4, 9), (1.0, 0.3, 0.6)
+    E, nu, body = 210e9, 0.3, (0.0, 2.0e4, -76518.0)
+    grid = _lib.make_grid(3, n, Ls)
+    el = _lib.Elasticity()
+    el.E, el.nu = E, nu
+    for c in range(3):
+        el.body[c] = body[c]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        engs = [GpuElasticitySlabEngine(grid, el, *slab_range(n[2] + 1, nslabs, r), 0, stream) for r in range(nslabs)]
+
+        def exchange():
+            for r in range(nslabs - 1):
+                lo, hi = engs[r], engs[r + 1]
+                for a, b in zip(hi.halo_tensors(-1), lo.halo_tensors(lo.nk - 1)):
+                    a.copy_(b)
+                for a, b in zip(lo.halo_tensors(lo.nk), hi.halo_tensors(0)):
+                    a.copy_(b)
+
+        def allreduce(which):
+            a, b = engs[0].global_slots(which)
+            tot = sum(e.scalars()[a:b].clone() for e in engs)
+            for e in engs:
+                e.scalars()[a:b].copy_(tot)
+
+        for e in engs:
+            e.begin()
+        allreduce(1)
+        rr0 = engs[0].rr()
+        it = 0
+        while it < 6000:
+            for _ in range(50):
+                exchange()
+                for e in engs:
+                    e.k1()
+                allreduce(0)
+                for e in engs:
+                    e.k2()
+                allreduce(1)
+            it += 50
+            if engs[0].rr() <= 1e-24 * rr0:
+                break
+        for e in engs:
+            e.flush()
+        u = np.concatenate([e.get_u((n[0] + 1) * (n[1] + 1)) for e in engs], axis=0)
+        for e in engs:
+            e.close()
+    ref = o.solve_elasticity_3d(*Ls, *n, E, nu, *body, "stress")
+    assert rel_err(u, ref.extra["displacement"]) < TOL
+    field = np.empty(u.shape[0])
+    _lib.check(gpu_ctx, lib.pdegpu_elasticity_postprocess(gpu_ctx, grid, el, _lib.dptr(np.ascontiguousarray(u)), _lib.dptr(field)))
+    assert rel_err(field, ref.values[0]) < TOL
+
+
+def test_solve_elasticity_slabs_single_rank(lib, gpu_ctx):
+    """the rank-level driver (what each process runs under torch.distributed) with world size 1"""
+    from pdegpu import _lib
+    from pdegpu.dist import solve_elasticity_slabs
+    n, Ls = (16, 4, 4), (1.0, 0.25, 0.25)
+    grid = _lib.make_grid(3, n, Ls)
+    el = _lib.Elasticity()
+    el.E, el.nu = 210e9, 0.3
+    el.body[2] = -76518.0
+    out = solve_elasticity_slabs(grid, el, n, rtol=1e-12)
+    ref = o.solve_elasticity_3d(*Ls, *n, 210e9, 0.3, 0.0, 0.0, -76518.0, "stress")
+    assert rel_err(out["displacement"], ref.extra["displacement"]) < TOL and rel_err(out["field"], ref.values[0]) < TOL
