@@ -61,8 +61,13 @@ struct ElArgs {
     int mask_dirichlet;
 };
 
+// block weights of the interior boundary class, passed BY VALUE: kernel arguments live in the kernarg segment and are
+// fetched with scalar loads, so interior wavefronts read their 15 x 9 weights from SGPRs (a pointer inside ElArgs
+// would be a vector load — the compiler cannot prove it unclobbered)
+struct ElInterior { double w[PG_NOFF15 * 9]; };
+
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void k_el_apply(ElArgs a) {
+__global__ __launch_bounds__(256) void k_el_apply(ElArgs a, ElInterior wi) {
     __shared__ double sTab[27 * PG_NOFF15 * 9];
     __shared__ unsigned sMask[27];
     __shared__ double sRed[4];
@@ -109,17 +114,26 @@ __global__ __launch_bounds__(256) void k_el_apply(ElArgs a) {
                 if (alpha_prev != 0.0) a.x[c * a.stride + idx] += alpha_prev * po;
             }
         }
-        if (real && !dir) {
-            const int cls = pg_axis_class(i, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
-                            9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
-            const unsigned m = sMask[cls];
+        const bool active = real && !dir;
+        const int cls = pg_axis_class(i < g.NX ? i : 1, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
+                        9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
+        // wave-uniform boundary class (every interior wave): the 15 x 9 weights come through scalar loads into SGPRs
+        // instead of 135 LDS reads per lane
+        const unsigned long long act = __ballot(active);
+        int cls0 = 13;
+        bool uniform = false;
+        if (act) {
+            cls0 = __builtin_amdgcn_readlane(cls, (int)__builtin_ctzll(act));
+            uniform = __ballot(active && cls != cls0) == 0ull;
+        }
+        auto gather = [&](const double* __restrict__ wtab, unsigned m) {
 #pragma unroll
             for (int q = 0; q < PG_NOFF15; ++q) {
                 if (!((m >> q) & 1u)) continue;
                 const int o = pg_off15(q);
                 const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
                 const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
-                const double* blk = &sTab[(cls * PG_NOFF15 + q) * 9];
+                const double* blk = wtab + q * 9;
                 double v[D];
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
@@ -131,6 +145,11 @@ __global__ __launch_bounds__(256) void k_el_apply(ElArgs a) {
 #pragma unroll
                     for (int c = 0; c < D; ++c) s[r] += blk[r * 3 + c] * v[c];
             }
+        };
+        if (uniform && cls0 == 13) {
+            if (active) gather(wi.w, sMask[13]);                                 // interior class: weights from SGPRs
+        } else if (active) {
+            gather(&sTab[cls * PG_NOFF15 * 9], sMask[cls]);
         }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
@@ -193,6 +212,24 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
     if (threadIdx.x == 0) {
         a.partials[blockIdx.x] = t1;
         a.partials2[blockIdx.x] = t2;
+    }
+}
+
+// p_n = z_n + beta p_{n-1};  x += alpha_{n-1} p_{n-1}   over the owned planes AND the ghost planes inside the domain
+// (so that the block apply that follows finds p_n on the ghosts: z and p_{n-1} were exchanged before)
+template <int D>
+__global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, long long total) {
+    const double pq = a.scal[ESC_PQ], rz = a.scal[ESC_RZ], rz_prev = a.scal[ESC_RZ_PREV];
+    const double alpha_prev = (pq > 0.0 && rz_prev > 0.0) ? rz_prev / pq : 0.0;
+    const double beta = (rz_prev > 0.0) ? rz / rz_prev : 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long idx = first + e;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double po = a.p_old[c * a.stride + idx];
+            a.p_new[c * a.stride + idx] = a.in[c * a.stride + idx] + beta * po;
+            if (alpha_prev != 0.0) a.x[c * a.stride + idx] += alpha_prev * po;
+        }
     }
 }
 
@@ -436,6 +473,7 @@ struct ElSession {
     int nblk = 1;
     HeatTables ht{};
     double* h_pin = nullptr;
+    ElInterior interior{};
 
     double* alloc_vec() {
         double* base = nullptr;
@@ -473,9 +511,9 @@ template <int D>
 int el_launch_apply(ElSession* s, ElArgs a, int mode) {
     const int nb = s->nblk;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_el_apply<D, APPLY_PLAIN>), dim3(nb), dim3(256), 0, s->ctx->stream, a); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_el_apply<D, APPLY_RESIDUAL>), dim3(nb), dim3(256), 0, s->ctx->stream, a); break;
-        default: hipLaunchKernelGGL((k_el_apply<D, APPLY_CG_K1>), dim3(nb), dim3(256), 0, s->ctx->stream, a); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_el_apply<D, APPLY_PLAIN>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->interior); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_el_apply<D, APPLY_RESIDUAL>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->interior); break;
+        default: hipLaunchKernelGGL((k_el_apply<D, APPLY_CG_K1>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->interior); break;
     }
     PG_HIP(s->ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -492,15 +530,25 @@ int el_k2(ElSession* s, int use_alpha) {
     PG_HIP(s->ctx, hipGetLastError());
     return PDEGPU_OK;
 }
+// K1 = flat p-update (+ deferred x-update) followed by the plain block apply q = P A p with the p.q partials.
+// (The heat path recomputes p at the stencil neighbours to save an HBM pass; here everything is cache-resident and
+// the 15 x 3 x 2 neighbour reads of the fused form cost more than the extra launch: measured 110 -> ~60 us.)
 int el_k1(ElSession* s) {
     ElArgs a = s->args();
     a.in = s->z;
     a.p_old = s->p[s->pcur];
     a.p_new = s->p[1 - s->pcur];
     a.x = s->x;
-    a.out = s->q;
-    PG_TRY(el_apply(s, a, APPLY_CG_K1));
+    const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
+    const long long first = -(long long)lo * s->g.PP, total = (long long)(s->g.nkl + lo + hi) * s->g.PP;
+    if (s->D == 3) hipLaunchKernelGGL(k_el_pupdate<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
+    else hipLaunchKernelGGL(k_el_pupdate<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
+    PG_HIP(s->ctx, hipGetLastError());
     s->pcur ^= 1;
+    ElArgs b = s->args();
+    b.in = s->p[s->pcur];
+    b.out = s->q;
+    PG_TRY(el_apply(s, b, APPLY_PLAIN));
     hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part, (const double*)nullptr, s->nblk, s->scal, 0);
     PG_HIP(s->ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -543,6 +591,7 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     for (int r = 0; r < grid->dim; ++r) h[r] = grid->L[r] / grid->n[r];
     hipLaunchKernelGGL(k_el_tables, dim3(1), dim3(256), 0, ctx->stream, grid->dim, h[0], h[1], h[2], s->lam, s->mu, s->tab, s->dinv);
     PG_HIP(ctx, hipGetLastError());
+    for (int q = 0; q < PG_NOFF15; ++q) fold_elasticity_block(grid->dim, h, s->lam, s->mu, 13, q, s->interior.w + q * 9);
     PG_TRY(tables_build(ctx, grid, &s->ht));
     double** vecs[] = {&s->x, &s->r, &s->z, &s->p[0], &s->p[1], &s->q, &s->b};
     for (double** v : vecs) {
