@@ -161,9 +161,9 @@ def main():
                     traffic = None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_fast<7,2,CG_K1,nt> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)" if not args.general else "k_general<CG_K1>",
+                               "kernel": "k_fast<7,2,CG_K1,nt,ex> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)" if not args.general else "k_general<CG_K1>",
                                "alg_bytes_per_launch": k1_bytes, "avg_ms": k1_ms,
-                               "other_kernels": [{"kernel": "k_fast<7,2,CG_K2,nt> (r-=a*(A p); r.r)" if k1_per_dof == 40 else "k_k2 (r-=a*q; r.r)", "alg_bytes_per_launch": k2_bytes,
+                               "other_kernels": [{"kernel": "k_fast<7,2,CG_K2,nt,ex> (r-=a*(A p); r.r)" if k1_per_dof == 40 else "k_k2 (r-=a*q; r.r)", "alg_bytes_per_launch": k2_bytes,
                                                   "avg_ms": k2_ms, "achieved": k2_bytes / (k2_ms * 1e-3) / 1e9,
                                                   "frac": k2_bytes / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}],
                                "cg_iteration_alg_bytes_per_dof": k1_per_dof + 24}

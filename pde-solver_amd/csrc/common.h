@@ -19,6 +19,8 @@ struct pdegpu_ctx {
     int fast_ry = 2;            // rows per thread of the z-marching kernels (1, 2, 4, 8); 2 = 4 waves/SIMD, measured best
     int fast_nt = -1;           // bit 0: non-temporal stores of q / p / x; bit 1: non-temporal loads of x; -1 = auto
                                 // (3 when one slab vector exceeds 64 MiB, i.e. nothing stays cache-resident)
+    int fast_ex = 1;            // 1: CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
+                                // instead of 2-lane global loads (measured: 1.65 -> 1.52 ms per 512^3 CG iteration)
     int fast_wg_per_cu = 0;     // 0 = occupancy API
     int k2_variant = 0;         // 0: grid-stride double2; 1: 4x unrolled; 2: 4x unrolled + non-temporal
     int grid_mult = 8;          // flat kernels: workgroups per CU
@@ -179,8 +181,8 @@ struct CgGraph {
     }
 };
 inline long long tunable_key(const pdegpu_ctx* c) {
-    return ((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 8 + c->k2_variant) * 128 + c->grid_mult) * 128 +
-            c->k2_grid_mult) * 4 + c->cg_variant;
+    return (((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 8 + c->k2_variant) * 128 + c->grid_mult) * 128 +
+             c->k2_grid_mult) * 4 + c->cg_variant) * 2 + c->fast_ex;
 }
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
@@ -201,8 +203,8 @@ int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
 // weighted.hip
-int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, double cM, double cK,
-                      double* ellA, double* ellM, double* dinv, long long stride);
+int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, const double* lengths, double cM,
+                      double cK, double* ellA, double* ellM, double* dinv, long long stride);
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
               double* partials, unsigned* counter, int use_alpha, LaunchInfo* li);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);

@@ -293,7 +293,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -306,6 +306,7 @@ namespace {
 int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_ry")) return &ctx->fast_ry;
     if (!strcmp(key, "fast_nt")) return &ctx->fast_nt;
+    if (!strcmp(key, "fast_ex")) return &ctx->fast_ex;
     if (!strcmp(key, "fast_wg_per_cu")) return &ctx->fast_wg_per_cu;
     if (!strcmp(key, "k2_variant")) return &ctx->k2_variant;
     if (!strcmp(key, "grid_mult")) return &ctx->grid_mult;
@@ -764,9 +765,12 @@ int session_make_weighted(pdegpu_session* s, const pdegpu_weight* w) {
     s->dinv = s->ell_base[2];
     s->ell_stride = n;
     PG_TRY(vec_alloc(ctx, s->g, &s->z));
-    double h[3] = {1, 1, 1};
-    for (int r = 0; r < s->grid.dim; ++r) h[r] = s->grid.L[r] / s->grid.n[r];
-    PG_TRY(weighted_assemble(ctx, s->g, w, h, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride));
+    double h[3] = {1, 1, 1}, lengths[3] = {0, 0, 0};
+    for (int r = 0; r < s->grid.dim; ++r) {
+        h[r] = s->grid.L[r] / s->grid.n[r];
+        lengths[r] = s->grid.L[r];
+    }
+    PG_TRY(weighted_assemble(ctx, s->g, w, h, lengths, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride));
     s->weighted = true;
     return PDEGPU_OK;
 }

@@ -185,9 +185,13 @@ __device__ __forceinline__ double2 load_pair_x(const double* p) {
     return *reinterpret_cast<const double2*>(p);
 }
 
-template <int NPT, int RY, int MODE, int NT>
+// EX = 1: the tile-edge x-neighbours are handed between the x-adjacent wavefronts of the workgroup through 512 B of
+// LDS (one barrier per z-step; the waves march in lockstep anyway) instead of 2-lane global loads; columns outside
+// the free range of a CG vector (Dirichlet / beyond the grid) need no load at all.
+template <int NPT, int RY, int MODE, int NT, int EX>
 __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     __shared__ double sRed[4];
+    __shared__ double sEdge[EX ? 2 : 1][4][RY + 2][2];
     const GridDev& g = a.g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr bool K1 = (MODE == APPLY_CG_K1);
@@ -208,9 +212,13 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     const int lk0 = fg.lkb + zc * fg.zlen;
     const int lk1 = min(lk0 + fg.zlen, fg.lke);
     const bool active = (xt < fg.ntx) && (yt < fg.nty) && (lk0 < lk1);
+    const int wave_x = wv % fg.wxt;                          // position of this wave among the workgroup's x-adjacent tiles
+    int estep = 0;                                            // LDS edge-exchange counter (same in every wave of the workgroup)
 
     double acc = 0.0;
-    if (active) {
+    // EX: every wave of a workgroup with work runs the loop (inactive ones with all loads / stores predicated off) so
+    // that the barriers match; lk0 / lk1 depend on the workgroup only
+    if (EX ? (lk0 < lk1) : active) {
         double alpha_prev = 0.0, beta = 0.0;
         if (K1) cg_scalars(a.scal, &alpha_prev, &beta);
         const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wz = a.w[3];
@@ -222,9 +230,9 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             res_scale = (pq > 0.0) ? rr / pq : 0.0;
         }
 
-        const bool lane_ok = i0 < g.PX;                       // pair inside the padded row
-        const bool ma = (i0 >= 1) && (i0 <= g.NX - 2);        // node a = i0 is an interior (free) node
-        const bool mb = (i0 + 1 <= g.NX - 2);                 // node b = i0+1
+        const bool lane_ok = active && i0 < g.PX;             // pair inside the padded row
+        const bool ma = active && (i0 >= 1) && (i0 <= g.NX - 2);   // node a = i0 is an interior (free) node
+        const bool mb = active && (i0 + 1 <= g.NX - 2);       // node b = i0+1
         const bool edge_lane = (lane == 0) || (lane == 63);
         const long long edge_off = (lane == 0) ? -1 : 2;      // lane 0: node i0-1, lane 63: node i0+2
 
@@ -259,6 +267,56 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             }
             return e;
         };
+        // edge values of one plane: E[r] = value at node i0-1 (lane 0) / i0+2 (lane 63) of row r
+        auto plane_edges = [&](int lk, const double2* rows, double* E, bool all_rows) {
+            if (!EX) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const bool own = (r >= 1) && (r <= RY);
+                    E[r] = (all_rows || own) ? edge_value(lk, j0 - 1 + r) : 0.0;
+                }
+                return;
+            }
+            const int buf = estep & 1;
+            ++estep;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                if (lane == 0) sEdge[buf][wv][r][0] = rows[r].x;
+                if (lane == 63) sEdge[buf][wv][r][1] = rows[r].y;
+            }
+            __syncthreads();
+            // x-neighbour wave inside this workgroup (and covering real nodes: an inactive right neighbour holds zeros)
+            const bool has_l = wave_x > 0, has_r = (wave_x < fg.wxt - 1) && (xt + 1 < fg.ntx);
+            // a global load only where the neighbour tile belongs to another workgroup AND the node can be non-zero:
+            // CG vectors (K1: r, p; K2: p) vanish on the Dirichlet columns, PLAIN / RESIDUAL inputs carry boundary values
+            const int il = xt * 128 - 1, ir = xt * 128 + 128;
+            const bool cgvec = K1 || K2;
+            const bool gl = !has_l && il >= 0 && (il >= 1 || !cgvec) && active;
+            const bool gr = !has_r && ir <= g.NX - 1 && (ir <= g.NX - 2 || !cgvec) && active;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                const bool own = (r >= 1) && (r <= RY);
+                double e = 0.0;
+                if (all_rows || own) {
+                    const int j = j0 - 1 + r;
+                    if (lane == 0) {
+                        if (has_l) e = sEdge[buf][wv - 1][r][1];
+                        else if (gl && row_ok(j)) {
+                            const long long off = (long long)lk * g.PP + (long long)j * g.PX + il;
+                            e = K1 ? a.in[off] + beta * a.p_old[off] : a.in[off] + shift;
+                        }
+                    } else if (lane == 63) {
+                        if (has_r) e = sEdge[buf][wv + 1][r][0];
+                        else if (gr && row_ok(j)) {
+                            const long long off = (long long)lk * g.PP + (long long)j * g.PX + ir;
+                            e = K1 ? a.in[off] + beta * a.p_old[off] : a.in[off] + shift;
+                        }
+                    }
+                }
+                E[r] = e;
+            }
+        };
+
         // K1: x += alpha p_{n-1}, store p_n for an owned row-plane
         auto own_update = [&](int lk, int j, const double2& pn, const double2& po) {
             if (K1) {
@@ -283,18 +341,15 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             const bool own = (r >= 1) && (r <= RY);
             const int j = j0 - 1 + r;
             // plane lk0-1: 7-point needs own rows only; 15-point rows j-1..j (r = 0..RY)
-            if (W15 ? (r <= RY) : own) {
-                P[r] = value_row(lk0 - 1, j, nullptr);
-                EP[r] = W15 ? edge_value(lk0 - 1, j) : 0.0;
-            } else {
-                P[r] = make_double2(0.0, 0.0);
-                EP[r] = 0.0;
-            }
+            if (W15 ? (r <= RY) : own) P[r] = value_row(lk0 - 1, j, nullptr);
+            else P[r] = make_double2(0.0, 0.0);
+            EP[r] = 0.0;
             double2 po = make_double2(0.0, 0.0);
             C[r] = value_row(lk0, j, &po);
-            EC[r] = (W15 || own) ? edge_value(lk0, j) : 0.0;
             if (own) own_update(lk0, j, C[r], po);
         }
+        if (W15) plane_edges(lk0 - 1, P, EP, true);
+        plane_edges(lk0, C, EC, W15);
 
         // K1 keeps p_n valid on the ghost planes of the slab (same formula, same inputs as the neighbour rank)
         auto ghost_store = [&](int lk, const double2* rows) {
@@ -317,9 +372,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 const int j = j0 - 1 + r;
                 PO[r] = make_double2(0.0, 0.0);
                 N[r] = value_row(lk + 1, j, &PO[r]);
-                const bool own = (r >= 1) && (r <= RY);
-                EN[r] = (W15 || own) ? edge_value(lk + 1, j) : 0.0;
             }
+            if (!EX) plane_edges(lk + 1, N, EN, W15);          // global edge loads: issue them with the plane's loads
             double2 RHS[RY];
             if (RES) {
 #pragma unroll
@@ -331,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 }
             }
 
+            if (EX) plane_edges(lk + 1, N, EN, W15);           // LDS hand-off of the new plane's tile-edge values
             // ---- stencil of plane lk -----------------------------------------------------------
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
@@ -421,17 +476,17 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     return fg;
 }
 
-template <int NPT, int RY, int NT>
+template <int NPT, int RY, int NT, int EX>
 int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     static int occ[4] = {0, 0, 0, 0};   // resident workgroups per CU of each instantiation
     if (occ[mode] == 0) {
         int nb = 0;
         hipError_t e = hipSuccess;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT>, 256, 0); break;
-            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K2, NT>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT, EX>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX>, 256, 0); break;
+            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K2, NT, EX>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT, EX>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
         if (nb > 8) nb = 8;
@@ -444,10 +499,10 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     if (li) { li->grid = G; li->block = 256; }
     if (G == 0) return PDEGPU_OK;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -457,11 +512,19 @@ template <int NPT, int RY>
 int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     int nt = ctx->fast_nt;
     if (nt < 0) nt = ((long long)a.g.nkl * a.g.PP * 8 > (64LL << 20)) ? 3 : 0;
+    // the LDS edge hand-off pays in the CG kernels (K1 / K2: measured -3 % / -15 %); the bare apply and the residual
+    // pass do less work per z-step and lose to the extra barrier (measured +5 %)
+    if (ctx->fast_ex && (mode == APPLY_CG_K1 || mode == APPLY_CG_K2)) {
+        switch (nt & 3) {
+            case 3: return launch_fast<NPT, RY, 3, 1>(ctx, a, mode, li);
+            default: return launch_fast<NPT, RY, 0, 1>(ctx, a, mode, li);
+        }
+    }
     switch (nt & 3) {
-        case 1: return launch_fast<NPT, RY, 1>(ctx, a, mode, li);
-        case 2: return launch_fast<NPT, RY, 2>(ctx, a, mode, li);
-        case 3: return launch_fast<NPT, RY, 3>(ctx, a, mode, li);
-        default: return launch_fast<NPT, RY, 0>(ctx, a, mode, li);
+        case 1: return launch_fast<NPT, RY, 1, 0>(ctx, a, mode, li);
+        case 2: return launch_fast<NPT, RY, 2, 0>(ctx, a, mode, li);
+        case 3: return launch_fast<NPT, RY, 3, 0>(ctx, a, mode, li);
+        default: return launch_fast<NPT, RY, 0, 0>(ctx, a, mode, li);
     }
 }
 

@@ -271,9 +271,9 @@ __host__ __device__ inline double pg_mono(int d, const int* e) {
 }
 
 // row of node (i, j, k): rowK[15], rowM[15] (positions of the 15-offset list) and the load entry int w phi_i
-__host__ __device__ inline void weighted_row(int dim, const int* nn /*node counts*/, const double* origin, const double* h, int kind,
-                                             double core_radius, double core_ratio, int i, int j, int k, double* rowK,
-                                             double* rowM, double* load) {
+__host__ __device__ inline void weighted_row(int dim, const int* nn /*node counts*/, const double* origin, const double* h,
+                                             const double* lengths, int kind, double core_radius, double core_ratio, int i,
+                                             int j, int k, double* rowK, double* rowM, double* load) {
     for (int q = 0; q < PG_NOFF15; ++q) { rowK[q] = 0.0; rowM[q] = 0.0; }
     *load = 0.0;
     const int idx3[3] = {i, j, k};
@@ -297,9 +297,13 @@ __host__ __device__ inline void weighted_row(int dim, const int* nn /*node count
             double g[4][3], vol;
             simplex_grads(dim, verts, h, g, &vol);
             // vertex coordinates and the interpolated weight as sum_t coef_t * prod lambda^{exp_t}
+            // vertex coordinates exactly as the mesh generators form them, a + (b - a) * i / n (mul, div, add: the same
+            // IEEE operations as the oracle, so borderline `r < core_radius` tests agree bit for bit)
             double X[4][3];
             for (int p = 0; p <= dim; ++p)
-                for (int r = 0; r < 3; ++r) X[p][r] = r < dim ? origin[r] + (c0[r] + ((verts[p] >> r) & 1)) * h[r] : 0.0;
+                for (int r = 0; r < 3; ++r) {
+                    X[p][r] = r < dim ? origin[r] + (lengths[r] * (double)(c0[r] + ((verts[p] >> r) & 1))) / (double)(nn[r] - 1) : 0.0;
+                }
             double coef[14];
             int expo[14][4];
             int nt = 0;

@@ -26,7 +26,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-struct WeightGeom { double origin[3], h[3], core_radius, core_ratio; };
+struct WeightGeom { double origin[3], h[3], lengths[3], core_radius, core_ratio; };
 
 __global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom wg, int kind, double cM, double cK,
                                                             double* __restrict__ ellA, double* __restrict__ ellM,
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom
         const int k = g.k0 + (int)(row / g.NY);
         double rowK[PG_NOFF15], rowM[PG_NOFF15], ld = 0.0;
         if (i < g.NX) {
-            weighted_row(g.dim, nn, wg.origin, wg.h, kind, wg.core_radius, wg.core_ratio, i, j, k, rowK, rowM, &ld);
+            weighted_row(g.dim, nn, wg.origin, wg.h, wg.lengths, kind, wg.core_radius, wg.core_ratio, i, j, k, rowK, rowM, &ld);
         } else {
             for (int q = 0; q < PG_NOFF15; ++q) rowK[q] = rowM[q] = 0.0;
         }
@@ -89,10 +89,10 @@ inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
 
 }  // namespace
 
-int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, double cM, double cK,
-                      double* ellA, double* ellM, double* dinv, long long stride) {
+int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, const double* lengths, double cM,
+                      double cK, double* ellA, double* ellM, double* dinv, long long stride) {
     WeightGeom wg{};
-    for (int r = 0; r < 3; ++r) { wg.origin[r] = w->origin[r]; wg.h[r] = h[r]; }
+    for (int r = 0; r < 3; ++r) { wg.origin[r] = w->origin[r]; wg.h[r] = h[r]; wg.lengths[r] = lengths[r]; }
     wg.core_radius = w->core_radius;
     wg.core_ratio = w->core_ratio;
     const int kind = w->kind;
@@ -122,18 +122,19 @@ extern "C" int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const pdegpu_w
     if (kind < PDEGPU_WEIGHT_R || kind > PDEGPU_WEIGHT_RCYL) return PDEGPU_EINVAL;
     if (kind == PDEGPU_WEIGHT_R2SIN && grid->dim < 2) return PDEGPU_EINVAL;
     if (kind == PDEGPU_WEIGHT_RCYL && grid->dim < 3) return PDEGPU_EINVAL;
-    double h[3] = {1, 1, 1};
+    double h[3] = {1, 1, 1}, lengths[3] = {0, 0, 0};
     int nn[3] = {1, 1, 1};
     for (int r = 0; r < grid->dim; ++r) {
         if (grid->n[r] < 1 || !(grid->L[r] > 0)) return PDEGPU_EINVAL;
         h[r] = grid->L[r] / grid->n[r];
+        lengths[r] = grid->L[r];
         nn[r] = grid->n[r] + 1;
     }
     long long idx = 0;
     for (int k = 0; k < nn[2]; ++k)
         for (int j = 0; j < nn[1]; ++j)
             for (int i = 0; i < nn[0]; ++i, ++idx)
-                weighted_row(grid->dim, nn, origin, h, kind, weight->core_radius, weight->core_ratio, i, j, k, rowsK + idx * 15, rowsM + idx * 15,
+                weighted_row(grid->dim, nn, origin, h, lengths, kind, weight->core_radius, weight->core_ratio, i, j, k, rowsK + idx * 15, rowsM + idx * 15,
                              load + idx);
     return PDEGPU_OK;
 }

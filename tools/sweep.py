@@ -17,15 +17,14 @@ grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0))
 N = (n - 1) ** 3
 
 configs = []
-base = dict(fast_ry=2, fast_nt=-1, fast_wg_per_cu=0, k2_variant=0, grid_mult=8, k2_grid_mult=2, cg_variant=1)
-for rep in range(2):
-    for ry, wg, nt in ((2, 0, -1), (2, 3, -1), (2, 4, -1), (2, 5, -1), (2, 6, -1), (2, 7, -1), (2, 8, -1), (2, 4, 0), (2, 8, 0), (2, 8, 1),
-                       (4, 4, -1), (4, 4, 0), (4, 3, -1), (8, 2, -1), (8, 3, -1), (8, 4, -1), (1, 8, -1)):
-        configs.append(dict(base, fast_ry=ry, fast_wg_per_cu=wg, fast_nt=nt))
+base = dict(fast_ry=2, fast_nt=-1, fast_wg_per_cu=0, k2_variant=0, grid_mult=8, k2_grid_mult=2, cg_variant=1, fast_ex=0)
+for rep in range(3):
+    for ex in (0, 1):
+        configs.append(dict(base, fast_ex=ex))
 if len(sys.argv) > 3:
     configs = [dict(base, **eval(sys.argv[3]))]
 
-for steady in (1,):
+for steady in (1, 0):
     for cfg in configs:
         for k, v in cfg.items():
             L.check(ctx, lib.pdegpu_set_tunable(ctx, k.encode(), v))
@@ -40,14 +39,14 @@ for steady in (1,):
         L.check(ctx, lib.pdegpu_session_reduce_local(s, 1, 1))
         L.check(ctx, lib.pdegpu_session_iterate(s, 4, 0, None))
         st = L.Stats()
-        L.check(ctx, lib.pdegpu_session_iterate(s, 6, 1, st)); iters = 6
+        L.check(ctx, lib.pdegpu_session_iterate(s, 20, 1, st)); iters = 20
         rr = C.c_double()
         L.check(ctx, lib.pdegpu_session_rr(s, C.byref(rr)))
         ms = C.c_double()
         L.check(ctx, lib.pdegpu_session_time_apply(s, 30, C.byref(ms)))
         k1, k2 = st.kernel_ms[0] / iters, st.kernel_ms[1] / iters
         tot = (k1 + k2)
-        print(f"steady={steady} cv={cfg['cg_variant']} ry={cfg['fast_ry']}: K1+K2 {tot:.3f} ms -> {N/tot/1e6:.1f} GDoF/s | K1 {k1:.3f} ms {48*N/k1/1e6:6.0f} GB/s | K2 {k2:.3f} ms {24*N/k2/1e6:6.0f} GB/s | "
+        print(f"steady={steady} ex={cfg['fast_ex']}: K1+K2 {tot:.3f} ms -> {N/tot/1e6:.1f} GDoF/s | K1 {k1:.3f} ms {48*N/k1/1e6:6.0f} GB/s | K2 {k2:.3f} ms {24*N/k2/1e6:6.0f} GB/s | "
               f"SpMV {ms.value:.3f} ms {16*N/ms.value/1e6:6.0f} GB/s | rr {rr.value:.9e}", flush=True)
         if False:
             names = ["copy 1R+1W", "read 1R", "write 1W", "triad 2R+1W", "inplace 2R+1W"]
