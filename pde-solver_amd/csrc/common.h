@@ -30,6 +30,7 @@ struct pdegpu_ctx {
     int use_graph = 0;          // opt-in: replay the CG inner loop from a captured hipGraph.  Measured: no gain (the small
                                 // configs are bound by kernel time, not launches) and rocprofv3 7.2 crashes on graph launches
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
+    int direct_1d = 1;          // 1-D grids: 1 = Thomas recurrence inside one launch (tridiag.hip); 0 = the CG path (diagnostic)
     int k2_grid_mult = 2;       // K2: workgroups per CU (few, deep streams beat many shallow ones on mixed R/W)
     std::string err;
     char name[256] = {0};
@@ -211,6 +212,12 @@ int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const 
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense
 int vec_unpack(pdegpu_ctx* ctx, const GridDev& g, const double* dense, double* v);   // dense -> pitched
+
+// tridiag.hip: direct solver of the 1-D tools
+int tridiag_setup(pdegpu_ctx* ctx, const GridDev& g, const double* tabA, const double* tabM, const double* ellA,
+                  const double* ellM, long long ell_stride, double* rows /*device [8][NX]*/);
+int tridiag_run(pdegpu_ctx* ctx, int N, const double* rows, double* work /*device [3][N]*/, double* u, double shift, int rhs_given,
+                int nsteps, int step0, int total_steps, int stride, double* snaps);
 
 GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0, int64_t nk);
 int validate_grid(pdegpu_ctx* ctx, const pdegpu_grid* grid);

@@ -293,7 +293,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -315,6 +315,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "use_graph")) return &ctx->use_graph;
     if (!strcmp(key, "inlaunch_dot")) return &ctx->inlaunch_dot;
     if (!strcmp(key, "el_grid_mult")) return &ctx->el_grid_mult;
+    if (!strcmp(key, "direct_1d")) return &ctx->direct_1d;
     return nullptr;
 }
 }  // namespace
@@ -797,6 +798,73 @@ extern "C" int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* gr
     return heat_solve_impl(ctx, grid, heat_in, weight, nullptr, values_out, times_out, stats);
 }
 
+
+namespace {
+// 1-D grids: factor the tridiagonal once, run all backward-Euler steps inside one launch per batch of snapshots
+// (tridiag.hip).  `s->x` holds u^0 with the boundary values imposed (transient) or is overwritten (steady / project).
+struct TriBuffers {
+    double* rows = nullptr;
+    double* work = nullptr;
+    double* snaps = nullptr;
+    ~TriBuffers() {
+        if (rows) (void)hipFree(rows);
+        if (work) (void)hipFree(work);
+        if (snaps) (void)hipFree(snaps);
+    }
+};
+
+int tri_prepare(pdegpu_session* s, TriBuffers* tb) {
+    pdegpu_ctx* ctx = s->ctx;
+    const size_t N = (size_t)s->g.NX;
+    PG_HIP(ctx, hipMalloc(&tb->rows, 8 * N * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&tb->work, 3 * N * sizeof(double)));
+    return tridiag_setup(ctx, s->g, s->tabs.d_tabA, s->tabs.d_tabM, s->weighted ? s->ellA : nullptr, s->weighted ? s->ellM : nullptr,
+                         s->ell_stride, tb->rows);
+}
+
+int heat_1d_direct(pdegpu_session* s, const pdegpu_heat& heat, double* values_out, double* times_out, pdegpu_stats* st) {
+    pdegpu_ctx* ctx = s->ctx;
+    const int N = s->g.NX;
+    TriBuffers tb;
+    PG_TRY(tri_prepare(s, &tb));
+    st->path = 2;
+    if (heat.steady) {
+        PG_HIP(ctx, hipMemsetAsync(s->x.v, 0, (size_t)N * sizeof(double), ctx->stream));      // b = M (0 + f)
+        PG_TRY(tridiag_run(ctx, N, tb.rows, tb.work, s->x.v, heat.source, 0, 1, 0, 1, 1, nullptr));
+        PG_HIP(ctx, hipMemcpyAsync(values_out, s->x.v, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        times_out[0] = 0.0;
+        st->linear_solves += 1;
+        return PDEGPU_OK;
+    }
+    PG_HIP(ctx, hipMemcpyAsync(values_out, s->x.v, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    times_out[0] = 0.0;
+    const int stride = heat.snapshot_stride, total = heat.num_steps;
+    // snapshots of one launch stay on the device until the launch ends: at most 256 MiB of them per batch
+    const long long per_batch_snaps = std::max<long long>(1, (256LL << 20) / ((long long)N * 8));
+    const int batch_steps = (int)std::min<long long>(total > 0 ? total : 1, per_batch_snaps * stride);
+    PG_HIP(ctx, hipMalloc(&tb.snaps, (size_t)per_batch_snaps * N * sizeof(double)));
+    int snap = 1;
+    for (int done = 0; done < total;) {
+        const int n = std::min(batch_steps, total - done);
+        int nsnap = 0;
+        for (int q = done + 1; q <= done + n; ++q)
+            if (q % stride == 0 || q == total) ++nsnap;
+        PG_TRY(tridiag_run(ctx, N, tb.rows, tb.work, s->x.v, heat.dt * heat.source, 0, n, done, total, stride, tb.snaps));
+        if (nsnap)
+            PG_HIP(ctx, hipMemcpyAsync(values_out + (size_t)snap * N, tb.snaps, (size_t)nsnap * N * sizeof(double), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int q = done + 1; q <= done + n; ++q)
+            if (q % stride == 0 || q == total) times_out[snap++] = q * heat.dt;
+        done += n;
+        st->linear_solves += n;
+    }
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PDEGPU_OK;
+}
+}  // namespace
+
 namespace {
 int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat_in, const pdegpu_weight* weight,
                     const double* u0, double* values_out, double* times_out, pdegpu_stats* stats) {
@@ -858,7 +926,10 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
         st.n_unknowns = nfree;
     }
 
-    if (heat.steady) {
+    const bool direct = grid->dim == 1 && ctx->direct_1d != 0;
+    if (direct && heat.steady) {
+        rc = heat_1d_direct(s, heat, values_out, times_out, &st);
+    } else if (heat.steady) {
         rc = pdegpu_session_begin(s, 0.0);
         if (rc == PDEGPU_OK) rc = linear_solve(s, true, &st);
         if (rc == PDEGPU_OK || rc == PDEGPU_ENOCONV) {
@@ -878,11 +949,13 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
         }
         const int stride = heat.snapshot_stride;
         int snap = 0;
-        if (rc == PDEGPU_OK) {
+        if (direct) {
+            if (rc == PDEGPU_OK) rc = heat_1d_direct(s, heat, values_out, times_out, &st);
+        } else if (rc == PDEGPU_OK) {
             rc = get_vec(s, s->x.v, values_out);
             times_out[snap++] = 0.0;
         }
-        for (int n = 0; n < heat.num_steps && rc == PDEGPU_OK; ++n) {
+        for (int n = 0; !direct && n < heat.num_steps && rc == PDEGPU_OK; ++n) {
             // b = M (u^n + dt f)   — `u_n*v*dx + dt*f*v*dx` (:305, :434, :703)
             rc = op_plain(s, 1, s->x.v, heat.dt * heat.source, s->b.v, 0);
             if (rc == PDEGPU_OK) rc = linear_solve(s, false, &st);
@@ -928,6 +1001,25 @@ extern "C" int pdegpu_mass_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const
     pdegpu_stats st{};
     st.converged = 1;
     st.n_nodes = st.n_unknowns = pdegpu_grid_num_nodes(grid);
+    if (rc == PDEGPU_OK && grid->dim == 1 && ctx->direct_1d != 0) {
+        // 1-D: tridiagonal M, Thomas recurrence in one launch; the right-hand side goes straight into the scratch row
+        auto direct = [&]() -> int {
+            const int N = s->g.NX;
+            TriBuffers tb;
+            PG_TRY(tri_prepare(s, &tb));
+            PG_HIP(ctx, hipMemcpyAsync(tb.work + 2 * (size_t)N, rhs, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            PG_TRY(tridiag_run(ctx, N, tb.rows, tb.work, s->x.v, 0.0, 1, 1, 0, 1, 1, nullptr));
+            PG_HIP(ctx, hipMemcpyAsync(s_out, s->x.v, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return PDEGPU_OK;
+        };
+        rc = direct();
+        st.path = 2;
+        st.linear_solves = 1;
+        pdegpu_session_destroy(s);
+        if (stats) *stats = st;
+        return rc;
+    }
     if (rc == PDEGPU_OK) rc = put_vec(s, rhs, s->b.v);
     if (rc == PDEGPU_OK) rc = vec_zero(ctx, s->g, &s->x);
     if (rc == PDEGPU_OK) rc = linear_solve(s, true, &st);

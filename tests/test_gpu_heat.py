@@ -99,6 +99,38 @@ def test_heat_1d_config1_matches_oracle(lib, gpu_ctx):
     assert st.times.tolist() == [0.0] and st.meta["steady"] is True
 
 
+def test_heat_1d_direct_tridiagonal_path(lib, gpu_ctx, monkeypatch):
+    """1-D grids run the Thomas recurrence inside one launch (csrc/tridiag.hip): same fields as the CG path
+    (PDEGPU_DIRECT_1D=0) and the oracle; grids longer than one LDS chunk (1024 nodes); snapshot stride; the config-1
+    known answers of SURVEY §8c(iii) at full length"""
+    from pdegpu import heat, _lib
+    full = heat._solve_heat_1d_raw(2.0, 1000, 1.0, 20.0, 0.0, 0.0, 0.01, 200)
+    assert full.meta["solver_path"] == "tridiagonal-direct" and full.meta["cg_iterations"] == 0
+    assert full.values.shape == (201, 1001)
+    for (t, i), want in {(200, 250): 14.931253742, (200, 500): 9.902778170, (200, 750): 4.931253827, (50, 500): 6.236415842}.items():
+        assert abs(full.values[t, i] - want) < 5e-9
+    # longer than four chunks, trigonometric IC (project -> 1-D mass solve, also direct), source term
+    kw = dict(source_type="constant", source_value=2.5, initial_type="cosine", initial_amplitude=3.0, initial_wavenumber=2.0)
+    got = heat._solve_heat_1d_raw(1.5, 4500, 0.3, 1.0, -2.0, 0.0, 0.02, 6, **kw)
+    ref = o.solve_heat_1d(1.5, 4500, 0.3, 1.0, -2.0, 0.0, 0.02, 6, **kw)
+    assert rel_err(got.values, ref.values) < TOL
+    # the CG path on the same problem
+    ctx = _lib.context(0)
+    _lib.check(ctx, lib.pdegpu_set_tunable(ctx, b"direct_1d", 0))
+    try:
+        cg = heat._solve_heat_1d_raw(1.5, 4500, 0.3, 1.0, -2.0, 0.0, 0.02, 6, rtol=1e-13, **kw)
+    finally:
+        _lib.check(ctx, lib.pdegpu_set_tunable(ctx, b"direct_1d", 1))
+    assert cg.meta["solver_path"] == "general" and cg.meta["cg_iterations"] > 0
+    assert rel_err(got.values, cg.values) < TOL
+    # stride 4 over 10 steps: snapshots 0, 4, 8, 10
+    monkeypatch.setenv("PDEGPU_SNAPSHOT_STRIDE", "4")
+    st = heat._solve_heat_1d_raw(2.0, 50, 1.0, 20.0, 0.0, 5.0, 0.01, 10)
+    monkeypatch.delenv("PDEGPU_SNAPSHOT_STRIDE")
+    every = heat._solve_heat_1d_raw(2.0, 50, 1.0, 20.0, 0.0, 5.0, 0.01, 10)
+    assert np.allclose(st.times, [0.0, 0.04, 0.08, 0.1]) and np.array_equal(st.values, every.values[[0, 4, 8, 10]])
+
+
 @pytest.mark.parametrize("steady", [False, True])
 def test_heat_2d_matches_oracle(lib, gpu_ctx, steady):
     from pdegpu import heat
