@@ -30,6 +30,11 @@ struct pdegpu_ctx {
     int use_graph = 0;          // opt-in: replay the CG inner loop from a captured hipGraph.  Measured: no gain (the small
                                 // configs are bound by kernel time, not launches) and rocprofv3 7.2 crashes on graph launches
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
+    int el_fast = 1;            // 3-D elasticity: 1 = z-marching block stencil (k_el_fast); 0 = thread-per-node class-table kernel
+    int el_fast_ry = 1;         // rows per wavefront column of k_el_fast (1 | 2)
+    int el_fast_waves = 2048;   // wavefronts the marching part aims for (sets the z-chunk length)
+    int lazy_dot = 1;           // single-slab CG loops: 1 = the next kernel's prologue sums the previous launch's partials (no reduce
+                                // launches); 0 = one-workgroup k_reduce launch after every dot-producing kernel
     int direct_1d = 1;          // 1-D grids: 1 = Thomas recurrence inside one launch (tridiag.hip); 0 = the CG path (diagnostic)
     int k2_grid_mult = 2;       // K2: workgroups per CU (few, deep streams beat many shallow ones on mixed R/W)
     std::string err;
@@ -136,6 +141,20 @@ void tables_free(HeatTables* t);
 // ------------------------------------------------------------------------------------------------
 enum ApplyMode { APPLY_PLAIN = 0, APPLY_RESIDUAL = 1, APPLY_CG_K1 = 2, APPLY_CG_K2 = 3 };
 
+// device scalar block used by the CG kernels
+enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_COUNT = 8 };
+
+// where a CG kernel finds the dot product of the launch before it.  part == nullptr: already reduced, rr_n in
+// scal[s_rr], rr_{n-1} in scal[s_rr_old], p.q in scal[SC_PQ] (the eager protocol of the multi-GPU driver: SC_RR /
+// SC_RR_PREV).  part != nullptr: the n per-workgroup partials of the previous launch, summed in the kernel prologue
+// (dot_finish.h); workgroup 0 records the sum (K1: rr_n -> scal[s_rr], a slot nobody reads in that launch; K2: -> SC_PQ).
+struct DotIn {
+    const double* part = nullptr;
+    int n = 0;
+    int s_rr = SC_RR;
+    int s_rr_old = SC_RR_PREV;
+};
+
 struct StencilArgs {
     GridDev g;
     const double* tabA;       // device [27][27] class table (general path)
@@ -154,12 +173,10 @@ struct StencilArgs {
     int npt;                  // 7 or 15 (fast path)
     unsigned* counter;        // dot_finish ticket counter (device word)
     int dot_which;            // 0: p.q, 1: r.r (the kernel completes the dot product itself), -1: partials only
+    DotIn di;                 // CG_K1 / CG_K2: how the previous launch's dot product arrives
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
 };
-
-// device scalar block used by the CG kernels
-enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_COUNT = 8 };
 
 struct LaunchInfo { int grid = 0; int block = 256; };
 
@@ -200,7 +217,9 @@ int vec_zero(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
 int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const double* nodal_dense, int only_bc);
 int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal);
 int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, unsigned* counter,
-           LaunchInfo* li);
+           LaunchInfo* li, const DotIn& di = DotIn());
+// which: 0 p.q -> SC_PQ(_LOCAL); 1 r.r -> SC_RR_PREV <- SC_RR, SC_RR(_LOCAL); 2 r.r -> SC_RR(_LOCAL) only (SC_RR_PREV
+// already holds the previous value: end of a lazy chunk whose current slot is SC_RR_PREV)
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
 // weighted.hip

@@ -25,6 +25,52 @@ __device__ __forceinline__ double df_wave_sum(double v) {
     return v;
 }
 
+// Prologue completion of the PREVIOUS launch's dot product (DotIn, common.h): every workgroup of the consuming kernel
+// sums all partials in the order k_reduce uses (per-thread stride 256, 64-lane shuffle tree, (s0+s1)+(s2+s3)), so every
+// workgroup holds the bitwise identical scalar and no reduce launch is needed; the partials (a few KB) come from L2.
+// All 256 threads must call; sRed: >= 4 doubles of LDS.
+__device__ __forceinline__ double dot_in_sum(const double* __restrict__ part, int n, double* sRed) {
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += 256) acc += part[e];
+    acc = df_wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+}
+// K1 side: rr_n (summed here or read from its slot), rr_{n-1}, pq_{n-1} -> alpha_{n-1}, beta_{n-1}
+__device__ __forceinline__ void cg_scalars_in(const DotIn& di, double* scal, double* sRed, double* alpha_prev, double* beta) {
+    double rr;
+    if (di.part) {
+        rr = dot_in_sum(di.part, di.n, sRed);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal[di.s_rr] = rr;
+            scal[SC_RR_LOCAL] = rr;
+        }
+    } else {
+        rr = scal[di.s_rr];
+    }
+    const double pq = scal[SC_PQ], rr_prev = scal[di.s_rr_old];
+    // alpha_{n-1} = rr_{n-1} / (p_{n-1}.q_{n-1}),  beta_{n-1} = rr_n / rr_{n-1};  both 0 on the first iteration
+    *alpha_prev = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
+    *beta = (rr_prev > 0.0) ? rr / rr_prev : 0.0;
+}
+// K2 side: alpha_n = rr_n / (p_n.q_n), p_n.q_n summed here or read from SC_PQ
+__device__ __forceinline__ double cg_alpha_in(const DotIn& di, double* scal, double* sRed) {
+    double pq;
+    if (di.part) {
+        pq = dot_in_sum(di.part, di.n, sRed);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal[SC_PQ] = pq;
+            scal[SC_PQ_LOCAL] = pq;
+        }
+    } else {
+        pq = scal[SC_PQ];
+    }
+    const double rr = scal[di.s_rr];
+    return (pq > 0.0) ? rr / pq : 0.0;
+}
+
 // block_total is valid in thread 0.  sRed: >= 4 doubles of LDS.  All 256 threads must call.
 __device__ __forceinline__ void dot_finish(double block_total, const DotSink& d, double* sRed) {
     __shared__ int sLast;

@@ -33,7 +33,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm) {
 }
 
 __global__ __launch_bounds__(256) void k_el_tables(int dim, double hx, double hy, double hz, double lam, double mu,
-                                                    double* __restrict__ tab /*[27][15][9]*/, double* __restrict__ dinv /*[27][3]*/) {
+                                                    double* __restrict__ tab /*[27][15][9]*/, double* __restrict__ dinv /*[27][3]*/,
+                                                    unsigned* __restrict__ mask /*[27] nonzero blocks*/) {
     const double h[3] = {hx, hy, hz};
     for (int e = threadIdx.x; e < 27 * PG_NOFF15; e += blockDim.x) {
         double blk[9];
@@ -41,6 +42,17 @@ __global__ __launch_bounds__(256) void k_el_tables(int dim, double hx, double hy
         for (int t = 0; t < 9; ++t) tab[e * 9 + t] = blk[t];
         if (e % PG_NOFF15 == 0)
             for (int a = 0; a < 3; ++a) dinv[(e / PG_NOFF15) * 3 + a] = blk[a * 3 + a] > 0.0 ? 1.0 / blk[a * 3 + a] : 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        unsigned m = 0;
+        for (int q = 0; q < PG_NOFF15; ++q) {
+            bool nz = false;
+            for (int t = 0; t < 9; ++t) nz |= tab[(threadIdx.x * PG_NOFF15 + q) * 9 + t] != 0.0;
+            if (nz) m |= 1u << q;
+        }
+        mask[threadIdx.x] = m;
     }
 }
 
@@ -59,7 +71,20 @@ struct ElArgs {
     double* partials;
     double* partials2;
     int mask_dirichlet;
+    // lazy dot products (same scheme as DotIn of the heat path): non-null = per-workgroup partials of the previous launch,
+    // summed in this kernel's prologue.  p-update: r.z (din) and r.r (din2) of K2;  K2: p.q (din) of the block apply.
+    const double* din = nullptr;
+    const double* din2 = nullptr;
+    int din_n = 0;
+    int s_rz = 1, s_rz_old = 3;     // ESC_RZ / ESC_RZ_PREV: slots of r.z of this and of the previous iteration
 };
+
+// fixed-order sum of n partials by all 256 threads (identical in every workgroup; the order k_el_reduce uses)
+__device__ __forceinline__ double el_sum_in(const double* __restrict__ part, int n, double* sRed) {
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += 256) acc += part[e];
+    return block_sum_256(acc, sRed);
+}
 
 // block weights of the interior boundary class, passed BY VALUE: kernel arguments live in the kernarg segment and are
 // fetched with scalar loads, so interior wavefronts read their 15 x 9 weights from SGPRs (a pointer inside ElArgs
@@ -171,6 +196,210 @@ __global__ __launch_bounds__(256) void k_el_apply(ElArgs a, ElInterior wi) {
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3-D fast apply: z-marching block stencil for the interior class + the boundary nodes in the same launch
+// ---------------------------------------------------------------------------------------------------------------
+// On interior nodes of the uniform Kuhn split the 15 blocks are symmetric, B(-o) = B(o), and the four diagonal
+// offsets have a zero diagonal (el_fast_weights checks this on the host table before the path is enabled), so
+//   y_i = C u_i + sum_{7 offsets o} B_o (u_{i+o} + u_{i-o})
+// needs 36 distinct weights (72 SGPRs, fetched from the kernarg segment) and 60 FMAs instead of 135.  One wavefront
+// owns a 62-node x RY-row column (lanes 0 and 63 only carry the x-halo, so no edge exchange exists), marches along z
+// with three planes of RY+2 rows x 3 components in registers, and takes its x-neighbours from DPP wave shifts: 9 (RY=1)
+// or 6 (RY=2) coalesced loads per node instead of 45.  Boundary nodes (traction-free faces, the clamped face, 7 % of
+// config 5) are enumerated analytically and handled by extra workgroups of the same launch with the class table in LDS.
+struct ElW36 {
+    double c[6];        // centre block: xx yy zz xy xz yz
+    double ax[3][6];    // offsets (1,0,0) (0,1,0) (0,0,1)
+    double dg[4][3];    // offsets (1,1,0) (1,0,1) (0,1,1) (1,1,1): xy xz yz (zero diagonal)
+};
+struct ElFastGeom {
+    int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
+    int lkb, lke;              // local interior plane range [lkb, lke)
+    int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
+    int nb_bnd;                // boundary workgroups (launched first so that their short tail overlaps the marching part)
+    int full_lo, full_hi;      // 1: this slab owns the global plane 0 / NZ-1 (all of its nodes are boundary nodes)
+    int ring;                  // boundary nodes of an interior plane: 2 NX + 2 (NY - 2)
+    long long nbnd;            // boundary nodes of the slab
+    const unsigned* mask;      // [27] nonzero-block masks of the class table
+};
+
+__device__ __forceinline__ double el_dpp_lower(double v) {     // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double el_dpp_upper(double v) {     // lane l <- lane l+1 (v_mov_b32_dpp wave_shl:1)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void el_sym6(const double* b, const double* v, double* y) {
+    y[0] += b[0] * v[0] + b[3] * v[1] + b[4] * v[2];
+    y[1] += b[3] * v[0] + b[1] * v[1] + b[5] * v[2];
+    y[2] += b[4] * v[0] + b[5] * v[1] + b[2] * v[2];
+}
+__device__ __forceinline__ void el_off3(const double* b, const double* v, double* y) {
+    y[0] += b[0] * v[1] + b[1] * v[2];
+    y[1] += b[0] * v[0] + b[2] * v[2];
+    y[2] += b[1] * v[0] + b[2] * v[1];
+}
+
+template <int RY>
+__global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom fg) {
+    __shared__ double sTab[27 * PG_NOFF15 * 9];
+    __shared__ unsigned sMask[27];
+    __shared__ double sRed[4];
+    constexpr int RH = RY + 2;
+    const GridDev& g = a.g;
+    double acc = 0.0;
+    if ((int)blockIdx.x < fg.nb_bnd) {
+        // ---- boundary nodes: one thread per node, truncated class stencils from LDS -----------------------------
+        for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
+        if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
+        __syncthreads();
+        long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (e < fg.nbnd) {
+            int i, j, lk;
+            const long long plane_nodes = (long long)g.NX * g.NY;
+            if (fg.full_lo && e < plane_nodes) {
+                lk = -g.k0;                                   // global plane 0
+                j = (int)(e / g.NX);
+                i = (int)(e % g.NX);
+            } else {
+                e -= fg.full_lo ? plane_nodes : 0;
+                if (fg.full_hi && e < plane_nodes) {
+                    lk = g.NZ - 1 - g.k0;
+                    j = (int)(e / g.NX);
+                    i = (int)(e % g.NX);
+                } else {
+                    e -= fg.full_hi ? plane_nodes : 0;
+                    lk = fg.lkb + (int)(e / fg.ring);
+                    const int t = (int)(e % fg.ring);
+                    if (t < g.NX) { j = 0; i = t; }
+                    else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
+                    else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
+                }
+            }
+            const int kg = g.k0 + lk;
+            const long long idx = (long long)lk * g.PP + (long long)j * g.PX + i;
+            double dval;
+            const bool dir = a.mask_dirichlet && pg_dirichlet(g, i, j, kg, &dval);
+            double s[3] = {0.0, 0.0, 0.0};
+            if (!dir) {
+                const int cls = pg_axis_class(i, g.NX) + 3 * pg_axis_class(j, g.NY) + 9 * pg_axis_class(kg, g.NZ);
+                const double* wtab = &sTab[cls * PG_NOFF15 * 9];
+                const unsigned m = sMask[cls];
+#pragma unroll
+                for (int q = 0; q < PG_NOFF15; ++q) {
+                    if (!((m >> q) & 1u)) continue;
+                    const int o = pg_off15(q);
+                    const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+                    const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
+                    const double* blk = wtab + q * 9;
+                    const double v0 = a.in[nb], v1 = a.in[a.stride + nb], v2 = a.in[2 * a.stride + nb];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) s[r] += blk[r * 3] * v0 + blk[r * 3 + 1] * v1 + blk[r * 3 + 2] * v2;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a.out[c * a.stride + idx] = s[c];
+                acc += a.in[c * a.stride + idx] * s[c];
+            }
+        }
+    } else {
+        // ---- interior nodes: z-marching ------------------------------------------------------------------------
+        const int lane = threadIdx.x & 63;
+        const int wid = ((int)blockIdx.x - fg.nb_bnd) * 4 + (threadIdx.x >> 6);
+        const int xt = wid % fg.ntx, yt = (wid / fg.ntx) % fg.nty, zc = wid / (fg.ntx * fg.nty);
+        const int i = xt * 62 + lane;                         // lanes 0 and 63: x-halo only
+        const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
+        const int lk0 = fg.lkb + zc * fg.zlen;
+        const int lk1 = min(lk0 + fg.zlen, fg.lke);
+        if (zc < fg.nzc && lk0 < lk1) {
+            const bool ld_ok = i < g.PX;
+            const bool out_x = lane >= 1 && lane <= 62 && i <= g.NX - 2;
+            bool row_ld[RH], row_out[RH];
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                row_ld[r] = ld_ok && (j0 - 1 + r) <= g.NY - 1;
+                row_out[r] = out_x && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
+            }
+            const long long col = (long long)(j0 - 1) * g.PX + i;
+            double Pm[RH][3], P0[RH][3], Pp[RH][3];
+            auto load_plane = [&](int lk, double (*P)[3]) {
+                const long long base = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 0; r < RH; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[r][c] = row_ld[r] ? a.in[c * a.stride + base + (long long)r * g.PX] : 0.0;
+            };
+            load_plane(lk0 - 1, Pm);
+            load_plane(lk0, P0);
+            for (int lk = lk0; lk < lk1; ++lk) {
+                load_plane(lk + 1, Pp);
+                // x-shifted copies: up = value at i+1, lo = value at i-1
+                double P0up[RH][3], P0lo[RH][3], Ppup[RH][3], Pmlo[RH][3];
+#pragma unroll
+                for (int r = 0; r < RH; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        P0up[r][c] = el_dpp_upper(P0[r][c]);
+                        P0lo[r][c] = el_dpp_lower(P0[r][c]);
+                        Ppup[r][c] = el_dpp_upper(Pp[r][c]);
+                        Pmlo[r][c] = el_dpp_lower(Pm[r][c]);
+                    }
+                const long long obase = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) {
+                    double y[3] = {0.0, 0.0, 0.0}, v[3];
+                    el_sym6(w.c, P0[r], y);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = P0up[r][c] + P0lo[r][c];
+                    el_sym6(w.ax[0], v, y);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = P0[r + 1][c] + P0[r - 1][c];
+                    el_sym6(w.ax[1], v, y);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = Pp[r][c] + Pm[r][c];
+                    el_sym6(w.ax[2], v, y);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = P0up[r + 1][c] + P0lo[r - 1][c];
+                    el_off3(w.dg[0], v, y);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = Ppup[r][c] + Pmlo[r][c];
+                    el_off3(w.dg[1], v, y);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = Pp[r + 1][c] + Pm[r - 1][c];
+                    el_off3(w.dg[2], v, y);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = Ppup[r + 1][c] + Pmlo[r - 1][c];
+                    el_off3(w.dg[3], v, y);
+                    if (row_out[r]) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            a.out[c * a.stride + obase + (long long)r * g.PX] = y[c];
+                            acc += P0[r][c] * y[c];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RH; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        Pm[r][c] = P0[r][c];
+                        P0[r][c] = Pp[r][c];
+                    }
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+}
+
 // r -= alpha q;  z = D^-1 r;  partial r.z and r.r     (use_alpha == 0: alpha = 0, forms z and the sums only)
 template <int D>
 __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restrict__ q, double* __restrict__ r,
@@ -183,17 +412,33 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
     const long long total = (long long)g.nkl * g.PP;
     double alpha = 0.0;
     if (use_alpha) {
-        const double pq = a.scal[ESC_PQ], rz = a.scal[ESC_RZ];
+        double pq;
+        if (a.din) {
+            pq = el_sum_in(a.din, a.din_n, sRed);
+            if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<double*>(a.scal)[ESC_PQ] = pq;
+        } else {
+            pq = a.scal[ESC_PQ];
+        }
+        const double rz = a.scal[a.s_rz];
         alpha = pq > 0.0 ? rz / pq : 0.0;
     }
     double acc_rz = 0.0, acc_rr = 0.0;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int i = (int)(idx % g.PX);
-        const long long row = idx / g.PX;
-        const int j = (int)(row % g.NY);
-        const int kg = g.k0 + (int)(row / g.NY);
+    // (i, j, lk) advance incrementally by the grid stride: one division per thread instead of two per element
+    const long long step = (long long)gridDim.x * 256;
+    const int di = (int)(step % g.PX);
+    const long long drow = step / g.PX;
+    const int dj = (int)(drow % g.NY), dk = (int)(drow / g.NY);
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    int i = (int)(idx % g.PX), j = (int)((idx / g.PX) % g.NY), lk = (int)((idx / g.PX) / g.NY);
+    for (; idx < total; idx += step) {
+        const int kg = g.k0 + lk;
         const int cls = pg_axis_class(i < g.NX ? i : 1, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
                         9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
+        i += di;
+        j += dj;
+        lk += dk;
+        if (i >= g.PX) { i -= g.PX; ++j; }
+        if (j >= g.NY) { j -= g.NY; ++lk; }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             double rv = r[c * a.stride + idx];
@@ -219,7 +464,33 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
 // (so that the block apply that follows finds p_n on the ghosts: z and p_{n-1} were exchanged before)
 template <int D>
 __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, long long total) {
-    const double pq = a.scal[ESC_PQ], rz = a.scal[ESC_RZ], rz_prev = a.scal[ESC_RZ_PREV];
+    __shared__ double sRed2[8];
+    double rz;
+    if (a.din) {
+        // both sums in one pass: all loads issued before the first barrier (each is an L2 miss right after a kernel boundary)
+        double a1 = 0.0, a2 = 0.0;
+        for (int e = threadIdx.x; e < a.din_n; e += 256) {
+            a1 += a.din[e];
+            a2 += a.din2[e];
+        }
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        if ((threadIdx.x & 63) == 0) {
+            sRed2[threadIdx.x >> 6] = a1;
+            sRed2[4 + (threadIdx.x >> 6)] = a2;
+        }
+        __syncthreads();
+        rz = (sRed2[0] + sRed2[1]) + (sRed2[2] + sRed2[3]);
+        const double rr = (sRed2[4] + sRed2[5]) + (sRed2[6] + sRed2[7]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            double* sc = const_cast<double*>(a.scal);
+            sc[a.s_rz] = rz;          // a slot no workgroup of this launch reads
+            sc[ESC_RR] = rr;
+        }
+    } else {
+        rz = a.scal[a.s_rz];
+    }
+    const double pq = a.scal[ESC_PQ], rz_prev = a.scal[a.s_rz_old];
     const double alpha_prev = (pq > 0.0 && rz_prev > 0.0) ? rz_prev / pq : 0.0;
     const double beta = (rz_prev > 0.0) ? rz / rz_prev : 0.0;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -246,7 +517,7 @@ __global__ __launch_bounds__(256) void k_el_reduce(const double* __restrict__ p1
     if (threadIdx.x == 0) {
         if (which == 0) scal[ESC_PQ] = t1;
         else {
-            scal[ESC_RZ_PREV] = scal[ESC_RZ];
+            if (which == 1) scal[ESC_RZ_PREV] = scal[ESC_RZ];      // which == 2: ESC_RZ_PREV already holds the previous value
             scal[ESC_RZ] = t1;
             scal[ESC_RR] = t2;
         }
@@ -466,7 +737,7 @@ struct ElSession {
     int D = 3;
     double lam = 0, mu = 0;
     long long stride = 0;
-    double *tab = nullptr, *dinv = nullptr, *scal = nullptr, *part = nullptr, *part2 = nullptr;
+    double *tab = nullptr, *dinv = nullptr, *scal = nullptr, *part = nullptr, *part2 = nullptr, *part3 = nullptr;   // part3: p.q partials of the apply
     double *x = nullptr, *r = nullptr, *z = nullptr, *p[2] = {nullptr, nullptr}, *q = nullptr, *b = nullptr;   // origins
     std::vector<double*> bases;
     int pcur = 0;
@@ -474,6 +745,13 @@ struct ElSession {
     HeatTables ht{};
     double* h_pin = nullptr;
     ElInterior interior{};
+    // 3-D fast apply (k_el_fast): interior class by z-marching, boundary nodes by extra workgroups of the same launch
+    bool fast = false;
+    int fast_ry = 1;
+    ElW36 w36{};
+    ElFastGeom fgeom{};
+    unsigned* d_mask = nullptr;
+    int last_apply_blocks = 1;      // workgroups (= partials) of the most recent apply launch
 
     double* alloc_vec() {
         double* base = nullptr;
@@ -490,6 +768,8 @@ struct ElSession {
         if (scal) (void)hipFree(scal);
         if (part) (void)hipFree(part);
         if (part2) (void)hipFree(part2);
+        if (part3) (void)hipFree(part3);
+        if (d_mask) (void)hipFree(d_mask);
         if (h_pin) (void)hipHostFree(h_pin);
         tables_free(&ht);
     }
@@ -518,27 +798,138 @@ int el_launch_apply(ElSession* s, ElArgs a, int mode) {
     PG_HIP(s->ctx, hipGetLastError());
     return PDEGPU_OK;
 }
+// interior weights in the 36-value form of k_el_fast; false if the host table does not have the structure it relies on
+bool el_fast_weights(const double* w15 /*[15][9]*/, ElW36* out) {
+    auto qof = [](int dx, int dy, int dz) {
+        const int o = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+        for (int q = 0; q < PG_NOFF15; ++q)
+            if (pg_off15(q) == o) return q;
+        return -1;
+    };
+    double scale = 0.0;
+    for (int t = 0; t < 9; ++t) scale = std::max(scale, std::fabs(w15[qof(0, 0, 0) * 9 + t]));
+    const double tol = 1e-13 * scale;
+    auto sym6 = [&](const double* b, double* o6) {
+        if (std::fabs(b[1] - b[3]) > tol || std::fabs(b[2] - b[6]) > tol || std::fabs(b[5] - b[7]) > tol) return false;
+        o6[0] = b[0]; o6[1] = b[4]; o6[2] = b[8]; o6[3] = b[1]; o6[4] = b[2]; o6[5] = b[5];
+        return true;
+    };
+    auto same = [&](const double* b1, const double* b2) {
+        for (int t = 0; t < 9; ++t)
+            if (std::fabs(b1[t] - b2[t]) > tol) return false;
+        return true;
+    };
+    if (!sym6(w15 + qof(0, 0, 0) * 9, out->c)) return false;
+    const int axes[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int r = 0; r < 3; ++r) {
+        const double* bp = w15 + qof(axes[r][0], axes[r][1], axes[r][2]) * 9;
+        const double* bm = w15 + qof(-axes[r][0], -axes[r][1], -axes[r][2]) * 9;
+        if (!same(bp, bm) || !sym6(bp, out->ax[r])) return false;
+    }
+    const int dgs[4][3] = {{1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+    for (int r = 0; r < 4; ++r) {
+        const double* bp = w15 + qof(dgs[r][0], dgs[r][1], dgs[r][2]) * 9;
+        const double* bm = w15 + qof(-dgs[r][0], -dgs[r][1], -dgs[r][2]) * 9;
+        double o6[6];
+        if (!same(bp, bm) || !sym6(bp, o6)) return false;
+        if (std::fabs(o6[0]) > tol || std::fabs(o6[1]) > tol || std::fabs(o6[2]) > tol) return false;
+        out->dg[r][0] = o6[3]; out->dg[r][1] = o6[4]; out->dg[r][2] = o6[5];
+    }
+    return true;
+}
+
+void el_fast_geometry(ElSession* s) {
+    const GridDev& g = s->g;
+    ElFastGeom& fg = s->fgeom;
+    const int RY = s->fast_ry;
+    fg.full_lo = g.k0 == 0 ? 1 : 0;
+    fg.full_hi = g.k0 + g.nkl == g.NZ ? 1 : 0;
+    fg.lkb = fg.full_lo;
+    fg.lke = g.nkl - fg.full_hi;
+    const int planes = std::max(0, fg.lke - fg.lkb);
+    fg.ntx = (g.NX - 2 + 61) / 62;
+    fg.nty = (g.NY - 2 + RY - 1) / RY;
+    const long long cols = (long long)fg.ntx * fg.nty;
+    long long nzc = (s->ctx->el_fast_waves + cols - 1) / cols;
+    nzc = std::max(1LL, std::min<long long>(nzc, std::max(1, planes)));
+    fg.zlen = std::max(1, (int)((planes + nzc - 1) / nzc));
+    fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
+    fg.nb_fast = (int)((cols * fg.nzc + 3) / 4);
+    fg.ring = 2 * g.NX + 2 * (g.NY - 2);
+    fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * g.NX * g.NY + (long long)planes * fg.ring;
+    fg.nb_bnd = (int)((fg.nbnd + 255) / 256);
+    fg.mask = s->d_mask;
+}
+
 int el_apply(ElSession* s, const ElArgs& a, int mode) {
+    if (mode == APPLY_PLAIN && s->fast && s->ctx->el_fast) {
+        const ElFastGeom& fg = s->fgeom;
+        const int nb = fg.nb_fast + fg.nb_bnd;
+        if (s->fast_ry == 2) hipLaunchKernelGGL(k_el_fast<2>, dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        else hipLaunchKernelGGL(k_el_fast<1>, dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        PG_HIP(s->ctx, hipGetLastError());
+        s->last_apply_blocks = nb;
+        return PDEGPU_OK;
+    }
+    s->last_apply_blocks = s->nblk;
     return s->D == 3 ? el_launch_apply<3>(s, a, mode) : el_launch_apply<2>(s, a, mode);
 }
-int el_k2(ElSession* s, int use_alpha) {
+// lazy != nullptr: no reduce launches — K2's prologue sums the apply's p.q partials, the next p-update's prologue sums
+// K2's r.z / r.r partials; *lazy carries the state of one chunk (which r.z slot is current, whether partials are pending)
+struct ElLazy {
+    int cur = ESC_RZ;
+    bool pend = false;
+};
+int el_k2(ElSession* s, int use_alpha, ElLazy* lazy = nullptr) {
     ElArgs a = s->args();
+    if (lazy) {
+        a.din = s->part3;
+        a.din_n = s->last_apply_blocks;
+        a.s_rz = lazy->cur;
+    }
     if (s->D == 3) hipLaunchKernelGGL(k_el_k2<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, s->z, use_alpha);
     else hipLaunchKernelGGL(k_el_k2<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, s->z, use_alpha);
     PG_HIP(s->ctx, hipGetLastError());
+    if (lazy) {
+        lazy->pend = true;
+        return PDEGPU_OK;
+    }
     hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part, s->part2, s->nblk, s->scal, 1);
     PG_HIP(s->ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+// end of a lazy chunk: the pending r.z / r.r partials -> canonical slots (ESC_RZ current, ESC_RZ_PREV previous)
+int el_lazy_finish(ElSession* s, ElLazy* lazy) {
+    if (!lazy->pend) return PDEGPU_OK;
+    hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part, s->part2, s->nblk, s->scal, lazy->cur == ESC_RZ ? 1 : 2);
+    PG_HIP(s->ctx, hipGetLastError());
+    lazy->pend = false;
+    lazy->cur = ESC_RZ;
     return PDEGPU_OK;
 }
 // K1 = flat p-update (+ deferred x-update) followed by the plain block apply q = P A p with the p.q partials.
 // (The heat path recomputes p at the stencil neighbours to save an HBM pass; here everything is cache-resident and
 // the 15 x 3 x 2 neighbour reads of the fused form cost more than the extra launch: measured 110 -> ~60 us.)
-int el_k1(ElSession* s) {
+int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
     ElArgs a = s->args();
     a.in = s->z;
     a.p_old = s->p[s->pcur];
     a.p_new = s->p[1 - s->pcur];
     a.x = s->x;
+    if (lazy) {
+        if (lazy->pend) {
+            a.din = s->part;
+            a.din2 = s->part2;
+            a.din_n = s->nblk;
+            a.s_rz_old = lazy->cur;
+            a.s_rz = lazy->cur == ESC_RZ ? ESC_RZ_PREV : ESC_RZ;
+            lazy->cur = a.s_rz;
+            lazy->pend = false;
+        } else {
+            a.s_rz = lazy->cur;
+            a.s_rz_old = lazy->cur == ESC_RZ ? ESC_RZ_PREV : ESC_RZ;
+        }
+    }
     const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
     const long long first = -(long long)lo * s->g.PP, total = (long long)(s->g.nkl + lo + hi) * s->g.PP;
     if (s->D == 3) hipLaunchKernelGGL(k_el_pupdate<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
@@ -548,8 +939,10 @@ int el_k1(ElSession* s) {
     ElArgs b = s->args();
     b.in = s->p[s->pcur];
     b.out = s->q;
+    b.partials = s->part3;
     PG_TRY(el_apply(s, b, APPLY_PLAIN));
-    hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part, (const double*)nullptr, s->nblk, s->scal, 0);
+    if (lazy) return PDEGPU_OK;
+    hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part3, (const double*)nullptr, s->last_apply_blocks, s->scal, 0);
     PG_HIP(s->ctx, hipGetLastError());
     return PDEGPU_OK;
 }
@@ -583,15 +976,24 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     PG_HIP(ctx, hipMalloc(&s->tab, 27 * PG_NOFF15 * 9 * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->dinv, 81 * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->scal, ESC_COUNT * sizeof(double)));
-    PG_HIP(ctx, hipMalloc(&s->part, (size_t)s->nblk * sizeof(double)));
-    PG_HIP(ctx, hipMalloc(&s->part2, (size_t)s->nblk * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&s->d_mask, 32 * sizeof(unsigned)));
     PG_HIP(ctx, hipHostMalloc(&s->h_pin, ESC_COUNT * sizeof(double)));
     PG_HIP(ctx, hipMemsetAsync(s->scal, 0, ESC_COUNT * sizeof(double), ctx->stream));
     double h[3] = {1, 1, 1};
     for (int r = 0; r < grid->dim; ++r) h[r] = grid->L[r] / grid->n[r];
-    hipLaunchKernelGGL(k_el_tables, dim3(1), dim3(256), 0, ctx->stream, grid->dim, h[0], h[1], h[2], s->lam, s->mu, s->tab, s->dinv);
+    hipLaunchKernelGGL(k_el_tables, dim3(1), dim3(256), 0, ctx->stream, grid->dim, h[0], h[1], h[2], s->lam, s->mu, s->tab, s->dinv, s->d_mask);
     PG_HIP(ctx, hipGetLastError());
     for (int q = 0; q < PG_NOFF15; ++q) fold_elasticity_block(grid->dim, h, s->lam, s->mu, 13, q, s->interior.w + q * 9);
+    size_t npart = (size_t)s->nblk;
+    s->fast_ry = ctx->el_fast_ry == 2 ? 2 : 1;
+    s->fast = grid->dim == 3 && s->g.NX >= 3 && s->g.NY >= 3 && s->g.NZ >= 3 && el_fast_weights(s->interior.w, &s->w36);
+    if (s->fast) {
+        el_fast_geometry(s);
+        npart = std::max(npart, (size_t)s->fgeom.nb_fast + (size_t)((s->fgeom.nbnd + 255) / 256));
+    }
+    PG_HIP(ctx, hipMalloc(&s->part, npart * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&s->part2, npart * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&s->part3, npart * sizeof(double)));
     PG_TRY(tables_build(ctx, grid, &s->ht));
     double** vecs[] = {&s->x, &s->r, &s->z, &s->p[0], &s->p[1], &s->q, &s->b};
     for (double** v : vecs) {
@@ -767,10 +1169,13 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     PG_HIP(ctx, hipEventRecord(cgt.a, ctx->stream));
     while (rr > target && it < max_iter && std::isfinite(rr)) {
         const int n = std::min(chunk, max_iter - it);
+        ElLazy lazy;
+        ElLazy* lz = ctx->lazy_dot ? &lazy : nullptr;
         for (int i = 0; i < n; ++i) {
-            PG_TRY(el_k1(&s));
-            PG_TRY(el_k2(&s, 1));
+            PG_TRY(el_k1(&s, lz));
+            PG_TRY(el_k2(&s, 1, lz));
         }
+        if (lz) PG_TRY(el_lazy_finish(&s, lz));
         it += n;
         PG_TRY(el_scalars(&s, sc));
         rr = sc[ESC_RR];

@@ -28,7 +28,8 @@ struct pdegpu_session {
     DevVec x, r, p[2], q, b;
     int pcur = 0;
     double* d_scal = nullptr;
-    double* d_part = nullptr;
+    double* d_part = nullptr;       // [2][npart]: per-workgroup partials; the second half takes K2's in the lazy loop
+    int npart = 0;
     unsigned* d_counter = nullptr;  // dot_finish ticket counter
     double* d_dense = nullptr;
     double* h_pin = nullptr;       // pinned host scalars
@@ -185,8 +186,9 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
 // 15-point operator the second stencil pass costs more than the 8 B/DoF it saves (measured)
 bool k2_is_stencil(const pdegpu_session* s) { return s->fast && s->ctx->cg_variant == 1 && s->npt == 7; }
 
-int op_k1(pdegpu_session* s, LaunchInfo* li) {
+int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
     StencilArgs a{};
+    a.di = di;
     a.g = s->g;
     a.in = s->weighted ? s->z.v : s->r.v;          // PCG: p = z + beta p with z = D^-1 r
     if (s->weighted) {
@@ -217,15 +219,18 @@ int op_k1(pdegpu_session* s, LaunchInfo* li) {
 }
 
 // K2: r -= alpha q, partial r.r   (fast path variant 1: q = A p recomputed by the marching stencil)
-int op_k2(pdegpu_session* s, LaunchInfo* li) {
+// part_out: where this launch's r.r partials go (the lazy loop keeps them apart from K1's p.q partials)
+int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* part_out = nullptr) {
+    if (!part_out) part_out = s->d_part;
     if (k2_is_stencil(s)) {
         StencilArgs a{};
+        a.di = di;
         a.g = s->g;
         a.in = s->p[s->pcur].v;
         a.rhs = s->r.v;
         a.out = s->r.v;
         a.scal = s->d_scal;
-        a.partials = s->d_part;
+        a.partials = part_out;
         a.counter = s->d_counter;
         a.dot_which = s->ctx->inlaunch_dot ? 1 : -1;
         a.mask_dirichlet = 1;
@@ -236,7 +241,7 @@ int op_k2(pdegpu_session* s, LaunchInfo* li) {
     }
     unsigned* cnt = s->ctx->inlaunch_dot ? s->d_counter : nullptr;      // nullptr: partials only, reduced by k_reduce
     if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, cnt, 1, li);
-    return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, s->d_part, cnt, li);
+    return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, part_out, cnt, li, di);
 }
 
 // after a RESIDUAL pass: PCG needs z = D^-1 r and rho = r.z in place of r.r
@@ -293,7 +298,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "el_fast", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -316,6 +321,10 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "inlaunch_dot")) return &ctx->inlaunch_dot;
     if (!strcmp(key, "el_grid_mult")) return &ctx->el_grid_mult;
     if (!strcmp(key, "direct_1d")) return &ctx->direct_1d;
+    if (!strcmp(key, "lazy_dot")) return &ctx->lazy_dot;
+    if (!strcmp(key, "el_fast")) return &ctx->el_fast;
+    if (!strcmp(key, "el_fast_ry")) return &ctx->el_fast_ry;
+    if (!strcmp(key, "el_fast_waves")) return &ctx->el_fast_waves;
     return nullptr;
 }
 }  // namespace
@@ -403,7 +412,8 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
         if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);
     const int npart = stencil_max_partials(ctx);
     if (rc == PDEGPU_OK && hipMalloc(&s->d_scal, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc scal");
-    if (rc == PDEGPU_OK && hipMalloc(&s->d_part, npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
+    s->npart = npart;
+    if (rc == PDEGPU_OK && hipMalloc(&s->d_part, 2 * (size_t)npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
     if (rc == PDEGPU_OK && (hipMalloc(&s->d_counter, 64) != hipSuccess || hipMemsetAsync(s->d_counter, 0, 64, ctx->stream) != hipSuccess))
         rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc counter");
     if (rc == PDEGPU_OK && hipHostMalloc(&s->h_pin, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipHostMalloc");
@@ -553,6 +563,43 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
                 done += kGraphIters;
             }
         }
+    }
+    // lazy dot products (default): no reduce launches inside the chunk — K2's prologue sums K1's p.q partials, the next
+    // K1's prologue sums K2's r.r partials (same summation order as k_reduce: bitwise the same scalars); the two r.r
+    // slots alternate so that no launch overwrites a scalar its own workgroups still read, and one reduce launch at the
+    // end of the chunk leaves the canonical layout (SC_RR current, SC_RR_PREV previous) for the host and for flush.
+    const int64_t nslow = s->grid.dim == 3 ? (int64_t)s->grid.n[2] + 1 : 1;
+    const bool lazy = ctx->lazy_dot && !ctx->inlaunch_dot && !s->weighted && s->g.k0 == 0 && s->g.nkl == nslow &&
+                      (k2_is_stencil(s) || ctx->k2_variant == 0) && done < iters;
+    if (lazy) {
+        int cur = SC_RR;
+        bool pend = false;
+        for (int it = done; it < iters; ++it) {
+            DotIn d1;
+            if (pend) {
+                d1.part = s->d_part + s->npart;
+                d1.n = l2.grid;
+                d1.s_rr = cur == SC_RR ? SC_RR_PREV : SC_RR;
+                d1.s_rr_old = cur;
+                cur = d1.s_rr;
+            }
+            if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 0], ctx->stream));
+            PG_TRY(op_k1(s, &l1, d1));
+            if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 1], ctx->stream));
+            if (l1.grid < 1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "lazy CG loop: empty K1 grid");
+            DotIn d2;
+            d2.part = s->d_part;
+            d2.n = l1.grid;
+            d2.s_rr = cur;
+            if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 2], ctx->stream));
+            PG_TRY(op_k2(s, &l2, d2, s->d_part + s->npart));
+            if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
+            if (l2.grid < 1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "lazy CG loop: empty K2 grid");
+            pend = true;
+            ++s->eager_iters;
+        }
+        PG_TRY(vec_reduce(ctx, s->d_part + s->npart, l2.grid, s->d_scal, cur == SC_RR ? 1 : 2, 1));
+        done = iters;
     }
     for (int it = done; it < iters; ++it) {
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 0], ctx->stream));

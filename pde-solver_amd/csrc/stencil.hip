@@ -44,13 +44,6 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);   // fixed order: bitwise reproducible
 }
 
-__device__ __forceinline__ void cg_scalars(const double* scal, double* alpha_prev, double* beta) {
-    // alpha_{n-1} = rr_{n-1} / (p_{n-1}.q_{n-1}),  beta_{n-1} = rr_n / rr_{n-1};  both 0 on the first iteration
-    const double pq = scal[SC_PQ], rr = scal[SC_RR], rr_prev = scal[SC_RR_PREV];
-    *alpha_prev = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
-    *beta = (rr_prev > 0.0) ? rr / rr_prev : 0.0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // general path
 // ---------------------------------------------------------------------------------------------
@@ -66,7 +59,7 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
     const GridDev& g = a.g;
     const long long total = (long long)g.nkl * g.PP;
     double alpha_prev = 0.0, beta = 0.0;
-    if (MODE == APPLY_CG_K1) cg_scalars(a.scal, &alpha_prev, &beta);
+    if (MODE == APPLY_CG_K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
 
     double acc = 0.0;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -216,19 +209,16 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     int estep = 0;                                            // LDS edge-exchange counter (same in every wave of the workgroup)
 
     double acc = 0.0;
+    // CG scalars: every thread of every workgroup takes part (the prologue sum of the previous launch's partials has barriers)
+    double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
+    if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
+    if (K2) res_scale = cg_alpha_in(a.di, a.scal, sRed);      // alpha_n = rr_n / (p_n . A p_n)
     // EX: every wave of a workgroup with work runs the loop (inactive ones with all loads / stores predicated off) so
     // that the barriers match; lk0 / lk1 depend on the workgroup only
     if (EX ? (lk0 < lk1) : active) {
-        double alpha_prev = 0.0, beta = 0.0;
-        if (K1) cg_scalars(a.scal, &alpha_prev, &beta);
         const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wz = a.w[3];
         const double wxy = a.w[4], wxz = a.w[5], wyz = a.w[6], wxyz = a.w[7];
         const double shift = a.in_shift;
-        double res_scale = 1.0;
-        if (K2) {                                             // alpha_n = rr_n / (p_n . A p_n)
-            const double pq = a.scal[SC_PQ], rr = a.scal[SC_RR];
-            res_scale = (pq > 0.0) ? rr / pq : 0.0;
-        }
 
         const bool lane_ok = active && i0 < g.PX;             // pair inside the padded row
         const bool ma = active && (i0 >= 1) && (i0 <= g.NX - 2);   // node a = i0 is an interior (free) node
@@ -468,7 +458,12 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     int target = wg_per_cu * ctx->num_cu;
     int nzc = (target + xy - 1) / xy;
     if (nzc < 1) nzc = 1;
-    int maxc = planes / 8;
+    // chunks of >= 8 planes keep the redundant two-plane prologue below 25 % when there is parallelism to spare; a grid too
+    // small to fill the device is latency-bound on the serial march instead, so it gets shorter chunks (down to 2 planes)
+    int minlen = (int)((long long)planes * xy / (target > 0 ? target : 1));
+    if (minlen > 8) minlen = 8;
+    if (minlen < 2) minlen = 2;
+    int maxc = planes / minlen;
     if (maxc < 1) maxc = 1;
     if (nzc > maxc) nzc = maxc;
     fg.zlen = planes > 0 ? (planes + nzc - 1) / nzc : 1;

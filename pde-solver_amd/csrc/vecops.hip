@@ -49,10 +49,9 @@ __global__ __launch_bounds__(256) void k_set_bc(GridDev g, double* __restrict__ 
 
 // r -= alpha q, partial r.r      (n2 = number of double2 elements)
 __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
-                                             double* scal, double* __restrict__ partials, unsigned* counter) {
+                                             double* scal, double* __restrict__ partials, unsigned* counter, DotIn di) {
     __shared__ double sRed[4];
-    const double pq = scal[SC_PQ], rr = scal[SC_RR];
-    const double alpha = (pq > 0.0) ? rr / pq : 0.0;
+    const double alpha = cg_alpha_in(di, scal, sRed);
     double acc = 0.0;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long long)gridDim.x * 256) {
         double2 rv = r[e];
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ parti
             scal[SC_PQ_LOCAL] = tot;
             if (copy_to_global) scal[SC_PQ] = tot;
         } else {
-            scal[SC_RR_PREV] = scal[SC_RR];
+            if (which == 1) scal[SC_RR_PREV] = scal[SC_RR];
             scal[SC_RR_LOCAL] = tot;
             if (copy_to_global) scal[SC_RR] = tot;
         }
@@ -241,7 +240,7 @@ int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const 
 }
 
 int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, unsigned* counter,
-           LaunchInfo* li) {
+           LaunchInfo* li, const DotIn& di) {
     const long long n2 = (long long)g.nkl * g.PP / 2;
     long long nbl = (n2 + 255) / 256;
     if (nbl > (long long)ctx->k2_grid_mult * ctx->num_cu) nbl = (long long)ctx->k2_grid_mult * ctx->num_cu;
@@ -264,7 +263,7 @@ int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double
                            reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
     else
         hipLaunchKernelGGL(k_k2, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
+                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

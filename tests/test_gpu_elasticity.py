@@ -34,6 +34,37 @@ def test_block_operator_matches_assembled_matrix(lib, gpu_ctx, dim, n, Ls, plane
     assert rel_err(y, ref) < 1e-12
 
 
+@pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((63, 4, 5), (2.0, 0.3, 0.2)), ((64, 3, 3), (2.0, 0.3, 0.2)),
+                                  ((65, 2, 9), (1.0, 0.2, 0.5)), ((130, 5, 3), (1.0, 0.2, 0.1)), ((2, 2, 2), (1.0, 1.0, 1.0))])
+def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
+    """k_el_fast (z-marching interior + boundary workgroups): rows per column 1 | 2, z-chunk lengths from one plane to the
+    whole column, x-tiles ending at 62 / 63 / 64 / 65 nodes, against the assembled matrix and the thread-per-node kernel"""
+    from pdegpu import _lib
+    E, nu = 210e9, 0.3
+    lam, mu = o.lame(E, nu)
+    c, cells = o.box_mesh(*Ls, *n)
+    K = o.assemble_elasticity(c, cells, lam, mu)
+    u = np.random.default_rng(11).uniform(-1, 1, (c.shape[0], 3))
+    ref = (K @ u.ravel()).reshape(-1, 3)
+    el = _lib.Elasticity()
+    el.E, el.nu = E, nu
+    g = _lib.make_grid(3, n, Ls)
+    outs = {}
+    try:
+        for fast, ry, waves in ((0, 1, 2048), (1, 1, 2048), (1, 2, 2048), (1, 1, 1), (1, 2, 100000)):
+            for k, v in (("el_fast", fast), ("el_fast_ry", ry), ("el_fast_waves", waves)):
+                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+            y = np.full_like(u, np.nan)
+            _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 0))
+            assert rel_err(y, ref) < 1e-12, (fast, ry, waves)
+            outs[(fast, ry, waves)] = y
+    finally:
+        for k, v in (("el_fast", 1), ("el_fast_ry", 1), ("el_fast_waves", 2048)):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+    # z-chunking does not change a single bit (same per-node arithmetic)
+    assert np.array_equal(outs[(1, 1, 2048)], outs[(1, 1, 1)])
+
+
 @pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((37, 3, 2), (2.0, 0.3, 0.2)), ((16, 1, 1), (1.0, 0.1, 0.1))])
 def test_mfma_element_by_element_apply_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
     """v_mfma_f64_16x16x4_f64 element-by-element form (24x24 macro element, scatter by fp64 atomics) == matrix;
@@ -179,3 +210,21 @@ def test_solve_elasticity_slabs_single_rank(lib, gpu_ctx):
     out = solve_elasticity_slabs(grid, el, n, rtol=1e-12)
     ref = o.solve_elasticity_3d(*Ls, *n, 210e9, 0.3, 0.0, 0.0, -76518.0, "stress")
     assert rel_err(out["displacement"], ref.extra["displacement"]) < TOL and rel_err(out["field"], ref.values[0]) < TOL
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, dim):
+    """elasticity PCG without reduce launches (prologue sums) == with k_el_reduce after every kernel, bit for bit"""
+    from pdegpu import elasticity, _lib
+    outs = []
+    try:
+        for lazy in (1, 0):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", lazy))
+            if dim == 2:
+                outs.append(elasticity._solve_elasticity_2d_static(1.0, 0.3, 24, 9, 210e9, 0.3, 0.0, -5.0e4, "stress", True, rtol=1e-10))
+            else:
+                outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 20, 6, 5, 210e9, 0.3, 0.0, 0.0, -7.0e4, "stress", rtol=1e-10))
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", 1))
+    assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"] > 0
+    assert np.array_equal(outs[0].values, outs[1].values)

@@ -460,3 +460,28 @@ def test_heat_2d_uses_the_fused_kernels(lib, gpu_ctx):
     st = heat._solve_heat_2d_raw(**{**kw, "steady": True, "source_type": "constant", "source_value": 3.0}, rtol=1e-12)
     assert st.meta["solver_path"] == "fast"
     assert rel_err(st.values, o.solve_heat_2d(**{**kw, "steady": True, "source_type": "constant", "source_value": 3.0}).values) < TOL
+
+
+@pytest.mark.parametrize("case", ["3d_fast", "3d_fast_72B", "3d_general", "2d_fast", "3d_transient_15pt"])
+def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, case):
+    """default CG loop (the next kernel's prologue sums the previous launch's partials, no reduce launches) vs
+    lazy_dot=0 (k_reduce after every dot-producing kernel): same summation order, so identical iterates bit for bit"""
+    from pdegpu import heat, _lib
+    def run():
+        if case == "2d_fast":
+            return heat._solve_heat_2d_raw(1.0, 0.7, 90, 50, 0.8, 3.0, 20.0, 0.004, 3, rtol=1e-11)
+        kw = dict(steady=True, source_type="constant", source_value=2.0) if case != "3d_transient_15pt" else {}
+        return heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 40, 21, 17, 0.9, 1.5, 20.0, 0.003, 2, rtol=1e-11,
+                                       fast_path=(case != "3d_general"), **kw)
+    outs = []
+    try:
+        if case == "3d_fast_72B":
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_variant", 0))
+        for lazy in (1, 0):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", lazy))
+            outs.append(run())
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_variant", 1))
+    assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"] > 0
+    assert np.array_equal(outs[0].values, outs[1].values)
