@@ -123,7 +123,12 @@ const char* pdegpu_version(void);
  * "k2_variant" (0..5), "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
  * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF), "use_graph"
  * (1 = replay the CG inner loop from a captured hipGraph), "inlaunch_dot" (1 = finish dot products inside the producing
- * launch instead of a separate one-workgroup reduce launch; measured slower).  Results do not depend on them. */
+ * launch instead of a separate one-workgroup reduce launch; measured slower), "lazy_dot" (1 = the next
+ * kernel's prologue sums the previous launch's partials, no reduce launches inside a single-slab CG chunk; same bits),
+ * "direct_1d" (1 = 1-D grids use the Thomas recurrence inside one launch, 0 = CG), "el_fast" (1 = 3-D elasticity
+ * z-marching block stencil), "el_fast_ry" (1|2 rows per column), "el_fast_waves" (wavefront target of the marching part),
+ * "el_fused_k1" (1 = p-update inside the marching kernel; measured slower).  Results do not depend on them beyond the
+ * solver tolerance. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 
 /* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw

@@ -247,14 +247,47 @@ __device__ __forceinline__ void el_off3(const double* b, const double* v, double
     y[2] += b[1] * v[0] + b[2] * v[1];
 }
 
-template <int RY>
+// K1 = true: the fused CG kernel — p_n = z_n + beta p_{n-1} is formed at every loaded position (own nodes: stored, and
+// x += alpha_{n-1} p_{n-1} applied, when the value is first formed), q = A p_n, partial p_n.q: the separate p-update pass
+// (5 vector passes over HBM / MALL) disappears.  K1 = false: q = A in, partial in.q.
+template <int RY, bool K1>
 __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom fg) {
     __shared__ double sTab[27 * PG_NOFF15 * 9];
     __shared__ unsigned sMask[27];
-    __shared__ double sRed[4];
+    __shared__ double sRed[8];
     constexpr int RH = RY + 2;
     const GridDev& g = a.g;
     double acc = 0.0;
+    double alpha_prev = 0.0, beta = 0.0;
+    if (K1) {
+        double rz;
+        if (a.din) {               // lazy: r.z / r.r partials of the previous K2, summed here (all loads before the barrier)
+            double a1 = 0.0, a2 = 0.0;
+            for (int e = threadIdx.x; e < a.din_n; e += 256) {
+                a1 += a.din[e];
+                a2 += a.din2[e];
+            }
+            a1 = wave_sum(a1);
+            a2 = wave_sum(a2);
+            if ((threadIdx.x & 63) == 0) {
+                sRed[threadIdx.x >> 6] = a1;
+                sRed[4 + (threadIdx.x >> 6)] = a2;
+            }
+            __syncthreads();
+            rz = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+            const double rr = (sRed[4] + sRed[5]) + (sRed[6] + sRed[7]);
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                double* sc = const_cast<double*>(a.scal);
+                sc[a.s_rz] = rz;
+                sc[ESC_RR] = rr;
+            }
+        } else {
+            rz = a.scal[a.s_rz];
+        }
+        const double pq = a.scal[ESC_PQ], rz_prev = a.scal[a.s_rz_old];
+        alpha_prev = (pq > 0.0 && rz_prev > 0.0) ? rz_prev / pq : 0.0;
+        beta = (rz_prev > 0.0) ? rz / rz_prev : 0.0;
+    }
     if ((int)blockIdx.x < fg.nb_bnd) {
         // ---- boundary nodes: one thread per node, truncated class stencils from LDS -----------------------------
         for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
@@ -287,27 +320,48 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
             const long long idx = (long long)lk * g.PP + (long long)j * g.PX + i;
             double dval;
             const bool dir = a.mask_dirichlet && pg_dirichlet(g, i, j, kg, &dval);
+            double pc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (K1) {
+                    const double po = a.p_old[c * a.stride + idx];
+                    pc[c] = a.in[c * a.stride + idx] + beta * po;
+                    a.p_new[c * a.stride + idx] = pc[c];
+                    if (alpha_prev != 0.0) a.x[c * a.stride + idx] += alpha_prev * po;
+                } else {
+                    pc[c] = a.in[c * a.stride + idx];
+                }
+            }
+            // All 15 neighbours are loaded unconditionally (45 loads in flight instead of 15 dependent round trips): an
+            // offset that leaves the grid still lands inside the allocation (ghost planes / guards / row pads, all zero
+            // or finite neighbour data) and meets a class weight that is exactly 0.
             double s[3] = {0.0, 0.0, 0.0};
+            double nv[PG_NOFF15][3];
+#pragma unroll
+            for (int q = 0; q < PG_NOFF15; ++q) {
+                const int o = pg_off15(q);
+                const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+                const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    nv[q][c] = a.in[c * a.stride + nb];
+                    if (K1) nv[q][c] += beta * a.p_old[c * a.stride + nb];
+                }
+            }
             if (!dir) {
                 const int cls = pg_axis_class(i, g.NX) + 3 * pg_axis_class(j, g.NY) + 9 * pg_axis_class(kg, g.NZ);
                 const double* wtab = &sTab[cls * PG_NOFF15 * 9];
-                const unsigned m = sMask[cls];
 #pragma unroll
                 for (int q = 0; q < PG_NOFF15; ++q) {
-                    if (!((m >> q) & 1u)) continue;
-                    const int o = pg_off15(q);
-                    const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
-                    const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
                     const double* blk = wtab + q * 9;
-                    const double v0 = a.in[nb], v1 = a.in[a.stride + nb], v2 = a.in[2 * a.stride + nb];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) s[r] += blk[r * 3] * v0 + blk[r * 3 + 1] * v1 + blk[r * 3 + 2] * v2;
+                    for (int r = 0; r < 3; ++r) s[r] += blk[r * 3] * nv[q][0] + blk[r * 3 + 1] * nv[q][1] + blk[r * 3 + 2] * nv[q][2];
                 }
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 a.out[c * a.stride + idx] = s[c];
-                acc += a.in[c * a.stride + idx] * s[c];
+                acc += pc[c] * s[c];
             }
         }
     } else {
@@ -320,46 +374,46 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
         const int lk0 = fg.lkb + zc * fg.zlen;
         const int lk1 = min(lk0 + fg.zlen, fg.lke);
         if (zc < fg.nzc && lk0 < lk1) {
-            const bool ld_ok = i < g.PX;
+            // Loads are unconditional (branch-free, all of a plane in flight at once): every address a wave can form lies
+            // inside the allocation — rows up to NY (= first row of the next plane), columns up to NX+60 < PX+64, planes
+            // -1 .. nkl, covered by the ghost planes and the guard of kGuard + one row on both sides — and a value from
+            // outside the grid only ever reaches outputs that are not stored (an interior node has all 15 neighbours inside).
             const bool out_x = lane >= 1 && lane <= 62 && i <= g.NX - 2;
-            bool row_ld[RH], row_out[RH];
+            bool row_out[RH];
 #pragma unroll
-            for (int r = 0; r < RH; ++r) {
-                row_ld[r] = ld_ok && (j0 - 1 + r) <= g.NY - 1;
-                row_out[r] = out_x && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
-            }
+            for (int r = 0; r < RH; ++r) row_out[r] = out_x && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
             const long long col = (long long)(j0 - 1) * g.PX + i;
             double Pm[RH][3], P0[RH][3], Pp[RH][3];
-            auto load_plane = [&](int lk, double (*P)[3]) {
+            // own == true: the plane belongs to this wave's chunk, so its own rows get p_n stored and x updated here
+            auto load_plane = [&](int lk, double (*P)[3], bool own) {
                 const long long base = (long long)lk * g.PP + col;
 #pragma unroll
                 for (int r = 0; r < RH; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) P[r][c] = row_ld[r] ? a.in[c * a.stride + base + (long long)r * g.PX] : 0.0;
-            };
-            load_plane(lk0 - 1, Pm);
-            load_plane(lk0, P0);
-            for (int lk = lk0; lk < lk1; ++lk) {
-                load_plane(lk + 1, Pp);
-                // x-shifted copies: up = value at i+1, lo = value at i-1
-                double P0up[RH][3], P0lo[RH][3], Ppup[RH][3], Pmlo[RH][3];
-#pragma unroll
-                for (int r = 0; r < RH; ++r)
-#pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        P0up[r][c] = el_dpp_upper(P0[r][c]);
-                        P0lo[r][c] = el_dpp_lower(P0[r][c]);
-                        Ppup[r][c] = el_dpp_upper(Pp[r][c]);
-                        Pmlo[r][c] = el_dpp_lower(Pm[r][c]);
+                        const long long at = c * a.stride + base + (long long)r * g.PX;
+                        double v = a.in[at];
+                        if (K1) {
+                            const double po = a.p_old[at];
+                            v += beta * po;
+                            if (own && row_out[r]) {
+                                a.p_new[at] = v;
+                                if (alpha_prev != 0.0) a.x[at] += alpha_prev * po;
+                            }
+                        }
+                        P[r][c] = v;
                     }
+            };
+            load_plane(lk0 - 1, Pm, false);
+            load_plane(lk0, P0, true);
+            for (int lk = lk0; lk < lk1; ++lk) {
+                load_plane(lk + 1, Pp, lk + 1 < lk1);
                 const long long obase = (long long)lk * g.PP + col;
 #pragma unroll
                 for (int r = 1; r <= RY; ++r) {
-                    double y[3] = {0.0, 0.0, 0.0}, v[3];
+                    // y = [unshifted terms] + up(U) + lo(L): the x-shifts act on two accumulated 3-vectors, not on 24 inputs
+                    double y[3] = {0.0, 0.0, 0.0}, U[3] = {0.0, 0.0, 0.0}, Lw[3] = {0.0, 0.0, 0.0}, v[3];
                     el_sym6(w.c, P0[r], y);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] = P0up[r][c] + P0lo[r][c];
-                    el_sym6(w.ax[0], v, y);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) v[c] = P0[r + 1][c] + P0[r - 1][c];
                     el_sym6(w.ax[1], v, y);
@@ -367,17 +421,18 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                     for (int c = 0; c < 3; ++c) v[c] = Pp[r][c] + Pm[r][c];
                     el_sym6(w.ax[2], v, y);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] = P0up[r + 1][c] + P0lo[r - 1][c];
-                    el_off3(w.dg[0], v, y);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] = Ppup[r][c] + Pmlo[r][c];
-                    el_off3(w.dg[1], v, y);
-#pragma unroll
                     for (int c = 0; c < 3; ++c) v[c] = Pp[r + 1][c] + Pm[r - 1][c];
                     el_off3(w.dg[2], v, y);
+                    el_sym6(w.ax[0], P0[r], U);               // the (+-1,0,0) term is the same 3-vector for both shifts
+                    Lw[0] = U[0]; Lw[1] = U[1]; Lw[2] = U[2];
+                    el_off3(w.dg[0], P0[r + 1], U);           // source (i+1, j+1, k)
+                    el_off3(w.dg[1], Pp[r], U);               //        (i+1, j, k+1)
+                    el_off3(w.dg[3], Pp[r + 1], U);           //        (i+1, j+1, k+1)
+                    el_off3(w.dg[0], P0[r - 1], Lw);          //        (i-1, j-1, k)
+                    el_off3(w.dg[1], Pm[r], Lw);              //        (i-1, j, k-1)
+                    el_off3(w.dg[3], Pm[r - 1], Lw);          //        (i-1, j-1, k-1)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] = Ppup[r + 1][c] + Pmlo[r - 1][c];
-                    el_off3(w.dg[3], v, y);
+                    for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
                     if (row_out[r]) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
@@ -865,8 +920,8 @@ int el_apply(ElSession* s, const ElArgs& a, int mode) {
     if (mode == APPLY_PLAIN && s->fast && s->ctx->el_fast) {
         const ElFastGeom& fg = s->fgeom;
         const int nb = fg.nb_fast + fg.nb_bnd;
-        if (s->fast_ry == 2) hipLaunchKernelGGL(k_el_fast<2>, dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-        else hipLaunchKernelGGL(k_el_fast<1>, dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        if (s->fast_ry == 2) hipLaunchKernelGGL((k_el_fast<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        else hipLaunchKernelGGL((k_el_fast<1, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
         PG_HIP(s->ctx, hipGetLastError());
         s->last_apply_blocks = nb;
         return PDEGPU_OK;
@@ -929,6 +984,22 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
             a.s_rz = lazy->cur;
             a.s_rz_old = lazy->cur == ESC_RZ ? ESC_RZ_PREV : ESC_RZ;
         }
+    }
+    if (s->fast && s->ctx->el_fast && s->ctx->el_fused_k1) {
+        // one launch: p-update, deferred x-update, q = A p, p.q partials (k_el_fast<RY, true>)
+        const ElFastGeom& fg = s->fgeom;
+        const int nb = fg.nb_fast + fg.nb_bnd;
+        a.out = s->q;
+        a.partials = s->part3;
+        if (s->fast_ry == 2) hipLaunchKernelGGL((k_el_fast<2, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        else hipLaunchKernelGGL((k_el_fast<1, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        PG_HIP(s->ctx, hipGetLastError());
+        s->last_apply_blocks = nb;
+        s->pcur ^= 1;
+        if (lazy) return PDEGPU_OK;
+        hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part3, (const double*)nullptr, nb, s->scal, 0);
+        PG_HIP(s->ctx, hipGetLastError());
+        return PDEGPU_OK;
     }
     const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
     const long long first = -(long long)lo * s->g.PP, total = (long long)(s->g.nkl + lo + hi) * s->g.PP;

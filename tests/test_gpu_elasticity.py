@@ -59,7 +59,7 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
             assert rel_err(y, ref) < 1e-12, (fast, ry, waves)
             outs[(fast, ry, waves)] = y
     finally:
-        for k, v in (("el_fast", 1), ("el_fast_ry", 1), ("el_fast_waves", 2048)):
+        for k, v in (("el_fast", 1), ("el_fast_ry", 2), ("el_fast_waves", 4096)):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
     # z-chunking does not change a single bit (same per-node arithmetic)
     assert np.array_equal(outs[(1, 1, 2048)], outs[(1, 1, 1)])
@@ -228,3 +228,26 @@ def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, dim):
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", 1))
     assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"] > 0
     assert np.array_equal(outs[0].values, outs[1].values)
+
+
+def test_fused_and_unfused_k1_and_row_variants_agree(lib, gpu_ctx):
+    """3-D PCG: p-update fused into the marching kernel (default) vs flat p-update + plain apply, 1 | 2 rows per column,
+    thread-per-node kernels: the same solution to solver tolerance (partial sums are grouped differently)"""
+    from pdegpu import elasticity, _lib
+    def tun(**kw):
+        for k, v in kw.items():
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+    outs = []
+    try:
+        for cfg in (dict(el_fast=1, el_fused_k1=1, el_fast_ry=1), dict(el_fast=1, el_fused_k1=0, el_fast_ry=1),
+                    dict(el_fast=1, el_fused_k1=1, el_fast_ry=2), dict(el_fast=0), dict(el_fast=1, el_fused_k1=1, el_fast_ry=1, lazy_dot=0)):
+            tun(**cfg)
+            outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress",
+                                                               rtol=1e-12, want_displacement=True))
+    finally:
+        tun(el_fast=1, el_fused_k1=0, el_fast_ry=2, lazy_dot=1)
+    ref = o.solve_elasticity_3d(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress")
+    for f in outs:
+        assert rel_err(f.values, ref.values) < TOL
+        assert rel_err(f.values, outs[0].values) < 1e-9
+    assert np.array_equal(outs[0].values, outs[4].values)          # lazy vs eager dot products: bitwise
