@@ -34,6 +34,7 @@ struct pdegpu_ctx {
     int el_fused_k1 = 0;        // with el_fast: 1 = p-update fused into the marching kernel; 0 = flat p-update launch + plain apply
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
+    int extrapolate = 1;        // transient solves start CG from 2 u^n - u^{n-1} instead of u^n (fewer iterations, same tolerance)
     int lazy_dot = 1;           // single-slab CG loops: 1 = the next kernel's prologue sums the previous launch's partials (no reduce
                                 // launches); 0 = one-workgroup k_reduce launch after every dot-producing kernel
     int direct_1d = 1;          // 1-D grids: 1 = Thomas recurrence inside one launch (tridiag.hip); 0 = the CG path (diagnostic)
@@ -216,6 +217,7 @@ int vec_zero(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
 // x = Dirichlet value on constrained nodes, `fill` (or nodal[] when non-null, dense host-order device
 // array of the slab) elsewhere
 int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const double* nodal_dense, int only_bc);
+int vec_extrapolate(pdegpu_ctx* ctx, const GridDev& g, double* x, double* xprev, int first);   // x <- 2x - xprev; xprev <- x
 int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal);
 int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, unsigned* counter,
            LaunchInfo* li, const DotIn& di = DotIn());
@@ -239,5 +241,6 @@ int tridiag_setup(pdegpu_ctx* ctx, const GridDev& g, const double* tabA, const d
 int tridiag_run(pdegpu_ctx* ctx, int N, const double* rows, double* work /*device [3][N]*/, double* u, double shift, int rhs_given,
                 int nsteps, int step0, int total_steps, int stride, double* snaps);
 
+int next_poll_chunk(double rr_before, double rr_after, double target, int n_done, int chunk, int cap);   // heat.hip
 GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0, int64_t nk);
 int validate_grid(pdegpu_ctx* ctx, const pdegpu_grid* grid);

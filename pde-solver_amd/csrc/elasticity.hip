@@ -1248,9 +1248,10 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
         }
         if (lz) PG_TRY(el_lazy_finish(&s, lz));
         it += n;
+        const double rr_before = rr;
         PG_TRY(el_scalars(&s, sc));
         rr = sc[ESC_RR];
-        if (chunk < 256) chunk *= 2;
+        chunk = next_poll_chunk(rr_before, rr, target, n, chunk, 256);
     }
     PG_TRY(el_flush(&s));
     PG_HIP(ctx, hipEventRecord(cgt.b, ctx->stream));

@@ -26,6 +26,7 @@ struct pdegpu_session {
     int npt = 15;
     double hA[27 * 27];
     DevVec x, r, p[2], q, b;
+    DevVec xprev;                  // u^{n-1} of a transient solve (allocated on first use)
     int pcur = 0;
     double* d_scal = nullptr;
     double* d_part = nullptr;       // [2][npart]: per-workgroup partials; the second half takes K2's in the lazy loop
@@ -298,7 +299,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -322,6 +323,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "el_grid_mult")) return &ctx->el_grid_mult;
     if (!strcmp(key, "direct_1d")) return &ctx->direct_1d;
     if (!strcmp(key, "lazy_dot")) return &ctx->lazy_dot;
+    if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
     if (!strcmp(key, "el_fast")) return &ctx->el_fast;
     if (!strcmp(key, "el_fast_ry")) return &ctx->el_fast_ry;
     if (!strcmp(key, "el_fused_k1")) return &ctx->el_fused_k1;
@@ -373,6 +375,7 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     for (double* b0 : s->ell_base)
         if (b0) (void)hipFree(b0);
     vec_free(&s->z);
+    vec_free(&s->xprev);
     delete s;
 }
 
@@ -728,6 +731,20 @@ extern "C" int pdegpu_session_get_x(pdegpu_session* s, double* x_out) {
 // ---------------------------------------------------------------------------------------------
 // CG on one slab until ||r|| <= rtol * bnorm  (host polls r.r every `chunk` iterations)
 // ---------------------------------------------------------------------------------------------
+// iterations until the next host poll of r.r: the observed reduction rate of the last chunk predicts how many more
+// iterations reach the target (+10 %), clamped to [4, cap]; without a usable rate the chunk doubles.  The host reads 8
+// bytes per poll, so a few extra polls near convergence are far cheaper than overshooting by half a chunk.
+int next_poll_chunk(double rr_before, double rr_after, double target, int n_done, int chunk, int cap) {
+    if (rr_after > 0.0 && rr_before > rr_after && target > 0.0 && rr_after > target && n_done > 0) {
+        const double rate = std::log(rr_before / rr_after) / n_done;
+        const double need = std::log(rr_after / target) / rate * 1.1 + 1.0;
+        if (need < 4.0) return 4;
+        if (need < (double)cap) return (int)need;
+        return cap;
+    }
+    return chunk < cap ? std::min(2 * chunk, cap) : cap;
+}
+
 namespace {
 int cg_solve(pdegpu_session* s, double bnorm2, double rtol, int max_iter, pdegpu_stats* st, int* iters_out, double* rel_out) {
     pdegpu_ctx* ctx = s->ctx;
@@ -742,10 +759,11 @@ int cg_solve(pdegpu_session* s, double bnorm2, double rtol, int max_iter, pdegpu
     PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
     while (rr > target && it < max_iter && std::isfinite(rr)) {
         const int n = std::min(chunk, max_iter - it);
+        const double rr_before = rr;
         PG_TRY(pdegpu_session_iterate(s, n, 0, nullptr));
         it += n;
         PG_TRY(pdegpu_session_rr(s, &rr));
-        if (chunk < 64) chunk *= 2;
+        chunk = next_poll_chunk(rr_before, rr, target, n, chunk, 64);
     }
     PG_TRY(pdegpu_session_flush(s));
     PG_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -1006,6 +1024,11 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
         for (int n = 0; !direct && n < heat.num_steps && rc == PDEGPU_OK; ++n) {
             // b = M (u^n + dt f)   — `u_n*v*dx + dt*f*v*dx` (:305, :434, :703)
             rc = op_plain(s, 1, s->x.v, heat.dt * heat.source, s->b.v, 0);
+            // CG starts from the linear extrapolation 2 u^n - u^{n-1} (u^n itself on the first step)
+            if (rc == PDEGPU_OK && ctx->extrapolate && heat.num_steps > 1) {
+                if (!s->xprev.base) rc = vec_alloc(ctx, s->g, &s->xprev);
+                if (rc == PDEGPU_OK) rc = vec_extrapolate(ctx, s->g, s->x.v, s->xprev.v, n == 0 ? 1 : 0);
+            }
             if (rc == PDEGPU_OK) rc = linear_solve(s, false, &st);
             const int step = n + 1;
             if ((rc == PDEGPU_OK) && (step % stride == 0 || step == heat.num_steps)) {

@@ -172,6 +172,19 @@ __global__ __launch_bounds__(256) void k_flush(double2* __restrict__ x, const do
     }
 }
 
+// initial guess of the next backward-Euler solve: x <- 2 x - xprev (linear extrapolation in time), xprev <- x.
+// Dirichlet nodes hold the same value in both, pads and ghost planes are zero in both: they stay what they are.
+__global__ __launch_bounds__(256) void k_extrapolate(double2* __restrict__ x, double2* __restrict__ xprev, long long n2, int first) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long long)gridDim.x * 256) {
+        const double2 xv = x[e];
+        if (!first) {
+            const double2 pv = xprev[e];
+            x[e] = make_double2(2.0 * xv.x - pv.x, 2.0 * xv.y - pv.y);
+        }
+        xprev[e] = xv;
+    }
+}
+
 // fixed-order sum of the per-workgroup partials of the previous kernel
 __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ partials, int n, double* __restrict__ scal,
                                                  int which, int copy_to_global) {
@@ -281,6 +294,14 @@ int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p
     const long long n2 = (long long)g.nkl * g.PP / 2;
     hipLaunchKernelGGL(k_flush, dim3(flat_grid(ctx, n2)), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(x),
                        reinterpret_cast<const double2*>(p), n2, scal);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+int vec_extrapolate(pdegpu_ctx* ctx, const GridDev& g, double* x, double* xprev, int first) {
+    const long long n2 = (long long)g.nkl * g.PP / 2;
+    hipLaunchKernelGGL(k_extrapolate, dim3(flat_grid(ctx, n2)), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(x),
+                       reinterpret_cast<double2*>(xprev), n2, first);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }
