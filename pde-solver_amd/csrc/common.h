@@ -21,6 +21,8 @@ struct pdegpu_ctx {
                                 // (3 when one slab vector exceeds 64 MiB, i.e. nothing stays cache-resident)
     int fast_ex = 1;            // 1: CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
                                 // instead of 2-lane global loads (measured: 1.65 -> 1.52 ms per 512^3 CG iteration)
+    int fast_minlen = 1;        // shortest z-chunk of the marching kernels on grids too small to fill the device
+    int fast_small_mult = 1;    // such grids may launch this many resident rounds of workgroups
     int fast_wg_per_cu = 0;     // 0 = occupancy API
     int k2_variant = 0;         // 0: grid-stride double2; 1: 4x unrolled; 2: 4x unrolled + non-temporal
     int grid_mult = 8;          // flat kernels: workgroups per CU

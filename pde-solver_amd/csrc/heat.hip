@@ -299,7 +299,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "fast_minlen", "fast_small_mult", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -324,6 +324,8 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "direct_1d")) return &ctx->direct_1d;
     if (!strcmp(key, "lazy_dot")) return &ctx->lazy_dot;
     if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
+    if (!strcmp(key, "fast_minlen")) return &ctx->fast_minlen;
+    if (!strcmp(key, "fast_small_mult")) return &ctx->fast_small_mult;
     if (!strcmp(key, "el_fast")) return &ctx->el_fast;
     if (!strcmp(key, "el_fast_ry")) return &ctx->el_fast_ry;
     if (!strcmp(key, "el_fused_k1")) return &ctx->el_fused_k1;

@@ -456,13 +456,19 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     const int xy = fg.nxg * fg.nyg;
     // one resident round: (workgroups that fit per CU) x CUs, at least 8 planes per chunk
     int target = wg_per_cu * ctx->num_cu;
+    // chunks of >= 8 planes keep the redundant two-plane prologue below 25 % when there is parallelism to spare; a grid too
+    // small to fill the device is latency-bound on the serial march instead (every plane step is a dependent memory round
+    // trip), so it gets shorter chunks (down to fast_minlen planes) and up to fast_small_mult resident rounds of workgroups
+    int minlen = (int)((long long)planes * xy / (target > 0 ? target : 1));
+    if (minlen < 8) {
+        target *= ctx->fast_small_mult > 0 ? ctx->fast_small_mult : 1;
+        minlen = (int)((long long)planes * xy / (target > 0 ? target : 1));
+    }
+    if (minlen > 8) minlen = 8;
+    if (minlen < ctx->fast_minlen) minlen = ctx->fast_minlen;
+    if (minlen < 1) minlen = 1;
     int nzc = (target + xy - 1) / xy;
     if (nzc < 1) nzc = 1;
-    // chunks of >= 8 planes keep the redundant two-plane prologue below 25 % when there is parallelism to spare; a grid too
-    // small to fill the device is latency-bound on the serial march instead, so it gets shorter chunks (down to 2 planes)
-    int minlen = (int)((long long)planes * xy / (target > 0 ? target : 1));
-    if (minlen > 8) minlen = 8;
-    if (minlen < 2) minlen = 2;
     int maxc = planes / minlen;
     if (maxc < 1) maxc = 1;
     if (nzc > maxc) nzc = maxc;
