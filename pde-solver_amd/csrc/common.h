@@ -36,6 +36,8 @@ struct pdegpu_ctx {
     int el_fused_k1 = 0;        // with el_fast: 1 = p-update fused into the marching kernel; 0 = flat p-update launch + plain apply
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
+    int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary
+                                // nodes; 0 = class-table kernel everywhere
     int extrapolate = 1;        // transient solves start CG from 2 u^n - u^{n-1} instead of u^n (fewer iterations, same tolerance)
     int lazy_dot = 1;           // single-slab CG loops: 1 = the next kernel's prologue sums the previous launch's partials (no reduce
                                 // launches); 0 = one-workgroup k_reduce launch after every dot-producing kernel
@@ -178,6 +180,14 @@ struct StencilArgs {
     unsigned* counter;        // dot_finish ticket counter (device word)
     int dot_which;            // 0: p.q, 1: r.r (the kernel completes the dot product itself), -1: partials only
     DotIn di;                 // CG_K1 / CG_K2: how the previous launch's dot product arrives
+    // hybrid path (3-D grids with natural faces): the marching kernel does the interior nodes, the class-table kernel the
+    // boundary nodes of the slab, enumerated analytically: bnd_n > 0 -> one thread per boundary node instead of per index
+    long long bnd_n = 0;      // boundary nodes of this slab
+    int bnd_full_lo = 0, bnd_full_hi = 0;   // the slab owns global plane 0 / NZ-1 (every node of it is a boundary node)
+    int bnd_lkb = 0;          // first local plane that is interior in z
+    int bnd_ring = 0;         // boundary nodes of such a plane: 2 NX + 2 (NY - 2)
+    int bnd_xcover = 0;       // columns [0, bnd_xcover) of interior rows get p / x from the marching kernel (128-node tiles)
+    int free_x = 0;           // marching kernel: the x-faces carry unknowns (their CG vectors are not zero: load them)
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
 };
@@ -209,6 +219,7 @@ inline long long tunable_key(const pdegpu_ctx* c) {
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 bool stencil_fast_supported(const GridDev& g, int element_mode);
+bool stencil_all_dirichlet(const GridDev& g);
 GridDev stencil_flat2d_view(const GridDev& g);
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 int stencil_max_partials(pdegpu_ctx* ctx);

@@ -23,6 +23,7 @@ struct pdegpu_session {
     HeatTables tabs{};
     double cM = 0, cK = 0;
     bool fast = false;
+    bool hybrid = false;           // fast && some boundary node is free: marching kernel (interior) + class-table kernel (boundary nodes)
     int npt = 15;
     double hA[27 * 27];
     DevVec x, r, p[2], q, b;
@@ -130,6 +131,28 @@ bool is_seven_point(const double* w) {
     return std::fabs(w[4]) <= tol && std::fabs(w[5]) <= tol && std::fabs(w[6]) <= tol && std::fabs(w[7]) <= tol;
 }
 
+// hybrid sessions: second launch of an operator application — the boundary nodes of the slab through the class-table
+// kernel (same mode, same arguments), its partials appended to the marching kernel's
+int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_fast) {
+    const GridDev& g = s->g;
+    a.g = g;
+    a.bnd_full_lo = g.k0 == 0 ? 1 : 0;
+    a.bnd_full_hi = g.k0 + g.nkl == g.NZ ? 1 : 0;
+    a.bnd_lkb = a.bnd_full_lo;
+    const int planes = std::max(0, g.nkl - a.bnd_full_lo - a.bnd_full_hi);
+    a.bnd_ring = 2 * g.NX + 2 * (g.NY - 2);
+    a.bnd_xcover = std::min(g.PX, ((g.NX - 1 + 127) / 128) * 128);
+    a.bnd_n = (long long)(a.bnd_full_lo + a.bnd_full_hi) * g.NX * g.NY + (long long)planes * a.bnd_ring;
+    if (a.bnd_n <= 0) return PDEGPU_OK;
+    const int n1 = li_fast ? li_fast->grid : 0;
+    a.partials = s->d_part + n1;
+    a.dot_which = -1;
+    LaunchInfo l2;
+    PG_TRY(stencil_general(s->ctx, a, mode, &l2));
+    if (li_fast) li_fast->grid = n1 + l2.grid;
+    return PDEGPU_OK;
+}
+
 // out = T (in + shift)   with T = A (which==0) or M (which==1); unmasked unless mask
 int op_plain(pdegpu_session* s, int which, const double* in, double shift, double* out, int mask) {
     StencilArgs a{};
@@ -152,7 +175,10 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
         a.g = s->gk;
         fast_weights(htab, a.w, s->gk.flat2d != 0);
         a.npt = is_seven_point(a.w) ? 7 : 15;
-        return stencil_fast(s->ctx, a, APPLY_PLAIN, nullptr);
+        a.free_x = s->hybrid ? 1 : 0;
+        LaunchInfo lf;
+        PG_TRY(stencil_fast(s->ctx, a, APPLY_PLAIN, &lf));
+        return s->hybrid ? hybrid_boundary(s, a, APPLY_PLAIN, &lf) : PDEGPU_OK;
     }
     return stencil_general(s->ctx, a, APPLY_PLAIN, nullptr);
 }
@@ -178,14 +204,17 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
-        return stencil_fast(s->ctx, a, APPLY_RESIDUAL, li);
+        a.free_x = s->hybrid ? 1 : 0;
+        if (s->hybrid) a.dot_which = -1;
+        PG_TRY(stencil_fast(s->ctx, a, APPLY_RESIDUAL, li));
+        return s->hybrid ? hybrid_boundary(s, a, APPLY_RESIDUAL, li) : PDEGPU_OK;
     }
     return stencil_general(s->ctx, a, APPLY_RESIDUAL, li);
 }
 
 // 64 B/DoF variant (K2 recomputes q with the marching stencil): pays for the 7-point operator only — with the
 // 15-point operator the second stencil pass costs more than the 8 B/DoF it saves (measured)
-bool k2_is_stencil(const pdegpu_session* s) { return s->fast && s->ctx->cg_variant == 1 && s->npt == 7; }
+bool k2_is_stencil(const pdegpu_session* s) { return s->fast && !s->hybrid && s->ctx->cg_variant == 1 && s->npt == 7; }
 
 int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
     StencilArgs a{};
@@ -211,7 +240,10 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
+        a.free_x = s->hybrid ? 1 : 0;
+        if (s->hybrid) a.dot_which = -1;
         rc = stencil_fast(s->ctx, a, APPLY_CG_K1, li);
+        if (rc == PDEGPU_OK && s->hybrid) rc = hybrid_boundary(s, a, APPLY_CG_K1, li);
     } else {
         rc = stencil_general(s->ctx, a, APPLY_CG_K1, li);
     }
@@ -250,7 +282,7 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
 // (k_reduce); with the inlaunch_dot tunable the producing kernel has already done it (dot_finish.h) unless its grid
 // was empty (a slab without free planes), in which case the sum 0 still has to be recorded
 int empty_dot(pdegpu_session* s, const LaunchInfo& li, int which) {
-    if (s->ctx->inlaunch_dot && li.grid > 0) return PDEGPU_OK;
+    if (s->ctx->inlaunch_dot && li.grid > 0 && !s->hybrid) return PDEGPU_OK;
     return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, which, 1);
 }
 int residual_finish(pdegpu_session* s, LaunchInfo* li) {
@@ -299,7 +331,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "fast_minlen", "fast_small_mult", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "k2_variant", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "fast_minlen", "fast_small_mult", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -324,6 +356,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "direct_1d")) return &ctx->direct_1d;
     if (!strcmp(key, "lazy_dot")) return &ctx->lazy_dot;
     if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
+    if (!strcmp(key, "hybrid_bc")) return &ctx->hybrid_bc;
     if (!strcmp(key, "fast_minlen")) return &ctx->fast_minlen;
     if (!strcmp(key, "fast_small_mult")) return &ctx->fast_small_mult;
     if (!strcmp(key, "el_fast")) return &ctx->el_fast;
@@ -407,6 +440,8 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     int rc = tables_build(ctx, grid, &s->tabs);
     if (rc == PDEGPU_OK) rc = tables_combine(ctx, &s->tabs, s->cM, s->cK, s->tabs.d_tabA, s->hA);
     s->fast = heat->fast_path != 0 && stencil_fast_supported(s->g, grid->element_mode);
+    s->hybrid = s->fast && !stencil_all_dirichlet(s->g) && ctx->hybrid_bc != 0;
+    if (s->fast && !stencil_all_dirichlet(s->g) && !s->hybrid) s->fast = false;
     s->gk = (s->fast && s->g.dim == 2) ? stencil_flat2d_view(s->g) : s->g;
     if (s->fast) {
         double w[8];
@@ -620,7 +655,7 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
     }
     if (stats) {
         stats->cg_iterations += iters;
-        stats->path = s->fast ? 1 : 0;
+        stats->path = s->hybrid ? 3 : (s->fast ? 1 : 0);
         if (time_kernels && iters > 0) {
             PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
             const double nloc = (double)s->g.nkl * s->g.NY * s->g.NX;
@@ -960,7 +995,7 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
     }
     const size_t N = (size_t)pdegpu_grid_num_nodes(grid);
     st.n_nodes = (int64_t)N;
-    st.path = s->fast ? 1 : 0;
+    st.path = s->hybrid ? 3 : (s->fast ? 1 : 0);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PDEGPU_OK;
     auto fail = [&](int code) {

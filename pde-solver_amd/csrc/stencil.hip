@@ -57,16 +57,45 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
     }
 
     const GridDev& g = a.g;
-    const long long total = (long long)g.nkl * g.PP;
+    const bool bnd = a.bnd_n > 0;
+    const long long total = bnd ? a.bnd_n : (long long)g.nkl * g.PP;
     double alpha_prev = 0.0, beta = 0.0;
     if (MODE == APPLY_CG_K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
 
     double acc = 0.0;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int i = (int)(idx % g.PX);
-        const long long row = idx / g.PX;
-        const int j = (int)(row % g.NY);
-        const int lk = (int)(row / g.NY);
+    for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += (long long)gridDim.x * 256) {
+        long long idx = e0;
+        int i, j, lk;
+        if (bnd) {
+            // boundary node e0 of the slab: the full planes z = 0 / NZ-1 first, then the ring of every other plane
+            long long e = e0;
+            const long long plane_nodes = (long long)g.NX * g.NY;
+            if (a.bnd_full_lo && e < plane_nodes) {
+                lk = -g.k0;
+                j = (int)(e / g.NX);
+                i = (int)(e % g.NX);
+            } else {
+                e -= a.bnd_full_lo ? plane_nodes : 0;
+                if (a.bnd_full_hi && e < plane_nodes) {
+                    lk = g.NZ - 1 - g.k0;
+                    j = (int)(e / g.NX);
+                    i = (int)(e % g.NX);
+                } else {
+                    e -= a.bnd_full_hi ? plane_nodes : 0;
+                    lk = a.bnd_lkb + (int)(e / a.bnd_ring);
+                    const int t = (int)(e % a.bnd_ring);
+                    if (t < g.NX) { j = 0; i = t; }
+                    else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
+                    else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
+                }
+            }
+            idx = (long long)lk * g.PP + (long long)j * g.PX + i;
+        } else {
+            i = (int)(idx % g.PX);
+            const long long row = idx / g.PX;
+            j = (int)(row % g.NY);
+            lk = (int)(row / g.NY);
+        }
         const int kg = g.k0 + lk;
         const bool real = i < g.NX;
         double dval = 0.0;
@@ -76,8 +105,12 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
         if (MODE == APPLY_CG_K1) {
             const double po = a.p_old[idx];
             pn = a.in[idx] + beta * po;
-            a.p_new[idx] = pn;
-            if (alpha_prev != 0.0) a.x[idx] += alpha_prev * po;
+            // hybrid: the marching kernel owns p / x of every node of its rows (interior j and k), x-faces included
+            const bool theirs = bnd && j >= 1 && j <= g.NY - 2 && kg >= 1 && kg <= g.NZ - 2 && i < a.bnd_xcover;
+            if (!theirs) {
+                a.p_new[idx] = pn;
+                if (alpha_prev != 0.0) a.x[idx] += alpha_prev * po;
+            }
         }
         double s = 0.0;
         if (ELL && real && !dir) {
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             // a global load only where the neighbour tile belongs to another workgroup AND the node can be non-zero:
             // CG vectors (K1: r, p; K2: p) vanish on the Dirichlet columns, PLAIN / RESIDUAL inputs carry boundary values
             const int il = xt * 128 - 1, ir = xt * 128 + 128;
-            const bool cgvec = K1 || K2;
+            const bool cgvec = (K1 || K2) && !a.free_x;
             const bool gl = !has_l && il >= 0 && (il >= 1 || !cgvec) && active;
             const bool gr = !has_r && ir <= g.NX - 1 && (ir <= g.NX - 2 || !cgvec) && active;
 #pragma unroll
@@ -532,7 +565,7 @@ int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* 
 }  // namespace
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
-    const long long total = (long long)a.g.nkl * a.g.PP;
+    const long long total = a.bnd_n > 0 ? a.bnd_n : (long long)a.g.nkl * a.g.PP;
     long long nb = (total + 255) / 256;
     const long long cap = (long long)ctx->grid_mult * ctx->num_cu;
     if (nb > cap) nb = cap;
@@ -558,11 +591,14 @@ int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo*
 // fast path: 3-D (or 2-D through the flat view), P1 split, every boundary node Dirichlet (uniform mode), at least one
 // interior node per axis
 bool stencil_fast_supported(const GridDev& g, int element_mode) {
-    if (element_mode != PDEGPU_ELEM_P1SPLIT || g.bc_mode != PDEGPU_BC_UNIFORM || !g.bc_present[0]) return false;
-    if (g.dim == 3) return g.NX >= 3 && g.NY >= 3 && g.NZ >= 3;
+    if (element_mode != PDEGPU_ELEM_P1SPLIT) return false;
+    if (g.dim == 3) return g.NX >= 3 && g.NY >= 3 && g.NZ >= 3;       // natural faces: hybrid (stencil_all_dirichlet false)
+    if (g.bc_mode != PDEGPU_BC_UNIFORM || !g.bc_present[0]) return false;
     if (g.dim == 2) return g.NX >= 3 && g.NY >= 3;
     return false;
 }
+// every boundary node constrained: the marching kernels alone cover the free nodes
+bool stencil_all_dirichlet(const GridDev& g) { return g.bc_mode == PDEGPU_BC_UNIFORM && g.bc_present[0]; }
 
 // The 2-D P1 operator (5-point stiffness, 7-point mass with the +-(1,1) diagonal of the "right" triangle split) is the
 // 3-D 15-point kernel restricted to ONE row of the middle axis: (x, y) -> (x, z), weights w0, wx, wz = w_y2d,

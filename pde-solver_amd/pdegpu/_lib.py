@@ -63,7 +63,7 @@ class Stats(C.Structure):
                 "linear_solves": self.linear_solves, "converged": bool(self.converged),
                 "final_rel_residual": self.final_rel_residual, "solve_ms": self.solve_ms, "cg_ms": self.cg_ms,
                 "kernel_ms": list(self.kernel_ms), "kernel_launches": list(self.kernel_launches),
-                "alg_bytes": list(self.alg_bytes), "path": {1: "fast", 2: "tridiagonal-direct"}.get(self.path, "general")}
+                "alg_bytes": list(self.alg_bytes), "path": {1: "fast", 2: "tridiagonal-direct", 3: "fast+boundary"}.get(self.path, "general")}
 
 
 _dp = C.POINTER(C.c_double)

@@ -179,11 +179,29 @@ def test_heat_3d_directional_bc_natural_faces(lib, gpu_ctx, bcs):
               num_steps=3, source_type="constant", source_value=1.5, **bcs)
     got = heat._solve_heat_3d_raw(**kw, rtol=1e-12)
     ref = o.solve_heat_3d(**kw)
-    assert got.meta["solver_path"] == "general"
+    assert got.meta["solver_path"] == "fast+boundary"      # marching kernel (interior) + class-table kernel (boundary nodes)
     assert rel_err(got.values, ref.values) < TOL
+    gen = heat._solve_heat_3d_raw(**kw, rtol=1e-12, fast_path=False)
+    assert gen.meta["solver_path"] == "general" and rel_err(gen.values, ref.values) < TOL
     for k, v in bcs.items():
         assert (k in got.meta) == (v is not None)
     assert "T_boundary" not in got.meta
+
+
+@pytest.mark.parametrize("nx", [128, 129, 130, 257])
+@pytest.mark.parametrize("steady", [False, True])
+def test_hybrid_path_tile_edges_and_modes(lib, gpu_ctx, nx, steady):
+    """hybrid (natural faces) runs vs the class-table kernels on grids whose last x-node falls on / next to a 128-node tile
+    boundary (the marching kernel covers x = NX-1 only when a tile reaches it), steady (7-point) and transient (15-point)"""
+    from pdegpu import heat
+    kw = dict(Lx=2.0, Ly=0.5, Lz=0.4, nx=nx, ny=5, nz=4, diffusivity=0.7, T_boundary=0.0, T_initial=2.0, dt=0.02,
+              num_steps=2, source_type="constant", source_value=1.5, T_left=10.0, T_right=None, T_side=None, steady=steady)
+    a = heat._solve_heat_3d_raw(**kw, rtol=1e-12)
+    b = heat._solve_heat_3d_raw(**kw, rtol=1e-12, fast_path=False)
+    assert a.meta["solver_path"] == "fast+boundary" and b.meta["solver_path"] == "general"
+    assert rel_err(a.values, b.values) < TOL
+    if nx <= 130:
+        assert rel_err(a.values, o.solve_heat_3d(**kw).values) < TOL
 
 
 @pytest.mark.parametrize("dim", [1, 2, 3])
@@ -282,7 +300,7 @@ def test_fast_and_general_sessions_agree(lib, gpu_ctx):
     assert rel_err(out[0][1], out[1][1]) < 1e-11
 
 
-@pytest.mark.parametrize("fast,variant", [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("fast,variant", [(1, 1), (1, 0), (0, 0), (2, 1)])
 @pytest.mark.parametrize("nslabs", [2, 3])
 def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs):
     """slab sessions (k0 > 0, ghost planes, global boundary classes) with the halo exchange / all-reduce done by
@@ -297,7 +315,10 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs)
     h.kappa, h.steady, h.source = 1.1, 1, 3.0
     h.bc_mode, h.fast_path = _lib.BC_UNIFORM, fast
     h.bc_present[0], h.bc_value[0] = 1, 0.25
-    iters = 150
+    hybrid = fast == 2                       # natural faces except x = 0: marching kernel + boundary kernel per slab
+    if hybrid:
+        h.bc_mode, h.fast_path = _lib.BC_DIRECTIONAL, 1
+    iters = 600 if hybrid else 150
 
     def solve(ns):
         stream = torch.cuda.Stream()
@@ -308,7 +329,7 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs)
                 engs.append(GpuSlabEngine(grid, h, k0, nk, 0, stream))
                 _lib.check(engs[-1].ctx, lib.pdegpu_set_tunable(engs[-1].ctx, b"cg_variant", variant))
             # the 64-B variant keeps p on the ghost planes itself: only r is exchanged
-            assert engs[0].needs_p_halo() == (not (fast == 1 and variant == 1))
+            assert engs[0].needs_p_halo() == (not (fast == 1 and variant == 1))      # hybrid: q is stored, r and p travel
             vecs = (VEC_R, VEC_P) if engs[0].needs_p_halo() else (VEC_R,)
 
             def exchange():
@@ -354,7 +375,8 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs)
 
     x1, h1 = solve(1)
     xs, hs = solve(nslabs)
-    ref = o.solve_heat_3d(*Ls, *n, 1.1, 0.25, 0.0, 0.1, 1, steady=True, source_type="constant", source_value=3.0).values[0]
+    ref = o.solve_heat_3d(*Ls, *n, 1.1, 0.25, 0.0, 0.1, 1, steady=True, source_type="constant", source_value=3.0,
+                          **(dict(T_left=0.25) if hybrid else {})).values[0]
     assert np.allclose(hs, h1, rtol=1e-10)
     assert rel_err(x1, ref) < TOL and rel_err(xs, ref) < TOL
     assert rel_err(xs, x1) < 1e-11
