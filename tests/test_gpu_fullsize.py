@@ -71,3 +71,31 @@ def test_steady_solve_at_512_cubed_satisfies_its_equation(lib, gpu_ctx):
     assert U.max() == pytest.approx(0.0562128, rel=2e-4)                    # max of -Lap u = 1 on the unit cube
     assert np.abs(U - U[::-1]).max() <= 1e-6 * U.max() and np.abs(U - U.transpose(2, 1, 0)).max() <= 1e-6 * U.max()
     print(f"\n512^3 steady solve: {f.meta['cg_iterations']} CG iterations")
+
+
+def test_repeated_solves_do_not_leak_device_memory(lib, gpu_ctx):
+    """every handle a solve creates dies with it (INTEGRATION.md ownership rule): free device memory after 40 mixed solves
+    is what it was after the first round"""
+    import torch
+    from pdegpu import heat, elasticity, curvilinear as cv
+
+    def round_():
+        heat._solve_heat_1d_raw(2.0, 300, 1.0, 20.0, 0.0, 0.0, 0.01, 5)
+        heat._solve_heat_2d_raw(1.0, 1.0, 96, 64, 1.0, 0.0, 20.0, 0.003, 2)
+        heat._solve_heat_3d_raw(1.0, 1.0, 1.0, 40, 24, 20, 1.0, 0.0, 20.0, 0.003, 2)
+        heat._solve_heat_3d_raw(1.0, 1.0, 1.0, 40, 24, 20, 1.0, 0.0, 20.0, 0.003, 2, T_left=5.0, T_right=1.0)
+        heat._solve_heat_3d_raw(1.0, 1.0, 1.0, 20, 12, 10, 1.0, 0.0, 20.0, 0.003, 1, initial_type="sine")
+        elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 24, 6, 5, 210e9, 0.3, 0.0, 0.0, -7.0e4, "stress", rtol=1e-8)
+        elasticity._solve_elasticity_2d_static(1.0, 0.3, 24, 9, 210e9, 0.3, 0.0, -5.0e4, "strain", True, rtol=1e-8)
+        cv._solve_heat_2d_cylindrical_raw(r_inner=0.1, r_outer=1.0, z_length=2.0, nr=20, nz=16, diffusivity=1.0, T_boundary=0.0,
+                                          T_initial=20.0, dt=0.01, num_steps=2, steady=False, source_type="none", source_value=0.0,
+                                          initial_type="constant", initial_amplitude=1.0)
+
+    round_()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        round_()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 40 solves"
