@@ -126,6 +126,18 @@ void fast_weights(const double* tab, double* w, bool flat2d = false) {
     }
 }
 
+// Q1 interior stencil: the weight of an offset depends on |dx|, |dy|, |dz| only (checked before the 27-point marching
+// kernel, which assumes it, is used)
+bool is_sign_symmetric(const double* c /*27 class-13 weights*/) {
+    double scale = std::fabs(c[13]);
+    for (int o = 0; o < 27; ++o) {
+        const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+        const int rep = (std::abs(dx) + 1) + 3 * (std::abs(dy) + 1) + 9 * (std::abs(dz) + 1);
+        if (std::fabs(c[o] - c[rep]) > 1e-13 * scale) return false;
+    }
+    return true;
+}
+
 bool is_seven_point(const double* w) {
     const double tol = 1e-12 * std::fabs(w[0]);
     return std::fabs(w[4]) <= tol && std::fabs(w[5]) <= tol && std::fabs(w[6]) <= tol && std::fabs(w[7]) <= tol;
@@ -174,7 +186,7 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     if (s->fast) {
         a.g = s->gk;
         fast_weights(htab, a.w, s->gk.flat2d != 0);
-        a.npt = is_seven_point(a.w) ? 7 : 15;
+        a.npt = s->grid.element_mode == PDEGPU_ELEM_Q1 ? 27 : (is_seven_point(a.w) ? 7 : 15);
         a.free_x = s->hybrid ? 1 : 0;
         LaunchInfo lf;
         PG_TRY(stencil_fast(s->ctx, a, APPLY_PLAIN, &lf));
@@ -447,6 +459,12 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
         double w[8];
         fast_weights(s->hA, w, s->gk.flat2d != 0);
         s->npt = is_seven_point(w) ? 7 : 15;
+        if (grid->element_mode == PDEGPU_ELEM_Q1) {
+            // 27-point marching kernel: needs the sign symmetry of the Q1 interior weights (stiffness and mass)
+            if (is_sign_symmetric(s->hA + 13 * 27) && is_sign_symmetric(s->tabs.h_tabM + 13 * 27) &&
+                is_sign_symmetric(s->tabs.h_tabK + 13 * 27)) s->npt = 27;
+            else s->fast = s->hybrid = false;
+        }
     }
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
     for (DevVec* v : vecs)

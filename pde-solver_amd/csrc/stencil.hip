@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     constexpr bool K1 = (MODE == APPLY_CG_K1);
     constexpr bool K2 = (MODE == APPLY_CG_K2);
     constexpr bool RES = (MODE == APPLY_RESIDUAL) || K2;      // out = rhs - scale * (A in)
-    constexpr bool W15 = (NPT == 15);
+    constexpr bool W15 = (NPT == 15) || (NPT == 27);     // every held row of every plane is needed (x-diagonals)
+    constexpr bool W27 = (NPT == 27);                     // Q1: all 26 neighbours, weights symmetric under every sign flip
     constexpr int RH = RY + 2;                 // rows held per plane (own rows + one halo row each side)
 
     // XCD-aware workgroup -> tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only), so
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         for (int r = 0; r < RH; ++r) {
             const bool own = (r >= 1) && (r <= RY);
             const int j = j0 - 1 + r;
-            // plane lk0-1: 7-point needs own rows only; 15-point rows j-1..j (r = 0..RY)
-            if (W15 ? (r <= RY) : own) P[r] = value_row(lk0 - 1, j, nullptr);
+            // plane lk0-1: 7-point needs own rows only; 15-point rows j-1..j (r = 0..RY); 27-point all rows
+            if (W27 || (W15 ? (r <= RY) : own)) P[r] = value_row(lk0 - 1, j, nullptr);
             else P[r] = make_double2(0.0, 0.0);
             EP[r] = 0.0;
             double2 po = make_double2(0.0, 0.0);
@@ -420,21 +421,37 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                     rC = (lane == 63) ? EC[c] : rC;
                     double qa = w0 * C[c].x + wx * (lC + C[c].y) + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x);
                     double qb = w0 * C[c].y + wx * (C[c].x + rC) + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y);
-                    if (W15) {
-                        // same-sign diagonals of the Kuhn split: +-(1,1,0), +-(1,0,1), +-(0,1,1), +-(1,1,1)
-                        double lCm = dpp_from_lower(C[c - 1].y), rCp = dpp_from_upper(C[c + 1].x);
-                        double lP = dpp_from_lower(P[c].y), rN = dpp_from_upper(N[c].x);
-                        double lPm = dpp_from_lower(P[c - 1].y), rNp = dpp_from_upper(N[c + 1].x);
-                        lCm = (lane == 0) ? EC[c - 1] : lCm;
-                        rCp = (lane == 63) ? EC[c + 1] : rCp;
-                        lP = (lane == 0) ? EP[c] : lP;
-                        rN = (lane == 63) ? EN[c] : rN;
-                        lPm = (lane == 0) ? EP[c - 1] : lPm;
-                        rNp = (lane == 63) ? EN[c + 1] : rNp;
-                        qa += wxy * (C[c + 1].y + lCm) + wxz * (N[c].y + lP) + wyz * (N[c + 1].x + P[c - 1].x) +
-                              wxyz * (N[c + 1].y + lPm);
-                        qb += wxy * (rCp + C[c - 1].x) + wxz * (rN + P[c].x) + wyz * (N[c + 1].y + P[c - 1].y) +
-                              wxyz * (rNp + P[c - 1].x);
+                    if (W27) {
+                        // Q1: q = w0 C + wy Sy + wz Sz + wyz Syz + l(T) + r(T),  T = wx C + wxy Sy + wxz Sz + wxyz Syz with the row
+                        // sums Sy = C[j-1] + C[j+1], Sz = P + N, Syz = P[j-1] + P[j+1] + N[j-1] + N[j+1]: two x-shifts per node
+                        const double2 Sy = make_double2(C[c - 1].x + C[c + 1].x, C[c - 1].y + C[c + 1].y);
+                        const double2 Sz = make_double2(P[c].x + N[c].x, P[c].y + N[c].y);
+                        const double2 Syz = make_double2((P[c - 1].x + P[c + 1].x) + (N[c - 1].x + N[c + 1].x),
+                                                         (P[c - 1].y + P[c + 1].y) + (N[c - 1].y + N[c + 1].y));
+                        const double2 T = make_double2(wx * C[c].x + wxy * Sy.x + wxz * Sz.x + wxyz * Syz.x,
+                                                       wx * C[c].y + wxy * Sy.y + wxz * Sz.y + wxyz * Syz.y);
+                        const double Te = wx * EC[c] + wxy * (EC[c - 1] + EC[c + 1]) + wxz * (EP[c] + EN[c]) +
+                                          wxyz * ((EP[c - 1] + EP[c + 1]) + (EN[c - 1] + EN[c + 1]));
+                        double lT = dpp_from_lower(T.y), rT = dpp_from_upper(T.x);
+                        lT = (lane == 0) ? Te : lT;
+                        rT = (lane == 63) ? Te : rT;
+                        qa = w0 * C[c].x + wy * Sy.x + wz * Sz.x + wyz * Syz.x + lT + T.y;
+                        qb = w0 * C[c].y + wy * Sy.y + wz * Sz.y + wyz * Syz.y + T.x + rT;
+                    } else if (W15) {
+                        // same-sign diagonals of the Kuhn split: +-(1,1,0), +-(1,0,1), +-(0,1,1), +-(1,1,1).  Everything whose
+                        // source sits at x+1 is accumulated in U, at x-1 in L, and the x-shift is applied to the two sums:
+                        // 2 DPP pairs per node instead of 8 (the x-term of the 7-point part included)
+                        const double2 U = make_double2(wx * C[c].x + wxy * C[c + 1].x + wxz * N[c].x + wxyz * N[c + 1].x,
+                                                       wx * C[c].y + wxy * C[c + 1].y + wxz * N[c].y + wxyz * N[c + 1].y);
+                        const double2 Lw = make_double2(wx * C[c].x + wxy * C[c - 1].x + wxz * P[c].x + wxyz * P[c - 1].x,
+                                                        wx * C[c].y + wxy * C[c - 1].y + wxz * P[c].y + wxyz * P[c - 1].y);
+                        const double Ue = wx * EC[c] + wxy * EC[c + 1] + wxz * EN[c] + wxyz * EN[c + 1];     // lane 63: node i0+2
+                        const double Le = wx * EC[c] + wxy * EC[c - 1] + wxz * EP[c] + wxyz * EP[c - 1];     // lane 0: node i0-1
+                        double lL = dpp_from_lower(Lw.y), rU = dpp_from_upper(U.x);
+                        lL = (lane == 0) ? Le : lL;
+                        rU = (lane == 63) ? Ue : rU;
+                        qa = w0 * C[c].x + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x) + wyz * (N[c + 1].x + P[c - 1].x) + U.y + lL;
+                        qb = w0 * C[c].y + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y) + wyz * (N[c + 1].y + P[c - 1].y) + rU + Lw.x;
                     }
                     double2 o;
                     if (RES) {
@@ -591,7 +608,7 @@ int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo*
 // fast path: 3-D (or 2-D through the flat view), P1 split, every boundary node Dirichlet (uniform mode), at least one
 // interior node per axis
 bool stencil_fast_supported(const GridDev& g, int element_mode) {
-    if (element_mode != PDEGPU_ELEM_P1SPLIT) return false;
+    if (element_mode != PDEGPU_ELEM_P1SPLIT && element_mode != PDEGPU_ELEM_Q1) return false;
     if (g.dim == 3) return g.NX >= 3 && g.NY >= 3 && g.NZ >= 3;       // natural faces: hybrid (stencil_all_dirichlet false)
     if (g.bc_mode != PDEGPU_BC_UNIFORM || !g.bc_present[0]) return false;
     if (g.dim == 2) return g.NX >= 3 && g.NY >= 3;
@@ -616,6 +633,7 @@ GridDev stencil_flat2d_view(const GridDev& g) {
 }
 
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
     if (a.npt == 7) {
         if (ctx->fast_ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
         if (ctx->fast_ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);

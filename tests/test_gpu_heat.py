@@ -262,7 +262,7 @@ def test_q1_mode_differs_by_h2(lib, gpu_ctx):
                   num_steps=5)
         q1 = heat._solve_heat_3d_raw(**kw, rtol=1e-12, element_mode=_lib.ELEM_Q1)
         ref = o.solve_heat_3d(**kw)
-        assert q1.meta["element_mode"] == "q1" and q1.meta["solver_path"] == "general"
+        assert q1.meta["element_mode"] == "q1" and q1.meta["solver_path"] == "fast"        # 27-point marching kernel
         errs.append(rel_err(q1.values[-1], ref.values[-1]))
     assert 1e-4 < errs[1] < errs[0] < 0.1
     assert errs[0] / errs[1] > 2.5
@@ -507,3 +507,23 @@ def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, case):
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_variant", 1))
     assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"] > 0
     assert np.array_equal(outs[0].values, outs[1].values)
+
+
+@pytest.mark.parametrize("case", ["3d_transient", "3d_steady", "3d_natural_faces", "2d_transient", "3d_wide"])
+def test_q1_27_point_marching_kernel_matches_class_table_kernel(lib, gpu_ctx, case):
+    """Q1 element mode: the 27-point (2-D: 9-point) form of the marching kernel — two x-shifts per node, weights by
+    |dx|,|dy|,|dz| — against the class-table kernel on anisotropic cells; and the bare operator against the host tables"""
+    from pdegpu import heat, _lib
+    q1 = dict(element_mode=_lib.ELEM_Q1, rtol=1e-12)
+    if case == "2d_transient":
+        run = lambda fast: heat._solve_heat_2d_raw(1.0, 0.7, 150, 40, 0.8, 3.0, 20.0, 0.004, 3, fast_path=fast, **q1)
+    else:
+        n = (140, 9, 7) if case == "3d_wide" else (30, 17, 12)
+        kw = dict(Lx=1.0, Ly=0.8, Lz=0.3, nx=n[0], ny=n[1], nz=n[2], diffusivity=0.9, T_boundary=1.5, T_initial=20.0, dt=0.003,
+                  num_steps=2, steady=(case == "3d_steady"), source_type="constant", source_value=2.0)
+        if case == "3d_natural_faces":
+            kw.update(T_left=10.0, T_right=None, T_side=None)
+        run = lambda fast: heat._solve_heat_3d_raw(**kw, fast_path=fast, **q1)
+    a, b = run(True), run(False)
+    assert a.meta["solver_path"] == ("fast+boundary" if case == "3d_natural_faces" else "fast") and b.meta["solver_path"] == "general"
+    assert a.meta["element_mode"] == "q1" and rel_err(a.values, b.values) < TOL
