@@ -120,7 +120,7 @@ int         pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen);
 const char* pdegpu_version(void);
 /* performance tunables of a context (also read from PDEGPU_<KEY> at pdegpu_create): "fast_ry" rows per thread of
  * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_ex" (1 = LDS hand-off of tile-edge values in the CG kernels), "fast_wg_per_cu" (0 = occupancy API),
- * "k2_variant" (0..5), "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
+ * "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
  * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF), "use_graph"
  * (1 = replay the CG inner loop from a captured hipGraph), "inlaunch_dot" (1 = finish dot products inside the producing
  * launch instead of a separate one-workgroup reduce launch; measured slower), "lazy_dot" (1 = the next

@@ -24,7 +24,6 @@ struct pdegpu_ctx {
     int fast_minlen = 1;        // shortest z-chunk of the marching kernels on grids too small to fill the device
     int fast_small_mult = 1;    // such grids may launch this many resident rounds of workgroups
     int fast_wg_per_cu = 0;     // 0 = occupancy API
-    int k2_variant = 0;         // 0: grid-stride double2; 1: 4x unrolled; 2: 4x unrolled + non-temporal
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
     int inlaunch_dot = 0;       // opt-in: finish dot products inside the producing launch (dot_finish.h).  Measured slower:
@@ -213,8 +212,8 @@ struct CgGraph {
     }
 };
 inline long long tunable_key(const pdegpu_ctx* c) {
-    return (((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 8 + c->k2_variant) * 128 + c->grid_mult) * 128 +
-             c->k2_grid_mult) * 4 + c->cg_variant) * 2 + c->fast_ex;
+    return ((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 128 + c->grid_mult) * 128 + c->k2_grid_mult) * 4 +
+            c->cg_variant) * 2 + c->fast_ex;
 }
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);

@@ -66,73 +66,6 @@ __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const doubl
     dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
 }
 
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-
-// U independent 16-B streams per lane per trip (2U loads in flight), optionally non-temporal
-template <int NT, int U>
-__global__ __launch_bounds__(256) void k_k2_u4(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
-                                                double* scal, double* __restrict__ partials, unsigned* counter) {
-    __shared__ double sRed[4];
-    const double pq = scal[SC_PQ], rr = scal[SC_RR];
-    const double alpha = (pq > 0.0) ? rr / pq : 0.0;
-    double acc = 0.0;
-    const long long stride = (long long)gridDim.x * 256;
-    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (; e + (U - 1) * stride < n2; e += U * stride) {
-        dbl2 rv[U], qv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const dbl2* rp = reinterpret_cast<const dbl2*>(r + e + u * stride);
-            const dbl2* qp = reinterpret_cast<const dbl2*>(q + e + u * stride);
-            rv[u] = NT ? __builtin_nontemporal_load(rp) : *rp;
-            qv[u] = NT ? __builtin_nontemporal_load(qp) : *qp;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            rv[u] -= alpha * qv[u];
-            dbl2* wp = reinterpret_cast<dbl2*>(r + e + u * stride);
-            if (NT) __builtin_nontemporal_store(rv[u], wp);
-            else *wp = rv[u];
-            acc += rv[u].x * rv[u].x + rv[u].y * rv[u].y;
-        }
-    }
-    for (; e < n2; e += stride) {
-        double2 rv = r[e];
-        const double2 qv = q[e];
-        rv.x -= alpha * qv.x;
-        rv.y -= alpha * qv.y;
-        r[e] = rv;
-        acc += rv.x * rv.x + rv.y * rv.y;
-    }
-    const double tot = block_sum_256(acc, sRed);
-    __syncthreads();
-    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
-}
-
-// contiguous chunk per workgroup instead of a grid-stride interleave
-__global__ __launch_bounds__(256) void k_k2_chunk(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
-                                                   double* scal, double* __restrict__ partials, unsigned* counter) {
-    __shared__ double sRed[4];
-    const double pq = scal[SC_PQ], rr = scal[SC_RR];
-    const double alpha = (pq > 0.0) ? rr / pq : 0.0;
-    double acc = 0.0;
-    const long long per = ((n2 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
-    const long long beg = per * blockIdx.x, end = beg + per < n2 ? beg + per : n2;
-    for (long long e = beg + threadIdx.x; e < end; e += 256) {
-        double2 rv = r[e];
-        const double2 qv = q[e];
-        rv.x -= alpha * qv.x;
-        rv.y -= alpha * qv.y;
-        r[e] = rv;
-        acc += rv.x * rv.x + rv.y * rv.y;
-    }
-    const double tot = block_sum_256(acc, sRed);
-    __syncthreads();
-    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
-}
-
-// in-run memory calibration (bench.py): 0 copy b=q, 1 read-only sum(r), 2 write-only b=c, 3 triad b=r+c*q,
-// 4 in-place update r=r+0*q (same traffic shape as K2 without the reduction epilogue)
 __global__ __launch_bounds__(256) void k_membench(int which, double2* __restrict__ r, const double2* __restrict__ q,
                                                    double2* __restrict__ b, long long n2, double c, double* __restrict__ sink) {
     double acc = 0.0;
@@ -259,24 +192,8 @@ int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double
     if (nbl > (long long)ctx->k2_grid_mult * ctx->num_cu) nbl = (long long)ctx->k2_grid_mult * ctx->num_cu;
     const int nb = nbl < 1 ? 1 : (int)nbl;
     if (li) { li->grid = nb; li->block = 256; }
-    if (ctx->k2_variant == 4)
-        hipLaunchKernelGGL((k_k2_u4<0, 8>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
-    else if (ctx->k2_variant == 5)
-        hipLaunchKernelGGL((k_k2_u4<1, 8>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
-    else if (ctx->k2_variant == 1)
-        hipLaunchKernelGGL((k_k2_u4<0, 4>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
-    else if (ctx->k2_variant == 3)
-        hipLaunchKernelGGL(k_k2_chunk, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
-    else if (ctx->k2_variant == 2)
-        hipLaunchKernelGGL((k_k2_u4<1, 4>), dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter);
-    else
-        hipLaunchKernelGGL(k_k2, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                           reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
+    hipLaunchKernelGGL(k_k2, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                       reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

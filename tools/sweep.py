@@ -17,7 +17,7 @@ grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0))
 N = (n - 1) ** 3
 
 configs = []
-base = dict(fast_ry=2, fast_nt=-1, fast_wg_per_cu=0, k2_variant=0, grid_mult=8, k2_grid_mult=2, cg_variant=1, fast_ex=0)
+base = dict(fast_ry=2, fast_nt=-1, fast_wg_per_cu=0, grid_mult=8, k2_grid_mult=2, cg_variant=1, fast_ex=0)
 for rep in range(3):
     for ex in (0, 1):
         configs.append(dict(base, fast_ex=ex))
