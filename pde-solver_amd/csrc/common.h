@@ -23,6 +23,7 @@ struct pdegpu_ctx {
                                 // instead of 2-lane global loads (measured: 1.65 -> 1.52 ms per 512^3 CG iteration)
     int fast_minlen = 1;        // shortest z-chunk of the marching kernels on grids too small to fill the device
     int fast_small_mult = 1;    // such grids may launch this many resident rounds of workgroups
+    int fast_wg_per_cu_k2 = 0;  // the same for the stencil K2 alone (0 = follow fast_wg_per_cu)
     int fast_wg_per_cu = 0;     // 0 = occupancy API
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)

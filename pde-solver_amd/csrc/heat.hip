@@ -343,7 +343,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "fast_minlen", "fast_small_mult", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "fast_minlen", "fast_small_mult", "el_fast", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -358,6 +358,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_nt")) return &ctx->fast_nt;
     if (!strcmp(key, "fast_ex")) return &ctx->fast_ex;
     if (!strcmp(key, "fast_wg_per_cu")) return &ctx->fast_wg_per_cu;
+    if (!strcmp(key, "fast_wg_per_cu_k2")) return &ctx->fast_wg_per_cu_k2;
     if (!strcmp(key, "grid_mult")) return &ctx->grid_mult;
     if (!strcmp(key, "k2_grid_mult")) return &ctx->k2_grid_mult;
     if (!strcmp(key, "cg_variant")) return &ctx->cg_variant;

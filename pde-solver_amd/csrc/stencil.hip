@@ -545,6 +545,7 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     }
     int wg_per_cu = occ[mode];
     if (ctx->fast_wg_per_cu >= 1 && ctx->fast_wg_per_cu <= 16) wg_per_cu = ctx->fast_wg_per_cu;
+    if (mode == APPLY_CG_K2 && ctx->fast_wg_per_cu_k2 >= 1 && ctx->fast_wg_per_cu_k2 <= 16) wg_per_cu = ctx->fast_wg_per_cu_k2;
     FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu);
     const int G = fg.nxg * fg.nyg * fg.nzc;
     if (li) { li->grid = G; li->block = 256; }

@@ -17,14 +17,15 @@ grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0))
 N = (n - 1) ** 3
 
 configs = []
-base = dict(fast_ry=2, fast_nt=-1, fast_wg_per_cu=0, grid_mult=8, k2_grid_mult=2, cg_variant=1, fast_ex=0)
-for rep in range(3):
-    for ex in (0, 1):
-        configs.append(dict(base, fast_ex=ex))
+base = dict(fast_ry=2, fast_nt=-1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, cg_variant=1, fast_ex=1)
+for w1 in (0, 2, 3, 4, 6):
+    configs.append(dict(base, fast_wg_per_cu=w1))
+for w2 in (1, 2, 3, 4, 6, 8):
+    configs.append(dict(base, fast_wg_per_cu_k2=w2))
 if len(sys.argv) > 3:
     configs = [dict(base, **eval(sys.argv[3]))]
 
-for steady in (1, 0):
+for steady in (1,):
     for cfg in configs:
         for k, v in cfg.items():
             L.check(ctx, lib.pdegpu_set_tunable(ctx, k.encode(), v))
@@ -46,7 +47,7 @@ for steady in (1, 0):
         L.check(ctx, lib.pdegpu_session_time_apply(s, 30, C.byref(ms)))
         k1, k2 = st.kernel_ms[0] / iters, st.kernel_ms[1] / iters
         tot = (k1 + k2)
-        print(f"steady={steady} ex={cfg['fast_ex']}: K1+K2 {tot:.3f} ms -> {N/tot/1e6:.1f} GDoF/s | K1 {k1:.3f} ms {48*N/k1/1e6:6.0f} GB/s | K2 {k2:.3f} ms {24*N/k2/1e6:6.0f} GB/s | "
+        print(f"steady={steady} wg={cfg['fast_wg_per_cu']} wg_k2={cfg['fast_wg_per_cu_k2']}: K1+K2 {tot:.3f} ms -> {N/tot/1e6:.1f} GDoF/s | K1 {k1:.3f} ms {48*N/k1/1e6:6.0f} GB/s | K2 {k2:.3f} ms {24*N/k2/1e6:6.0f} GB/s | "
               f"SpMV {ms.value:.3f} ms {16*N/ms.value/1e6:6.0f} GB/s | rr {rr.value:.9e}", flush=True)
         if False:
             names = ["copy 1R+1W", "read 1R", "write 1W", "triad 2R+1W", "inplace 2R+1W"]
