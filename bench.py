@@ -142,6 +142,12 @@ def main():
                        "rr_after": rr},
         }
 
+        if world > 1:
+            # per-GPU view of the whole iteration (kernels + halo exchange + two all-reduces); the per-kernel roofline is the N=1 line's
+            per_gpu = 64.0 * unknowns / world / (elapsed / args.steps) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBS,
+                               "traffic": None, "kernel": "whole CG iteration per GPU: K1 + K2 (64 B/DoF algorithmic) + r-plane halo exchange + "
+                                                          "two 8-byte all-reduces; kernel-level figures are in the n_gpus=1 line"}
         if world == 1:
             # ---- roofline of the dominant kernel (K1 = the SpMV-bearing fused kernel), HIP events ----------
             k1_ms = stats.kernel_ms[0] / max(1, stats.kernel_launches[0])
