@@ -238,8 +238,28 @@ class SlabCG:
             for t, (snd, rcv) in enumerate(zip(self._halo(nk - 1), self._halo(nk))):
                 ops.append(dist.P2POp(dist.isend, snd, hi, self.group, tag=2 * t + 1))
                 ops.append(dist.P2POp(dist.irecv, rcv, hi, self.group, tag=2 * t))
+        if ops and ops[0].tensor.is_cuda and dist.get_backend(self.group) == "gloo":
+            return self._exchange_staged(ops)
         for w in dist.batch_isend_irecv(ops):
             w.wait()          # stream-ordered for NCCL (no host block); completes the copy for gloo
+
+    def _exchange_staged(self, ops):
+        """gloo cannot send device memory: stage the planes through host buffers.  Only for rehearsing the multi-rank
+        driver with the HIP engine on a box with fewer GPUs than ranks (several ranks share one GPU, which RCCL refuses);
+        the production backend is nccl."""
+        torch.cuda.current_stream().synchronize()
+        host_ops, recvs = [], []
+        for op in ops:
+            if op.op is dist.isend:
+                host_ops.append(dist.P2POp(dist.isend, op.tensor.cpu(), op.peer, self.group, tag=op.tag))
+            else:
+                buf = torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                recvs.append((op.tensor, buf))
+                host_ops.append(dist.P2POp(dist.irecv, buf, op.peer, self.group, tag=op.tag))
+        for w in dist.batch_isend_irecv(host_ops):
+            w.wait()
+        for dev, buf in recvs:
+            dev.copy_(buf)
 
     def allreduce(self, which: int):
         """local partial -> global scalar(s) (sum over ranks), in place; which: 0 after k1, 1 after k2"""
@@ -250,7 +270,13 @@ class SlabCG:
             else:
                 a = SC_PQ if which == 0 else SC_RR
                 b = a + 1
-            dist.all_reduce(self.e.scalars()[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            t = self.e.scalars()[a:b]
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":       # rehearsal transport, see _exchange_staged
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- CG ---------------------------------------------------------------------------------------
     def start(self, x_fill: float = 0.0):

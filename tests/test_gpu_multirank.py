@@ -1,0 +1,27 @@
+"""N > 1 with the real HIP engine: two and three processes (one z-slab each) share this box's single GPU and run the product's
+multi-rank driver (pdegpu.dist.SlabCG + GpuSlabEngine) under `gloo` with the planes staged through the host — RCCL refuses
+several ranks on one device, and the pool gives one GPU per box; the nccl transport itself is covered by
+test_rccl_backend_on_library_owned_memory.  Rank 0 compares solution and residual history with a single-slab session."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.parametrize("world,cells", [(2, 24), (3, 16)])
+def test_multi_process_slab_cg_matches_single_slab(lib, gpu_ctx, world, cells):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tools" / "rehearse_ranks.py"), str(cells), "80"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "REHEARSAL OK" in out.stdout

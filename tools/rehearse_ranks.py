@@ -1,0 +1,59 @@
+"""Rehearsal of the multi-rank driver with the real HIP engine on ONE GPU: N processes (gloo, planes staged through the host —
+RCCL refuses several ranks on one device) each own a z-slab on cuda:0 and run pdegpu.dist.SlabCG exactly as bench.py does at
+N > 1; rank 0 checks the gathered solution and residual history against a single-slab session of the same global grid.
+usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 tools/rehearse_ranks.py [cells] [iters]"""
+import os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "pde-solver_amd")]
+import numpy as np
+import torch, torch.distributed as dist
+from pdegpu import _lib as L
+from pdegpu.dist import GpuSlabEngine, SlabCG, slab_range
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+lib = L.load_library()
+nzg = n * world
+grid = L.make_grid(3, (n, n, nzg), (1.0, 1.0, float(world)))
+heat = L.Heat(); heat.kappa, heat.dt, heat.steady, heat.source = 1.0, 0.0, 1, 1.0
+heat.bc_mode, heat.fast_path = L.BC_UNIFORM, 1; heat.bc_present[0] = 1
+k0, nk = slab_range(nzg + 1, world, rank)
+stream = torch.cuda.Stream(device=0)
+with torch.cuda.stream(stream):
+    eng = GpuSlabEngine(grid, heat, k0, nk, 0, stream)
+    cg = SlabCG(eng, rank, world)
+    cg.start(0.0)
+    hist = [eng.rr()]
+    for _ in range(iters // 10):
+        cg.iterate(10)
+        hist.append(eng.rr())
+    cg.finish()
+    x = np.empty(nk * (n + 1) * (n + 1))
+    L.check(eng.ctx, lib.pdegpu_session_get_x(eng.s, L.dptr(x)))
+    eng.close()
+parts = [None] * world
+dist.all_gather_object(parts, x)
+if rank == 0:
+    xs = np.concatenate(parts)
+    with torch.cuda.stream(stream):
+        one = GpuSlabEngine(grid, heat, 0, nzg + 1, 0, stream)
+        c1 = SlabCG(one, 0, 1)
+        c1.start(0.0)
+        h1 = [one.rr()]
+        for _ in range(iters // 10):
+            c1.iterate(10)
+            h1.append(one.rr())
+        c1.finish()
+        x1 = np.empty((nzg + 1) * (n + 1) * (n + 1))
+        L.check(one.ctx, lib.pdegpu_session_get_x(one.s, L.dptr(x1)))
+        one.close()
+    rel = np.abs(xs - x1).max() / np.abs(x1).max()
+    hrel = max(abs(a - b) / b for a, b in zip(hist, h1))
+    print(f"rehearsal world={world} cells={n}x{n}x{nzg}: max rel diff of x vs single slab {rel:.2e}, residual history rel diff {hrel:.2e}, rr {hist[-1]:.6e}", flush=True)
+    assert rel < 1e-11 and hrel < 1e-9
+    print("REHEARSAL OK", flush=True)
+dist.destroy_process_group()
