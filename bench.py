@@ -81,10 +81,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # PDEGPU_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, planes are
+    # staged through the host by pdegpu.dist); the measured configuration is always nccl = RCCL, one rank per GPU
+    backend = os.environ.get("PDEGPU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = args.cells
     # weak scaling: every GPU owns a 512-cell-thick slab; the global grid is n x n x (n*N) cells
@@ -126,7 +134,7 @@ def main():
         rr = eng.rr()
 
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
@@ -137,7 +145,7 @@ def main():
             "config": {"workload": f"3D heat {n}x{n}x{n} cells per GPU (BASELINE configs[2]: 512^3 P1 grid, steady "
                                    f"kappa*K u = f*m, f=1, T_boundary=0), one CG iteration per step",
                        "global_cells": [n, n, nz_global], "unknowns": unknowns, "element_mode": "p1split",
-                       "parallelism": f"z-slabs x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"z-slabs x{world}" + ("" if backend == "nccl" else f" (REHEARSAL over {backend}, shared GPU: not a measurement)")) if world > 1 else "single GPU",
                        "kernel_path": "general" if args.general else "fused z-marching",
                        "rr_after": rr},
         }

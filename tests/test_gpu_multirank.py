@@ -25,3 +25,25 @@ def test_multi_process_slab_cg_matches_single_slab(lib, gpu_ctx, world, cells):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "REHEARSAL OK" in out.stdout
+
+
+def test_bench_line_of_the_multi_rank_path(lib, gpu_ctx):
+    """bench.py under the launcher the driver uses for N > 1, here 2 ranks sharing the GPU over gloo (rehearsal mode): one JSON
+    line from rank 0 with the contract's keys and the whole-job unknown count"""
+    import json
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PDEGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--cells", "48"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["unknowns"] == 47 * 47 * 95
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["unknowns"] * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
