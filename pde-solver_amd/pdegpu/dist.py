@@ -309,6 +309,8 @@ def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     local = int(L.os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    if world > 1 and dist.get_backend(group) == "gloo":       # rehearsal: ranks may share a device (see SlabCG._exchange_staged)
+        local %= torch.cuda.device_count()
     nx, ny, nz = n_cells
     k0, nk = slab_range(nz + 1, world, rank)
     stream = torch.cuda.Stream(device=local)

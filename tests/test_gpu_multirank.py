@@ -47,3 +47,16 @@ def test_bench_line_of_the_multi_rank_path(lib, gpu_ctx):
         assert k in d
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["unknowns"] == 47 * 47 * 95
     assert d["value"] > 0 and abs(d["value"] - d["config"]["unknowns"] * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+
+
+def test_multi_process_elasticity_slabs(lib, gpu_ctx):
+    """solve_elasticity_slabs with 2 ranks sharing the GPU (gloo rehearsal): von Mises field == the single-process solve"""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tools" / "rehearse_elasticity.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "REHEARSAL OK" in out.stdout
