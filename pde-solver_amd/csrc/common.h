@@ -148,7 +148,7 @@ void tables_free(HeatTables* t);
 enum ApplyMode { APPLY_PLAIN = 0, APPLY_RESIDUAL = 1, APPLY_CG_K1 = 2, APPLY_CG_K2 = 3 };
 
 // device scalar block used by the CG kernels
-enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_COUNT = 8 };
+enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_BNORM = 5 /* reference norm of a solve, host-read only */, SC_COUNT = 8 };
 
 // where a CG kernel finds the dot product of the launch before it.  part == nullptr: already reduced, rr_n in
 // scal[s_rr], rr_{n-1} in scal[s_rr_old], p.q in scal[SC_PQ] (the eager protocol of the multi-GPU driver: SC_RR /

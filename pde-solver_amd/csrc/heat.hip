@@ -801,10 +801,8 @@ int next_poll_chunk(double rr_before, double rr_after, double target, int n_done
 }
 
 namespace {
-int cg_solve(pdegpu_session* s, double bnorm2, double rtol, int max_iter, pdegpu_stats* st, int* iters_out, double* rel_out) {
+int cg_solve(pdegpu_session* s, double bnorm2, double rr, double rtol, int max_iter, pdegpu_stats* st, int* iters_out, double* rel_out) {
     pdegpu_ctx* ctx = s->ctx;
-    double rr = 0;
-    PG_TRY(pdegpu_session_rr(s, &rr));
     const double target = rtol * rtol * bnorm2;
     int it = 0;
     int chunk = 8;
@@ -845,8 +843,8 @@ int linear_solve(pdegpu_session* s, bool x_is_lift_only, pdegpu_stats* st) {
     LaunchInfo li;
     double bnorm2 = 0;
     PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
-    PG_TRY(vec_zero(ctx, s->g, &s->p[0]));
-    PG_TRY(vec_zero(ctx, s->g, &s->p[1]));
+    // p of the previous solve is left as it is: with the scalars zeroed the first K1 forms beta = 0 and skips the x-update,
+    // so the finite old entries only ever meet a factor 0; they are zero on Dirichlet nodes and pads like every CG vector
     s->pcur = 0;
     if (!x_is_lift_only) {
         // ||P (b - A g)||: g = Dirichlet values, zero elsewhere (held in q for this pass, result in r)
@@ -854,16 +852,19 @@ int linear_solve(pdegpu_session* s, bool x_is_lift_only, pdegpu_stats* st) {
         PG_TRY(set_bc_ext(s, s->q.v, 0.0, nullptr, 0));
         PG_TRY(op_residual(s, s->q.v, s->b.v, s->r.v, &li));
         PG_TRY(residual_finish(s, &li));
-        PG_TRY(pdegpu_session_rr(s, &bnorm2));
+        // the reference norm stays on the device until the first poll reads it together with r.r (one host sync, not two)
+        PG_HIP(ctx, hipMemcpyAsync(s->d_scal + SC_BNORM, s->d_scal + SC_RR, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         PG_TRY(vec_zero(ctx, s->g, &s->q));
-        PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
+        PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_BNORM * sizeof(double), ctx->stream));
     }
     PG_TRY(op_residual(s, s->x.v, s->b.v, s->r.v, &li));
     PG_TRY(residual_finish(s, &li));
-    if (x_is_lift_only) PG_TRY(pdegpu_session_rr(s, &bnorm2));
+    double rr0 = 0;
+    PG_TRY(pdegpu_session_rr(s, &rr0));
+    bnorm2 = x_is_lift_only ? rr0 : s->h_pin[SC_BNORM];
     int iters = 0;
     double rel = 0;
-    int rc = cg_solve(s, bnorm2, s->heat.rtol, s->heat.max_iter, st, &iters, &rel);
+    int rc = cg_solve(s, bnorm2, rr0, s->heat.rtol, s->heat.max_iter, st, &iters, &rel);
     if (st) {
         st->final_rel_residual = rel;
         if (rc != PDEGPU_OK) st->converged = 0;
