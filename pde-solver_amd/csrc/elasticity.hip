@@ -367,7 +367,11 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
     } else {
         // ---- interior nodes: z-marching ------------------------------------------------------------------------
         const int lane = threadIdx.x & 63;
-        const int wid = ((int)blockIdx.x - fg.nb_bnd) * 4 + (threadIdx.x >> 6);
+        // XCD-aware order: workgroups b and b+8 share an XCD (round-robin dispatch), so XCD x is given the contiguous range
+        // [x*G/8, (x+1)*G/8) of tiles: y-neighbouring columns, whose halo rows overlap, then meet in one L2 (speed only)
+        int bm = (int)blockIdx.x - fg.nb_bnd;
+        if ((fg.nb_fast & 7) == 0) bm = (bm & 7) * (fg.nb_fast >> 3) + (bm >> 3);
+        const int wid = bm * 4 + (threadIdx.x >> 6);
         const int xt = wid % fg.ntx, yt = (wid / fg.ntx) % fg.nty, zc = wid / (fg.ntx * fg.nty);
         const int i = xt * 62 + lane;                         // lanes 0 and 63: x-halo only
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
@@ -404,10 +408,19 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                         P[r][c] = v;
                     }
             };
+            // PF: one more plane in flight (plane lk+2 is requested before plane lk is computed) — plain apply only
+            constexpr bool PF = !K1 && (RY == 1 || RY == 2);
+            double Pn[PF ? RH : 1][3];
             load_plane(lk0 - 1, Pm, false);
             load_plane(lk0, P0, true);
+            if (PF) load_plane(lk0 + 1, Pp, false);          // the address is inside the allocation even when lk0 + 1 == lk1 == nkl
             for (int lk = lk0; lk < lk1; ++lk) {
-                load_plane(lk + 1, Pp, lk + 1 < lk1);
+                if (PF) {
+                    // lk + 2 can reach nkl + 1 (one plane past the upper ghost plane) only when it is not needed: clamp it
+                    load_plane(min(lk + 2, lk1), Pn, false);
+                } else {
+                    load_plane(lk + 1, Pp, lk + 1 < lk1);
+                }
                 const long long obase = (long long)lk * g.PP + col;
 #pragma unroll
                 for (int r = 1; r <= RY; ++r) {
@@ -447,6 +460,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                     for (int c = 0; c < 3; ++c) {
                         Pm[r][c] = P0[r][c];
                         P0[r][c] = Pp[r][c];
+                        if (PF) Pp[r][c] = Pn[r][c];
                     }
             }
         }
@@ -910,6 +924,7 @@ void el_fast_geometry(ElSession* s) {
     fg.zlen = std::max(1, (int)((planes + nzc - 1) / nzc));
     fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
     fg.nb_fast = (int)((cols * fg.nzc + 3) / 4);
+    fg.nb_fast = (fg.nb_fast + 7) / 8 * 8;          // multiple of 8 for the XCD-aware tile order (surplus waves find zc >= nzc and idle)
     fg.ring = 2 * g.NX + 2 * (g.NY - 2);
     fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * g.NX * g.NY + (long long)planes * fg.ring;
     fg.nb_bnd = (int)((fg.nbnd + 255) / 256);
