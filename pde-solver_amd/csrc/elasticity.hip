@@ -5,9 +5,10 @@
 // 1803-1866).  The operator is applied matrix-free as a d x d-block node stencil over the 15 neighbours the
 // Kuhn split couples; the blocks are folded on the device from the 2^d-vertex macro-element matrix per
 // boundary class (all faces except x = 0 are traction-free, so boundary nodes use truncated class stencils).
-// Solver: Jacobi-preconditioned CG in the same two-kernel form as the heat path (K1: x-update, p-update,
-// q = A p, p.q;  K2: r-update, z = D^-1 r, r.z and r.r), displacement components stored as separate
-// pitched arrays so every neighbour read is coalesced.
+// Solver: Jacobi-preconditioned CG per iteration = flat p-update (p = z + beta p, deferred x += alpha p) -> block apply
+// q = A p with the p.q partials (3-D: z-marching k_el_fast + boundary workgroups; 2-D: thread per node) -> K2 (r -= alpha q,
+// z = D^-1 r, r.z and r.r); the scalars are summed in the consuming kernel's prologue (no reduce launches in the one-GPU loop).
+// Displacement components are stored as separate pitched arrays so every neighbour read is coalesced.
 #include "common.h"
 #include "tables_math.h"
 #include <algorithm>

@@ -8,12 +8,13 @@
 // Two implementations of the same three operations (PLAIN apply, RESIDUAL, fused CG "K1"):
 //   * general: one thread per node, coupling weights looked up per boundary class from the 27x27 class
 //     table in LDS (any dimension, any Dirichlet/natural face mix, P1 or Q1);
-//   * fast: 3-D, every boundary node Dirichlet, P1 split.  One wavefront owns a 128-node x 4-row column
-//     of the grid and marches along z keeping three planes in registers, so every input plane is read
-//     once per wave; x-neighbours come from DPP wave shifts (no LDS traffic), y/z neighbours from
-//     registers; loads and stores are 16 B per lane (global_load/store_dwordx4), fully coalesced 1 KiB
-//     per wave-instruction.  Workgroups are mapped so that one XCD sweeps one z-chunk of the whole x-y
-//     plane: the y-halo rows shared by neighbouring workgroups are then served by that XCD's L2.
+//   * fast: 3-D (2-D through a flat view), P1 split (7- / 15-point) or Q1 (27-point), interior nodes.  One wavefront owns a
+//     128-node x RY-row column (RY = 2 by default) and marches along z keeping three planes in registers, so every
+//     input plane is read once per wave; x-neighbours come from DPP wave shifts (tile edges: LDS hand-off between the
+//     workgroup's waves in the CG kernels), y/z neighbours from registers; loads and stores are 16 B per lane
+//     (global_load/store_dwordx4), fully coalesced 1 KiB per wave-instruction.  Workgroups are mapped so that one XCD
+//     sweeps one z-chunk of the whole x-y plane: the y-halo rows shared by neighbouring workgroups are then served by
+//     that XCD's L2.  Grids with natural faces add a second launch of the class-table kernel over the boundary nodes.
 //
 // CG K1 (both implementations) fuses, per iteration n:  x += alpha_{n-1} p_{n-1};  p_n = r_n + beta_{n-1}
 // p_{n-1};  q_n = A p_n;  partial(p_n . q_n)  — p_n is recomputed on the fly at the stencil neighbours
