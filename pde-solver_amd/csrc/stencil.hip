@@ -518,11 +518,21 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     if (minlen > 8) minlen = 8;
     if (minlen < ctx->fast_minlen) minlen = ctx->fast_minlen;
     if (minlen < 1) minlen = 1;
-    int nzc = (target + xy - 1) / xy;
-    if (nzc < 1) nzc = 1;
     int maxc = planes / minlen;
     if (maxc < 1) maxc = 1;
-    if (nzc > maxc) nzc = maxc;
+    // number of z-chunks: minimise (resident rounds) x (planes marched per chunk, two-plane prologue included).  One round
+    // when the x-y tiling alone does not fill the device; when it nearly does (1024^3: 1024 of 1280 slots) more, shorter
+    // chunks that fill whole rounds beat one partly filled round.
+    int nzc = 1;
+    long long best = -1;
+    for (int c = 1; c <= maxc; ++c) {
+        const long long rounds = ((long long)xy * c + target - 1) / (target > 0 ? target : 1);
+        const long long cost = rounds * ((planes + c - 1) / c + 2);
+        if (best < 0 || cost < best) {
+            best = cost;
+            nzc = c;
+        }
+    }
     fg.zlen = planes > 0 ? (planes + nzc - 1) / nzc : 1;
     fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
     return fg;
