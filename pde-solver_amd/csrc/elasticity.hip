@@ -216,6 +216,7 @@ struct ElW36 {
 };
 struct ElFastGeom {
     int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
+    int nyg;                   // groups of 4 y-tiles (one workgroup each) of the y-hand-off variant
     int lkb, lke;              // local interior plane range [lkb, lke)
     int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
     int nb_bnd;                // boundary workgroups (launched first so that their short tail overlaps the marching part)
@@ -251,7 +252,7 @@ __device__ __forceinline__ void el_off3(const double* b, const double* v, double
 // K1 = true: the fused CG kernel — p_n = z_n + beta p_{n-1} is formed at every loaded position (own nodes: stored, and
 // x += alpha_{n-1} p_{n-1} applied, when the value is first formed), q = A p_n, partial p_n.q: the separate p-update pass
 // (5 vector passes over HBM / MALL) disappears.  K1 = false: q = A in, partial in.q.
-template <int RY, bool K1>
+template <int RY, bool K1, bool YX>
 __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom fg) {
     __shared__ double sTab[27 * PG_NOFF15 * 9];
     __shared__ unsigned sMask[27];
@@ -294,8 +295,8 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
         for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
         if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
         __syncthreads();
-        long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-        if (e < fg.nbnd) {
+        for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * 256) {
+            long long e = e0;
             int i, j, lk;
             const long long plane_nodes = (long long)g.NX * g.NY;
             if (fg.full_lo && e < plane_nodes) {
@@ -372,8 +373,22 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
         // [x*G/8, (x+1)*G/8) of tiles: y-neighbouring columns, whose halo rows overlap, then meet in one L2 (speed only)
         int bm = (int)blockIdx.x - fg.nb_bnd;
         if ((fg.nb_fast & 7) == 0) bm = (bm & 7) * (fg.nb_fast >> 3) + (bm >> 3);
-        const int wid = bm * 4 + (threadIdx.x >> 6);
-        const int xt = wid % fg.ntx, yt = (wid / fg.ntx) % fg.nty, zc = wid / (fg.ntx * fg.nty);
+        const int wv = threadIdx.x >> 6;
+        int xt, yt, zc;
+        if (YX) {
+            // the four waves of a workgroup are y-neighbours (same x-tile, same z-chunk): they hand their y-halo rows to
+            // each other through LDS, so a workgroup loads 4 RY + 2 rows per plane instead of 4 (RY + 2)
+            xt = bm % fg.ntx;
+            yt = ((bm / fg.ntx) % fg.nyg) * 4 + wv;
+            zc = bm / (fg.ntx * fg.nyg);
+        } else {
+            const int wid = bm * 4 + wv;
+            xt = wid % fg.ntx;
+            yt = (wid / fg.ntx) % fg.nty;
+            zc = wid / (fg.ntx * fg.nty);
+        }
+        const bool ghost_wave = YX && yt >= fg.nty;           // beyond the last row tile: takes part in the barriers only
+        if (ghost_wave) yt = fg.nty - 1;                      // (loads stay inside the grid; nothing is stored)
         const int i = xt * 62 + lane;                         // lanes 0 and 63: x-halo only
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
         const int lk0 = fg.lkb + zc * fg.zlen;
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
             const bool out_x = lane >= 1 && lane <= 62 && i <= g.NX - 2;
             bool row_out[RH];
 #pragma unroll
-            for (int r = 0; r < RH; ++r) row_out[r] = out_x && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
+            for (int r = 0; r < RH; ++r) row_out[r] = out_x && !ghost_wave && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
             const long long col = (long long)(j0 - 1) * g.PX + i;
             double Pm[RH][3], P0[RH][3], Pp[RH][3];
             // own == true: the plane belongs to this wave's chunk, so its own rows get p_n stored and x updated here
@@ -411,14 +426,56 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
             };
             // PF: one more plane in flight (plane lk+2 is requested before plane lk is computed) — plain apply only
             constexpr bool PF = !K1 && (RY == 1 || RY == 2);
+            static_assert(!YX || PF, "the y hand-off is written for the prefetching plain apply");
             double Pn[PF ? RH : 1][3];
+            // YX: a marching plane is loaded without the halo rows its y-neighbours in the workgroup own (the lowest wave
+            // still loads row j0-1, the highest real wave row j0+RY); they arrive through LDS one step later, when the
+            // plane has become Pp and its loads have landed.  The LDS block is the class table's (boundary workgroups only).
+            const bool lo_global = !YX || wv == 0;
+            const bool hi_global = !YX || wv == 3 || (yt + 1 >= fg.nty);
+            auto load_own = [&](int lk, double (*P)[3]) {
+                const long long base = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const bool need = (r >= 1 && r <= RY) || (r == 0 ? lo_global : hi_global);      // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[r][c] = need ? a.in[c * a.stride + base + (long long)r * g.PX] : 0.0;
+                }
+            };
+            double* sY = sTab;                                // [2][4 waves][first | last own row][3][64]
+            int ybuf = 0;
+            auto y_exchange = [&](double (*P)[3]) {
+                double* mine = sY + ((ybuf * 4 + wv) * 2) * 192;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    mine[c * 64 + lane] = P[1][c];
+                    mine[192 + c * 64 + lane] = P[RY][c];
+                }
+                __syncthreads();
+                if (!lo_global) {
+                    const double* below = sY + ((ybuf * 4 + wv - 1) * 2 + 1) * 192;          // last own row of the wave below
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[0][c] = below[c * 64 + lane];
+                }
+                if (!hi_global) {
+                    const double* above = sY + ((ybuf * 4 + wv + 1) * 2) * 192;              // first own row of the wave above
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[RH - 1][c] = above[c * 64 + lane];
+                }
+                ybuf ^= 1;
+            };
             load_plane(lk0 - 1, Pm, false);
             load_plane(lk0, P0, true);
             if (PF) load_plane(lk0 + 1, Pp, false);          // the address is inside the allocation even when lk0 + 1 == lk1 == nkl
             for (int lk = lk0; lk < lk1; ++lk) {
                 if (PF) {
                     // lk + 2 can reach nkl + 1 (one plane past the upper ghost plane) only when it is not needed: clamp it
-                    load_plane(min(lk + 2, lk1), Pn, false);
+                    if (YX) {
+                        load_own(min(lk + 2, lk1), Pn);
+                        if (lk > lk0) y_exchange(Pp);         // Pp was requested one step ago; every wave of the workgroup passes here
+                    } else {
+                        load_plane(min(lk + 2, lk1), Pn, false);
+                    }
                 } else {
                     load_plane(lk + 1, Pp, lk + 1 < lk1);
                 }
@@ -919,7 +976,9 @@ void el_fast_geometry(ElSession* s) {
     const int planes = std::max(0, fg.lke - fg.lkb);
     fg.ntx = (g.NX - 2 + 61) / 62;
     fg.nty = (g.NY - 2 + RY - 1) / RY;
-    const long long cols = (long long)fg.ntx * fg.nty;
+    fg.nyg = (fg.nty + 3) / 4;
+    const bool yx = s->ctx->el_fast_yx != 0;
+    const long long cols = yx ? (long long)fg.ntx * fg.nyg * 4 : (long long)fg.ntx * fg.nty;      // wavefront columns launched
     long long nzc = (s->ctx->el_fast_waves + cols - 1) / cols;
     nzc = std::max(1LL, std::min<long long>(nzc, std::max(1, planes)));
     fg.zlen = std::max(1, (int)((planes + nzc - 1) / nzc));
@@ -928,7 +987,7 @@ void el_fast_geometry(ElSession* s) {
     fg.nb_fast = (fg.nb_fast + 7) / 8 * 8;          // multiple of 8 for the XCD-aware tile order (surplus waves find zc >= nzc and idle)
     fg.ring = 2 * g.NX + 2 * (g.NY - 2);
     fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * g.NX * g.NY + (long long)planes * fg.ring;
-    fg.nb_bnd = (int)((fg.nbnd + 255) / 256);
+    fg.nb_bnd = (int)std::min<long long>((fg.nbnd + 255) / 256, 2LL * s->ctx->num_cu);      // grid-stride: the 29 KB table is loaded per workgroup
     fg.mask = s->d_mask;
 }
 
@@ -936,8 +995,14 @@ int el_apply(ElSession* s, const ElArgs& a, int mode) {
     if (mode == APPLY_PLAIN && s->fast && s->ctx->el_fast) {
         const ElFastGeom& fg = s->fgeom;
         const int nb = fg.nb_fast + fg.nb_bnd;
-        if (s->fast_ry == 2) hipLaunchKernelGGL((k_el_fast<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-        else hipLaunchKernelGGL((k_el_fast<1, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        const bool yx = s->ctx->el_fast_yx != 0;
+        if (s->fast_ry == 2) {
+            if (yx) hipLaunchKernelGGL((k_el_fast<2, false, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+            else hipLaunchKernelGGL((k_el_fast<2, false, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        } else {
+            if (yx) hipLaunchKernelGGL((k_el_fast<1, false, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+            else hipLaunchKernelGGL((k_el_fast<1, false, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        }
         PG_HIP(s->ctx, hipGetLastError());
         s->last_apply_blocks = nb;
         return PDEGPU_OK;
@@ -1007,8 +1072,8 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
         const int nb = fg.nb_fast + fg.nb_bnd;
         a.out = s->q;
         a.partials = s->part3;
-        if (s->fast_ry == 2) hipLaunchKernelGGL((k_el_fast<2, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-        else hipLaunchKernelGGL((k_el_fast<1, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        if (s->fast_ry == 2) hipLaunchKernelGGL((k_el_fast<2, true, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        else hipLaunchKernelGGL((k_el_fast<1, true, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
         PG_HIP(s->ctx, hipGetLastError());
         s->last_apply_blocks = nb;
         s->pcur ^= 1;

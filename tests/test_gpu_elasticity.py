@@ -35,7 +35,8 @@ def test_block_operator_matches_assembled_matrix(lib, gpu_ctx, dim, n, Ls, plane
 
 
 @pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((63, 4, 5), (2.0, 0.3, 0.2)), ((64, 3, 3), (2.0, 0.3, 0.2)),
-                                  ((65, 2, 9), (1.0, 0.2, 0.5)), ((130, 5, 3), (1.0, 0.2, 0.1)), ((2, 2, 2), (1.0, 1.0, 1.0))])
+                                  ((65, 2, 9), (1.0, 0.2, 0.5)), ((130, 5, 3), (1.0, 0.2, 0.1)), ((2, 2, 2), (1.0, 1.0, 1.0)),
+                                  ((20, 11, 8), (1.0, 0.5, 0.4)), ((9, 23, 6), (0.5, 1.0, 0.3)), ((66, 8, 12), (1.0, 0.2, 0.3))])
 def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
     """k_el_fast (z-marching interior + boundary workgroups): rows per column 1 | 2, z-chunk lengths from one plane to the
     whole column, x-tiles ending at 62 / 63 / 64 / 65 nodes, against the assembled matrix and the thread-per-node kernel"""
@@ -51,18 +52,21 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
     g = _lib.make_grid(3, n, Ls)
     outs = {}
     try:
-        for fast, ry, waves in ((0, 1, 2048), (1, 1, 2048), (1, 2, 2048), (1, 1, 1), (1, 2, 100000)):
-            for k, v in (("el_fast", fast), ("el_fast_ry", ry), ("el_fast_waves", waves)):
+        for fast, ry, waves, yx in ((0, 1, 2048, 1), (1, 1, 2048, 1), (1, 2, 2048, 1), (1, 1, 1, 1), (1, 2, 100000, 1), (1, 1, 2048, 0),
+                                    (1, 2, 2048, 0), (1, 2, 1, 0)):
+            for k, v in (("el_fast", fast), ("el_fast_ry", ry), ("el_fast_waves", waves), ("el_fast_yx", yx)):
                 _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
             y = np.full_like(u, np.nan)
             _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 0))
-            assert rel_err(y, ref) < 1e-12, (fast, ry, waves)
-            outs[(fast, ry, waves)] = y
+            assert rel_err(y, ref) < 1e-12, (fast, ry, waves, yx)
+            outs[(fast, ry, waves, yx)] = y
     finally:
-        for k, v in (("el_fast", 1), ("el_fast_ry", 2), ("el_fast_waves", 4096)):
+        for k, v in (("el_fast", 1), ("el_fast_ry", 2), ("el_fast_waves", 4096), ("el_fast_yx", 1)):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
     # z-chunking does not change a single bit (same per-node arithmetic)
-    assert np.array_equal(outs[(1, 1, 2048)], outs[(1, 1, 1)])
+    assert np.array_equal(outs[(1, 1, 2048, 1)], outs[(1, 1, 1, 1)])
+    # neither does handing the y-halo rows through LDS instead of loading them
+    assert np.array_equal(outs[(1, 1, 2048, 1)], outs[(1, 1, 2048, 0)]) and np.array_equal(outs[(1, 2, 2048, 1)], outs[(1, 2, 2048, 0)])
 
 
 @pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((37, 3, 2), (2.0, 0.3, 0.2)), ((16, 1, 1), (1.0, 0.1, 0.1))])
