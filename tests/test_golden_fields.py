@@ -46,3 +46,25 @@ def test_hip_path_reproduces_committed_fields(lib, gpu_ctx, name):
     got = raw(**kw, rtol=1e-12)
     tol = 1e-8 if "elasticity" in name else 1e-9
     assert _rel(_cut(name, got.values), FIELDS[name]) < tol
+
+
+FULL = np.load(G / "fullsize_samples.npz", allow_pickle=False)
+
+
+@pytest.mark.gpu
+def test_config2_at_full_size_matches_the_oracle_samples(lib, gpu_ctx):
+    """BASELINE config 2 at its real size (1024 x 1024 cells, the first 60 of the 200 steps): the HIP path against samples of the
+    oracle's field (every 16th node, steps 1 / 20 / 60) computed once in the build container by
+    tests/golden/make_fullsize_goldens.py — a sparse LU of 1.05 M unknowns is too slow to repeat at test time"""
+    from pdegpu import heat
+    got = heat._solve_heat_2d_raw(1.0, 1.0, 1024, 1024, 1.0, 0.0, 20.0, 0.0025, 60, rtol=1e-12)
+    v = got.values[[1, 20, 60]].reshape(3, 1025, 1025)[:, ::16, ::16]
+    assert _rel(v, FULL["config2_1024_steps_1_20_60_every16"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_heat3d_40_cubed_matches_the_oracle_samples(lib, gpu_ctx):
+    from pdegpu import heat
+    got = heat._solve_heat_3d_raw(1.0, 1.0, 1.0, 40, 40, 40, 1.0, 0.0, 20.0, 0.0025, 6, rtol=1e-12)
+    v = got.values[[1, 6]].reshape(2, 41, 41, 41)[:, ::4, ::4, ::4]
+    assert _rel(v, FULL["heat3d_40_steps_1_6_every4"]) < 1e-9
