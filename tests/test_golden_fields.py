@@ -68,3 +68,13 @@ def test_heat3d_40_cubed_matches_the_oracle_samples(lib, gpu_ctx):
     got = heat._solve_heat_3d_raw(1.0, 1.0, 1.0, 40, 40, 40, 1.0, 0.0, 20.0, 0.0025, 6, rtol=1e-12)
     v = got.values[[1, 6]].reshape(2, 41, 41, 41)[:, ::4, ::4, ::4]
     assert _rel(v, FULL["heat3d_40_steps_1_6_every4"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_elasticity_quarter_scale_config5_matches_the_oracle_samples(lib, gpu_ctx):
+    """config 5's problem (E = 210 GPa, nu = 0.3, gravity on a 1 x 0.25 x 0.25 cantilever) at 64 x 16 x 16 cells — the largest the
+    oracle's sparse LU factors in half a minute — von Mises field sampled at every (4, 2, 2)-th node"""
+    from pdegpu import elasticity
+    got = elasticity._solve_elasticity_3d_static(1.0, 0.25, 0.25, 64, 16, 16, 210e9, 0.3, 0.0, 0.0, -76518.0, "stress", rtol=1e-12)
+    v = got.values[0].reshape(17, 17, 65)[::2, ::2, ::4]
+    assert _rel(v, FULL["elasticity3d_64x16x16_gravity_vm_every_4_2_2"]) < 1e-8
