@@ -296,23 +296,23 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
         if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
         __syncthreads();
         for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * 256) {
-            long long e = e0;
+            unsigned e = (unsigned)e0;                        // 32-bit divisions (nbnd < 2^31 is checked on the host)
             int i, j, lk;
-            const long long plane_nodes = (long long)g.NX * g.NY;
+            const unsigned plane_nodes = (unsigned)g.NX * (unsigned)g.NY;
             if (fg.full_lo && e < plane_nodes) {
                 lk = -g.k0;                                   // global plane 0
-                j = (int)(e / g.NX);
-                i = (int)(e % g.NX);
+                j = (int)(e / (unsigned)g.NX);
+                i = (int)(e % (unsigned)g.NX);
             } else {
-                e -= fg.full_lo ? plane_nodes : 0;
+                e -= fg.full_lo ? plane_nodes : 0u;
                 if (fg.full_hi && e < plane_nodes) {
                     lk = g.NZ - 1 - g.k0;
-                    j = (int)(e / g.NX);
-                    i = (int)(e % g.NX);
+                    j = (int)(e / (unsigned)g.NX);
+                    i = (int)(e % (unsigned)g.NX);
                 } else {
-                    e -= fg.full_hi ? plane_nodes : 0;
-                    lk = fg.lkb + (int)(e / fg.ring);
-                    const int t = (int)(e % fg.ring);
+                    e -= fg.full_hi ? plane_nodes : 0u;
+                    lk = fg.lkb + (int)(e / (unsigned)fg.ring);
+                    const int t = (int)(e % (unsigned)fg.ring);
                     if (t < g.NX) { j = 0; i = t; }
                     else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
                     else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
@@ -1141,6 +1141,7 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     s->fast = grid->dim == 3 && s->g.NX >= 3 && s->g.NY >= 3 && s->g.NZ >= 3 && el_fast_weights(s->interior.w, &s->w36);
     if (s->fast) {
         el_fast_geometry(s);
+        if (s->fgeom.nbnd > 0x7fffffffLL) s->fast = false;
         npart = std::max(npart, (size_t)s->fgeom.nb_fast + (size_t)((s->fgeom.nbnd + 255) / 256));
     }
     PG_HIP(ctx, hipMalloc(&s->part, npart * sizeof(double)));

@@ -156,6 +156,7 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     a.bnd_xcover = std::min(g.PX, ((g.NX - 1 + 127) / 128) * 128);
     a.bnd_n = (long long)(a.bnd_full_lo + a.bnd_full_hi) * g.NX * g.NY + (long long)planes * a.bnd_ring;
     if (a.bnd_n <= 0) return PDEGPU_OK;
+    if (a.bnd_n > 0x7fffffffLL) return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "hybrid path: more than 2^31 boundary nodes");
     const int n1 = li_fast ? li_fast->grid : 0;
     a.partials = s->d_part + n1;
     a.dot_which = -1;

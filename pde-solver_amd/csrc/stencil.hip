@@ -69,22 +69,24 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
         int i, j, lk;
         if (bnd) {
             // boundary node e0 of the slab: the full planes z = 0 / NZ-1 first, then the ring of every other plane
-            long long e = e0;
-            const long long plane_nodes = (long long)g.NX * g.NY;
+            // 32-bit arithmetic (64-bit integer division costs ~150 instructions on this ISA; the host only uses this mode
+            // while bnd_n < 2^31)
+            unsigned e = (unsigned)e0;
+            const unsigned plane_nodes = (unsigned)g.NX * (unsigned)g.NY;
             if (a.bnd_full_lo && e < plane_nodes) {
                 lk = -g.k0;
-                j = (int)(e / g.NX);
-                i = (int)(e % g.NX);
+                j = (int)(e / (unsigned)g.NX);
+                i = (int)(e % (unsigned)g.NX);
             } else {
-                e -= a.bnd_full_lo ? plane_nodes : 0;
+                e -= a.bnd_full_lo ? plane_nodes : 0u;
                 if (a.bnd_full_hi && e < plane_nodes) {
                     lk = g.NZ - 1 - g.k0;
-                    j = (int)(e / g.NX);
-                    i = (int)(e % g.NX);
+                    j = (int)(e / (unsigned)g.NX);
+                    i = (int)(e % (unsigned)g.NX);
                 } else {
-                    e -= a.bnd_full_hi ? plane_nodes : 0;
-                    lk = a.bnd_lkb + (int)(e / a.bnd_ring);
-                    const int t = (int)(e % a.bnd_ring);
+                    e -= a.bnd_full_hi ? plane_nodes : 0u;
+                    lk = a.bnd_lkb + (int)(e / (unsigned)a.bnd_ring);
+                    const int t = (int)(e % (unsigned)a.bnd_ring);
                     if (t < g.NX) { j = 0; i = t; }
                     else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
                     else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
