@@ -744,6 +744,7 @@ extern "C" int pdegpu_session_membench(pdegpu_session* s, int which, int reps, d
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_ms_out = ms / reps;
+    PG_TRY(vec_zero(ctx, s->g, &s->b));        // b was the scratch target: restore "pads and unconstrained garbage are zero"
     return PDEGPU_OK;
 }
 
