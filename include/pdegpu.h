@@ -127,8 +127,11 @@ const char* pdegpu_version(void);
  * kernel's prologue sums the previous launch's partials, no reduce launches inside a single-slab CG chunk; same bits),
  * "direct_1d" (1 = 1-D grids use the Thomas recurrence inside one launch, 0 = CG), "el_fast" (1 = 3-D elasticity
  * z-marching block stencil), "el_fast_ry" (1|2 rows per column), "el_fast_waves" (wavefront target of the marching part),
- * "el_fused_k1" (1 = p-update inside the marching kernel; measured slower).  Results do not depend on them beyond the
- * solver tolerance. */
+ * "el_fast_yx" (1 = y-halo rows handed between the workgroup's waves through LDS), "el_fused_k1" (1 = p-update inside the
+ * marching kernel; measured slower), "hybrid_bc" (1 = 3-D grids with natural faces: marching kernel on the interior + class-table
+ * kernel on the boundary nodes), "extrapolate" (1 = transient solves start CG from 2 u^n - u^{n-1}), "fast_minlen" /
+ * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2".
+ * Results do not depend on them beyond the solver tolerance. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 
 /* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw
