@@ -550,33 +550,41 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
         alpha = pq > 0.0 ? rz / pq : 0.0;
     }
     double acc_rz = 0.0, acc_rr = 0.0;
-    // (i, j, lk) advance incrementally by the grid stride: one division per thread instead of two per element
+    // 16 B per lane: element pairs (i, i+1) of a row (PX is even, so a pair never straddles rows); (i, j, lk) of the pair advance
+    // incrementally by the grid stride — one division per thread instead of two per element
+    const long long total2 = total / 2;
+    const int PX2 = g.PX / 2;
     const long long step = (long long)gridDim.x * 256;
-    const int di = (int)(step % g.PX);
-    const long long drow = step / g.PX;
+    const int di = (int)(step % PX2);
+    const long long drow = step / PX2;
     const int dj = (int)(drow % g.NY), dk = (int)(drow / g.NY);
-    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    int i = (int)(idx % g.PX), j = (int)((idx / g.PX) % g.NY), lk = (int)((idx / g.PX) / g.NY);
-    for (; idx < total; idx += step) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    int i2 = (int)(e % PX2), j = (int)((e / PX2) % g.NY), lk = (int)((e / PX2) / g.NY);
+    for (; e < total2; e += step) {
+        const long long idx = 2 * e;
         const int kg = g.k0 + lk;
-        const int cls = pg_axis_class(i < g.NX ? i : 1, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
-                        9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
-        i += di;
+        const int i = 2 * i2;
+        const int cyz = 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) + 9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
+        const int cls0 = pg_axis_class(i < g.NX ? i : 1, g.NX) + cyz;
+        const int cls1 = pg_axis_class(i + 1 < g.NX ? i + 1 : 1, g.NX) + cyz;
+        i2 += di;
         j += dj;
         lk += dk;
-        if (i >= g.PX) { i -= g.PX; ++j; }
+        if (i2 >= PX2) { i2 -= PX2; ++j; }
         if (j >= g.NY) { j -= g.NY; ++lk; }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            double rv = r[c * a.stride + idx];
+            double2 rv = *reinterpret_cast<double2*>(r + c * a.stride + idx);
             if (use_alpha) {
-                rv -= alpha * q[c * a.stride + idx];
-                r[c * a.stride + idx] = rv;
+                const double2 qv = *reinterpret_cast<const double2*>(q + c * a.stride + idx);
+                rv.x -= alpha * qv.x;
+                rv.y -= alpha * qv.y;
+                *reinterpret_cast<double2*>(r + c * a.stride + idx) = rv;
             }
-            const double zv = sDinv[cls * 3 + c] * rv;
-            z[c * a.stride + idx] = zv;
-            acc_rz += rv * zv;
-            acc_rr += rv * rv;
+            const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv.x, sDinv[cls1 * 3 + c] * rv.y);
+            *reinterpret_cast<double2*>(z + c * a.stride + idx) = zv;
+            acc_rz += rv.x * zv.x + rv.y * zv.y;
+            acc_rr += rv.x * rv.x + rv.y * rv.y;
         }
     }
     const double t1 = block_sum_256(acc_rz, sRed);
@@ -620,13 +628,21 @@ __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, l
     const double pq = a.scal[ESC_PQ], rz_prev = a.scal[a.s_rz_old];
     const double alpha_prev = (pq > 0.0 && rz_prev > 0.0) ? rz_prev / pq : 0.0;
     const double beta = (rz_prev > 0.0) ? rz / rz_prev : 0.0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long idx = first + e;
+    // 16 B per lane: first, total and the component stride are multiples of 16 doubles (PX is), the origins 128-B aligned
+    const long long total2 = total / 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total2; e += (long long)gridDim.x * 256) {
+        const long long idx = first + 2 * e;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const double po = a.p_old[c * a.stride + idx];
-            a.p_new[c * a.stride + idx] = a.in[c * a.stride + idx] + beta * po;
-            if (alpha_prev != 0.0) a.x[c * a.stride + idx] += alpha_prev * po;
+            const double2 po = *reinterpret_cast<const double2*>(a.p_old + c * a.stride + idx);
+            const double2 zv = *reinterpret_cast<const double2*>(a.in + c * a.stride + idx);
+            *reinterpret_cast<double2*>(a.p_new + c * a.stride + idx) = make_double2(zv.x + beta * po.x, zv.y + beta * po.y);
+            if (alpha_prev != 0.0) {
+                double2 xv = *reinterpret_cast<double2*>(a.x + c * a.stride + idx);
+                xv.x += alpha_prev * po.x;
+                xv.y += alpha_prev * po.y;
+                *reinterpret_cast<double2*>(a.x + c * a.stride + idx) = xv;
+            }
         }
     }
 }
