@@ -127,8 +127,7 @@ const char* pdegpu_version(void);
  * kernel's prologue sums the previous launch's partials, no reduce launches inside a single-slab CG chunk; same bits),
  * "direct_1d" (1 = 1-D grids use the Thomas recurrence inside one launch, 0 = CG), "el_fast" (1 = 3-D elasticity
  * z-marching block stencil), "el_fast_ry" (1|2 rows per column), "el_fast_waves" (wavefront target of the marching part),
- * "el_fast_yx" (1 = y-halo rows handed between the workgroup's waves through LDS), "el_fused_k1" (1 = p-update inside the
- * marching kernel; measured slower), "hybrid_bc" (1 = 3-D grids with natural faces: marching kernel on the interior + class-table
+ * "el_fast_yx" (1 = y-halo rows handed between the workgroup's waves through LDS), "hybrid_bc" (1 = 3-D grids with natural faces: marching kernel on the interior + class-table
  * kernel on the boundary nodes), "extrapolate" (1 = transient solves start CG from 2 u^n - u^{n-1}), "fast_minlen" /
  * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2".
  * Results do not depend on them beyond the solver tolerance. */
@@ -199,16 +198,16 @@ int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const
 int pdegpu_elasticity_tables_host(const pdegpu_grid* grid, double lam, double mu, double* tab);
 
 /* ---- slab-resident elasticity PCG session (3-D): same protocol as the heat session below.  Vectors: 0 x, 1 r,
- *      2 p (current), 3 q, 4 z = D^-1 r; each has 3 component arrays.  Before every k1 the host exchanges the first /
- *      last owned plane of z and p (3 components each) with the slab neighbours; after k1 it all-reduces scalars[0]
+ *      2 p (current), 3 q; each has 3 component arrays (z = D^-1 r is never stored: the p-update forms it).  Before every k1 the
+ *      host exchanges the first / last owned plane of r and p (3 components each) with the slab neighbours; after k1 it all-reduces scalars[0]
  *      (p.q), after k2 scalars[1..2] (r.z, r.r) — in place, 8 / 16 bytes.  begin() needs no exchange (x = 0). */
 typedef struct pdegpu_el_session pdegpu_el_session;
 int     pdegpu_el_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, int64_t k0, int64_t nk,
                                  pdegpu_el_session** out);
 void    pdegpu_el_session_destroy(pdegpu_el_session* s);
 int     pdegpu_el_session_begin(pdegpu_el_session* s);      /* b = body m; x = 0; r = P b; z; local r.z, r.r */
-int     pdegpu_el_session_k1(pdegpu_el_session* s);         /* x += a p; p = z + beta p; q = A p; local p.q */
-int     pdegpu_el_session_k2(pdegpu_el_session* s);         /* r -= a q; z = D^-1 r; local r.z, r.r */
+int     pdegpu_el_session_k1(pdegpu_el_session* s);         /* x += a p; p = D^-1 r + beta p; q = A p; local p.q */
+int     pdegpu_el_session_k2(pdegpu_el_session* s);         /* r -= a q; local r.z (z = D^-1 r), r.r */
 int     pdegpu_el_session_flush(pdegpu_el_session* s);      /* pending x += a p */
 double* pdegpu_el_session_scalars(pdegpu_el_session* s);    /* device {p.q, r.z, r.r, r.z_prev, ...} */
 int     pdegpu_el_session_scalars_host(pdegpu_el_session* s, double* out4);   /* synchronises */

@@ -34,7 +34,6 @@ struct pdegpu_ctx {
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
     int el_fast = 1;            // 3-D elasticity: 1 = z-marching block stencil (k_el_fast); 0 = thread-per-node class-table kernel
     int el_fast_yx = 1;         // k_el_fast: 1 = the 4 waves of a workgroup are y-neighbours and hand their y-halo rows through LDS
-    int el_fused_k1 = 0;        // with el_fast: 1 = p-update fused into the marching kernel; 0 = flat p-update launch + plain apply
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
     int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary

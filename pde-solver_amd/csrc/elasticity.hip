@@ -249,10 +249,7 @@ __device__ __forceinline__ void el_off3(const double* b, const double* v, double
     y[2] += b[1] * v[0] + b[2] * v[1];
 }
 
-// K1 = true: the fused CG kernel — p_n = z_n + beta p_{n-1} is formed at every loaded position (own nodes: stored, and
-// x += alpha_{n-1} p_{n-1} applied, when the value is first formed), q = A p_n, partial p_n.q: the separate p-update pass
-// (5 vector passes over HBM / MALL) disappears.  K1 = false: q = A in, partial in.q.
-template <int RY, bool K1, bool YX>
+template <int RY, bool YX>
 __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom fg) {
     __shared__ double sTab[27 * PG_NOFF15 * 9];
     __shared__ unsigned sMask[27];
@@ -260,36 +257,6 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
     constexpr int RH = RY + 2;
     const GridDev& g = a.g;
     double acc = 0.0;
-    double alpha_prev = 0.0, beta = 0.0;
-    if (K1) {
-        double rz;
-        if (a.din) {               // lazy: r.z / r.r partials of the previous K2, summed here (all loads before the barrier)
-            double a1 = 0.0, a2 = 0.0;
-            for (int e = threadIdx.x; e < a.din_n; e += 256) {
-                a1 += a.din[e];
-                a2 += a.din2[e];
-            }
-            a1 = wave_sum(a1);
-            a2 = wave_sum(a2);
-            if ((threadIdx.x & 63) == 0) {
-                sRed[threadIdx.x >> 6] = a1;
-                sRed[4 + (threadIdx.x >> 6)] = a2;
-            }
-            __syncthreads();
-            rz = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
-            const double rr = (sRed[4] + sRed[5]) + (sRed[6] + sRed[7]);
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                double* sc = const_cast<double*>(a.scal);
-                sc[a.s_rz] = rz;
-                sc[ESC_RR] = rr;
-            }
-        } else {
-            rz = a.scal[a.s_rz];
-        }
-        const double pq = a.scal[ESC_PQ], rz_prev = a.scal[a.s_rz_old];
-        alpha_prev = (pq > 0.0 && rz_prev > 0.0) ? rz_prev / pq : 0.0;
-        beta = (rz_prev > 0.0) ? rz / rz_prev : 0.0;
-    }
     if ((int)blockIdx.x < fg.nb_bnd) {
         // ---- boundary nodes: one thread per node, truncated class stencils from LDS -----------------------------
         for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
@@ -324,16 +291,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
             const bool dir = a.mask_dirichlet && pg_dirichlet(g, i, j, kg, &dval);
             double pc[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (K1) {
-                    const double po = a.p_old[c * a.stride + idx];
-                    pc[c] = a.in[c * a.stride + idx] + beta * po;
-                    a.p_new[c * a.stride + idx] = pc[c];
-                    if (alpha_prev != 0.0) a.x[c * a.stride + idx] += alpha_prev * po;
-                } else {
-                    pc[c] = a.in[c * a.stride + idx];
-                }
-            }
+            for (int c = 0; c < 3; ++c) pc[c] = a.in[c * a.stride + idx];
             // All 15 neighbours are loaded unconditionally (45 loads in flight instead of 15 dependent round trips): an
             // offset that leaves the grid still lands inside the allocation (ghost planes / guards / row pads, all zero
             // or finite neighbour data) and meets a class weight that is exactly 0.
@@ -345,10 +303,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                 const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
                 const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    nv[q][c] = a.in[c * a.stride + nb];
-                    if (K1) nv[q][c] += beta * a.p_old[c * a.stride + nb];
-                }
+                for (int c = 0; c < 3; ++c) nv[q][c] = a.in[c * a.stride + nb];
             }
             if (!dir) {
                 const int cls = pg_axis_class(i, g.NX) + 3 * pg_axis_class(j, g.NY) + 9 * pg_axis_class(kg, g.NZ);
@@ -404,30 +359,15 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
             for (int r = 0; r < RH; ++r) row_out[r] = out_x && !ghost_wave && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
             const long long col = (long long)(j0 - 1) * g.PX + i;
             double Pm[RH][3], P0[RH][3], Pp[RH][3];
-            // own == true: the plane belongs to this wave's chunk, so its own rows get p_n stored and x updated here
-            auto load_plane = [&](int lk, double (*P)[3], bool own) {
+            auto load_plane = [&](int lk, double (*P)[3]) {
                 const long long base = (long long)lk * g.PP + col;
 #pragma unroll
                 for (int r = 0; r < RH; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const long long at = c * a.stride + base + (long long)r * g.PX;
-                        double v = a.in[at];
-                        if (K1) {
-                            const double po = a.p_old[at];
-                            v += beta * po;
-                            if (own && row_out[r]) {
-                                a.p_new[at] = v;
-                                if (alpha_prev != 0.0) a.x[at] += alpha_prev * po;
-                            }
-                        }
-                        P[r][c] = v;
-                    }
+                    for (int c = 0; c < 3; ++c) P[r][c] = a.in[c * a.stride + base + (long long)r * g.PX];
             };
-            // PF: one more plane in flight (plane lk+2 is requested before plane lk is computed) — plain apply only
-            constexpr bool PF = !K1 && (RY == 1 || RY == 2);
-            static_assert(!YX || PF, "the y hand-off is written for the prefetching plain apply");
-            double Pn[PF ? RH : 1][3];
+            // one more plane in flight: plane lk+2 is requested before plane lk is computed
+            double Pn[RH][3];
             // YX: a marching plane is loaded without the halo rows its y-neighbours in the workgroup own (the lowest wave
             // still loads row j0-1, the highest real wave row j0+RY); they arrive through LDS one step later, when the
             // plane has become Pp and its loads have landed.  The LDS block is the class table's (boundary workgroups only).
@@ -464,20 +404,16 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                 }
                 ybuf ^= 1;
             };
-            load_plane(lk0 - 1, Pm, false);
-            load_plane(lk0, P0, true);
-            if (PF) load_plane(lk0 + 1, Pp, false);          // the address is inside the allocation even when lk0 + 1 == lk1 == nkl
+            load_plane(lk0 - 1, Pm);
+            load_plane(lk0, P0);
+            load_plane(lk0 + 1, Pp);                          // the address is inside the allocation even when lk0 + 1 == lk1 == nkl
             for (int lk = lk0; lk < lk1; ++lk) {
-                if (PF) {
-                    // lk + 2 can reach nkl + 1 (one plane past the upper ghost plane) only when it is not needed: clamp it
-                    if (YX) {
-                        load_own(min(lk + 2, lk1), Pn);
-                        if (lk > lk0) y_exchange(Pp);         // Pp was requested one step ago; every wave of the workgroup passes here
-                    } else {
-                        load_plane(min(lk + 2, lk1), Pn, false);
-                    }
+                // lk + 2 can reach nkl + 1 (one plane past the upper ghost plane) only when it is not needed: clamp it
+                if (YX) {
+                    load_own(min(lk + 2, lk1), Pn);
+                    if (lk > lk0) y_exchange(Pp);             // Pp was requested one step ago; every wave of the workgroup passes here
                 } else {
-                    load_plane(lk + 1, Pp, lk + 1 < lk1);
+                    load_plane(min(lk + 2, lk1), Pn);
                 }
                 const long long obase = (long long)lk * g.PP + col;
 #pragma unroll
@@ -518,7 +454,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                     for (int c = 0; c < 3; ++c) {
                         Pm[r][c] = P0[r][c];
                         P0[r][c] = Pp[r][c];
-                        if (PF) Pp[r][c] = Pn[r][c];
+                        Pp[r][c] = Pn[r][c];
                     }
             }
         }
@@ -527,10 +463,9 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
-// r -= alpha q;  z = D^-1 r;  partial r.z and r.r     (use_alpha == 0: alpha = 0, forms z and the sums only)
+// r -= alpha q;  partial r.z (z = D^-1 r, not stored) and r.r     (use_alpha == 0: alpha = 0, the sums only)
 template <int D>
-__global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restrict__ q, double* __restrict__ r,
-                                                double* __restrict__ z, int use_alpha) {
+__global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restrict__ q, double* __restrict__ r, int use_alpha) {
     __shared__ double sRed[4];
     __shared__ double sDinv[27 * 3];
     if (threadIdx.x < 81) sDinv[threadIdx.x] = a.dinv[threadIdx.x];
@@ -581,8 +516,8 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
                 rv.y -= alpha * qv.y;
                 *reinterpret_cast<double2*>(r + c * a.stride + idx) = rv;
             }
+            // z = D^-1 r is not stored: the p-update forms it again from r (one vector pass less per iteration)
             const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv.x, sDinv[cls1 * 3 + c] * rv.y);
-            *reinterpret_cast<double2*>(z + c * a.stride + idx) = zv;
             acc_rz += rv.x * zv.x + rv.y * zv.y;
             acc_rr += rv.x * rv.x + rv.y * rv.y;
         }
@@ -600,6 +535,9 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
 template <int D>
 __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, long long total) {
     __shared__ double sRed2[8];
+    __shared__ double sDinv[27 * 3];
+    if (threadIdx.x < 81) sDinv[threadIdx.x] = a.dinv[threadIdx.x];
+    __syncthreads();
     double rz;
     if (a.din) {
         // both sums in one pass: all loads issued before the first barrier (each is an L2 miss right after a kernel boundary)
@@ -628,14 +566,35 @@ __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, l
     const double pq = a.scal[ESC_PQ], rz_prev = a.scal[a.s_rz_old];
     const double alpha_prev = (pq > 0.0 && rz_prev > 0.0) ? rz_prev / pq : 0.0;
     const double beta = (rz_prev > 0.0) ? rz / rz_prev : 0.0;
-    // 16 B per lane: first, total and the component stride are multiples of 16 doubles (PX is), the origins 128-B aligned
+    // 16 B per lane: first, total and the component stride are multiples of 16 doubles (PX is), the origins 128-B aligned.
+    // a.in = r; z = D^-1 r is formed here from the class of the node (Jacobi diagonal of its truncated stencil), so K2 does not
+    // have to store z.  (i, j, lk) of a pair advance incrementally by the grid stride; lk starts at -1 when a lower ghost plane exists.
+    const GridDev& g = a.g;
     const long long total2 = total / 2;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total2; e += (long long)gridDim.x * 256) {
+    const int PX2 = g.PX / 2;
+    const long long step = (long long)gridDim.x * 256;
+    const int di = (int)(step % PX2);
+    const long long drow = step / PX2;
+    const int dj = (int)(drow % g.NY), dk = (int)(drow / g.NY);
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    int i2 = (int)(e % PX2), j = (int)((e / PX2) % g.NY), lk = (int)((e / PX2) / g.NY) + (int)(first / g.PP);
+    for (; e < total2; e += step) {
         const long long idx = first + 2 * e;
+        const int kg = g.k0 + lk;
+        const int i = 2 * i2;
+        const int cyz = 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) + 9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
+        const int cls0 = pg_axis_class(i < g.NX ? i : 1, g.NX) + cyz;
+        const int cls1 = pg_axis_class(i + 1 < g.NX ? i + 1 : 1, g.NX) + cyz;
+        i2 += di;
+        j += dj;
+        lk += dk;
+        if (i2 >= PX2) { i2 -= PX2; ++j; }
+        if (j >= g.NY) { j -= g.NY; ++lk; }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             const double2 po = *reinterpret_cast<const double2*>(a.p_old + c * a.stride + idx);
-            const double2 zv = *reinterpret_cast<const double2*>(a.in + c * a.stride + idx);
+            const double2 rv = *reinterpret_cast<const double2*>(a.in + c * a.stride + idx);
+            const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv.x, sDinv[cls1 * 3 + c] * rv.y);
             *reinterpret_cast<double2*>(a.p_new + c * a.stride + idx) = make_double2(zv.x + beta * po.x, zv.y + beta * po.y);
             if (alpha_prev != 0.0) {
                 double2 xv = *reinterpret_cast<double2*>(a.x + c * a.stride + idx);
@@ -881,7 +840,7 @@ struct ElSession {
     double lam = 0, mu = 0;
     long long stride = 0;
     double *tab = nullptr, *dinv = nullptr, *scal = nullptr, *part = nullptr, *part2 = nullptr, *part3 = nullptr;   // part3: p.q partials of the apply
-    double *x = nullptr, *r = nullptr, *z = nullptr, *p[2] = {nullptr, nullptr}, *q = nullptr, *b = nullptr;   // origins
+    double *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *q = nullptr, *b = nullptr;   // origins
     std::vector<double*> bases;
     int pcur = 0;
     int nblk = 1;
@@ -1013,11 +972,11 @@ int el_apply(ElSession* s, const ElArgs& a, int mode) {
         const int nb = fg.nb_fast + fg.nb_bnd;
         const bool yx = s->ctx->el_fast_yx != 0;
         if (s->fast_ry == 2) {
-            if (yx) hipLaunchKernelGGL((k_el_fast<2, false, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-            else hipLaunchKernelGGL((k_el_fast<2, false, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+            if (yx) hipLaunchKernelGGL((k_el_fast<2, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+            else hipLaunchKernelGGL((k_el_fast<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
         } else {
-            if (yx) hipLaunchKernelGGL((k_el_fast<1, false, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-            else hipLaunchKernelGGL((k_el_fast<1, false, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+            if (yx) hipLaunchKernelGGL((k_el_fast<1, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+            else hipLaunchKernelGGL((k_el_fast<1, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
         }
         PG_HIP(s->ctx, hipGetLastError());
         s->last_apply_blocks = nb;
@@ -1039,8 +998,8 @@ int el_k2(ElSession* s, int use_alpha, ElLazy* lazy = nullptr) {
         a.din_n = s->last_apply_blocks;
         a.s_rz = lazy->cur;
     }
-    if (s->D == 3) hipLaunchKernelGGL(k_el_k2<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, s->z, use_alpha);
-    else hipLaunchKernelGGL(k_el_k2<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, s->z, use_alpha);
+    if (s->D == 3) hipLaunchKernelGGL(k_el_k2<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, use_alpha);
+    else hipLaunchKernelGGL(k_el_k2<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, use_alpha);
     PG_HIP(s->ctx, hipGetLastError());
     if (lazy) {
         lazy->pend = true;
@@ -1064,7 +1023,7 @@ int el_lazy_finish(ElSession* s, ElLazy* lazy) {
 // the 15 x 3 x 2 neighbour reads of the fused form cost more than the extra launch: measured 110 -> ~60 us.)
 int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
     ElArgs a = s->args();
-    a.in = s->z;
+    a.in = s->r;                 // the p-update forms z = D^-1 r itself
     a.p_old = s->p[s->pcur];
     a.p_new = s->p[1 - s->pcur];
     a.x = s->x;
@@ -1081,22 +1040,6 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
             a.s_rz = lazy->cur;
             a.s_rz_old = lazy->cur == ESC_RZ ? ESC_RZ_PREV : ESC_RZ;
         }
-    }
-    if (s->fast && s->ctx->el_fast && s->ctx->el_fused_k1) {
-        // one launch: p-update, deferred x-update, q = A p, p.q partials (k_el_fast<RY, true>)
-        const ElFastGeom& fg = s->fgeom;
-        const int nb = fg.nb_fast + fg.nb_bnd;
-        a.out = s->q;
-        a.partials = s->part3;
-        if (s->fast_ry == 2) hipLaunchKernelGGL((k_el_fast<2, true, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-        else hipLaunchKernelGGL((k_el_fast<1, true, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-        PG_HIP(s->ctx, hipGetLastError());
-        s->last_apply_blocks = nb;
-        s->pcur ^= 1;
-        if (lazy) return PDEGPU_OK;
-        hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part3, (const double*)nullptr, nb, s->scal, 0);
-        PG_HIP(s->ctx, hipGetLastError());
-        return PDEGPU_OK;
     }
     const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
     const long long first = -(long long)lo * s->g.PP, total = (long long)(s->g.nkl + lo + hi) * s->g.PP;
@@ -1164,7 +1107,7 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     PG_HIP(ctx, hipMalloc(&s->part2, npart * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->part3, npart * sizeof(double)));
     PG_TRY(tables_build(ctx, grid, &s->ht));
-    double** vecs[] = {&s->x, &s->r, &s->z, &s->p[0], &s->p[1], &s->q, &s->b};
+    double** vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
     for (double** v : vecs) {
         *v = s->alloc_vec();
         if (!*v) return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc of an elasticity vector failed");
@@ -1176,7 +1119,7 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
 int el_begin(ElSession* s, const pdegpu_elasticity* el) {
     pdegpu_ctx* ctx = s->ctx;
     const size_t bytes = (size_t)s->D * s->stride * sizeof(double);
-    for (double* v : {s->x, s->p[0], s->p[1], s->q, s->z})
+    for (double* v : {s->x, s->p[0], s->p[1], s->q})
         PG_HIP(ctx, hipMemsetAsync(v - vec_front(s->g), 0, bytes, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(s->scal, 0, ESC_COUNT * sizeof(double), ctx->stream));
     s->pcur = 0;
@@ -1553,7 +1496,6 @@ extern "C" void* pdegpu_el_session_plane_ptr(pdegpu_el_session* h, int vec, int 
         case 1: base = h->s.r; break;
         case 2: base = h->s.p[h->s.pcur]; break;
         case 3: base = h->s.q; break;
-        case 4: base = h->s.z; break;
         default: return nullptr;
     }
     return base + (long long)comp * h->s.stride + which * h->s.g.PP;

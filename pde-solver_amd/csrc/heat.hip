@@ -344,7 +344,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fused_k1", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -374,7 +374,6 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_small_mult")) return &ctx->fast_small_mult;
     if (!strcmp(key, "el_fast")) return &ctx->el_fast;
     if (!strcmp(key, "el_fast_ry")) return &ctx->el_fast_ry;
-    if (!strcmp(key, "el_fused_k1")) return &ctx->el_fused_k1;
     if (!strcmp(key, "el_fast_yx")) return &ctx->el_fast_yx;
     if (!strcmp(key, "el_fast_waves")) return &ctx->el_fast_waves;
     return nullptr;

@@ -187,7 +187,7 @@ class GpuElasticitySlabEngine:
         return t
 
     def halo_tensors(self, which: int):
-        return [self.plane_tensor(v, c, which) for v in (4, 2) for c in range(3)]       # z and p, 3 components each
+        return [self.plane_tensor(v, c, which) for v in (1, 2) for c in range(3)]       # r and p, 3 components each (z = D^-1 r is formed by the p-update)
 
     def global_slots(self, which: int):
         return (0, 1) if which == 0 else (1, 3)          # p.q | r.z and r.r as one 16-byte message

@@ -234,22 +234,22 @@ def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, dim):
     assert np.array_equal(outs[0].values, outs[1].values)
 
 
-def test_fused_and_unfused_k1_and_row_variants_agree(lib, gpu_ctx):
-    """3-D PCG: p-update fused into the marching kernel (default) vs flat p-update + plain apply, 1 | 2 rows per column,
-    thread-per-node kernels: the same solution to solver tolerance (partial sums are grouped differently)"""
+def test_row_and_kernel_variants_agree(lib, gpu_ctx):
+    """3-D PCG with the marching block apply at 1 | 2 rows per column, with / without the LDS y-hand-off, with the
+    thread-per-node kernels, eager dot products: the same solution to solver tolerance (partial sums are grouped differently)"""
     from pdegpu import elasticity, _lib
     def tun(**kw):
         for k, v in kw.items():
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
     outs = []
     try:
-        for cfg in (dict(el_fast=1, el_fused_k1=1, el_fast_ry=1), dict(el_fast=1, el_fused_k1=0, el_fast_ry=1),
-                    dict(el_fast=1, el_fused_k1=1, el_fast_ry=2), dict(el_fast=0), dict(el_fast=1, el_fused_k1=1, el_fast_ry=1, lazy_dot=0)):
+        for cfg in (dict(el_fast=1, el_fast_ry=2, el_fast_yx=1), dict(el_fast=1, el_fast_ry=1, el_fast_yx=1), dict(el_fast=1, el_fast_ry=2, el_fast_yx=0),
+                    dict(el_fast=0), dict(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=0)):
             tun(**cfg)
             outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress",
-                                                               rtol=1e-12, want_displacement=True))
+                                                               rtol=1e-12))
     finally:
-        tun(el_fast=1, el_fused_k1=0, el_fast_ry=2, lazy_dot=1)
+        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1)
     ref = o.solve_elasticity_3d(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress")
     for f in outs:
         assert rel_err(f.values, ref.values) < TOL

@@ -20,9 +20,7 @@ for n in ((256, 64, 64), (512, 128, 128)):
         ms = C.c_double()
         L.check(ctx, lib.pdegpu_elasticity_time_apply(ctx, g, el, 0, 30, C.byref(ms)))
         print(f"{n} {cfg}: {ms.value*1e3:.1f} us/apply, {48*nodes/ms.value/1e6:.0f} GB/s alg", flush=True)
-for cfg in (dict(el_fast=0), dict(el_fast=1, el_fused_k1=0, el_fast_ry=1, el_fast_waves=2048), dict(el_fast=1, el_fused_k1=1, el_fast_ry=1, el_fast_waves=2048),
-            dict(el_fast=1, el_fused_k1=1, el_fast_ry=1, el_fast_waves=4096), dict(el_fast=1, el_fused_k1=1, el_fast_ry=2, el_fast_waves=2048),
-            dict(el_fast=1, el_fused_k1=1, el_fast_ry=2, el_fast_waves=4096)):
+for cfg in (dict(el_fast=0), dict(el_fast=1, el_fast_ry=1, el_fast_waves=2048), dict(el_fast=1, el_fast_ry=2, el_fast_waves=4096)):
     tun(**cfg)
     for rep in range(2):
         t0 = time.perf_counter()

@@ -1,4 +1,4 @@
-"""Scratch: elasticity PCG iteration time at an HBM-resident size, fused vs unfused K1."""
+"""Scratch: elasticity PCG iteration time at an HBM-resident size, rows per column."""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -6,7 +6,7 @@ sys.path[:0] = [str(ROOT), str(ROOT / "pde-solver_amd")]
 from pdegpu import _lib as L, elasticity
 lib = L.load_library(); ctx = L.context(0)
 n = (512, 128, 128)
-for cfg in (dict(el_fused_k1=0, el_fast_ry=2), dict(el_fused_k1=1, el_fast_ry=1), dict(el_fused_k1=1, el_fast_ry=2), dict(el_fused_k1=0, el_fast_ry=2)):
+for cfg in (dict(el_fast_ry=2), dict(el_fast_ry=1), dict(el_fast_ry=2)):
     for k, v in cfg.items():
         L.check(ctx, lib.pdegpu_set_tunable(ctx, k.encode(), v))
     try:
