@@ -36,6 +36,8 @@ struct pdegpu_ctx {
     int el_fast_yx = 1;         // k_el_fast: 1 = the 4 waves of a workgroup are y-neighbours and hand their y-halo rows through LDS
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
+    int plane2d_ry = 4;         // rows per wavefront tile of k_plane2d (2 | 4 | 8)
+    int plane2d = 1;            // 2-D grids: 1 = the two CG kernels load their tile in one round (k_plane2d); 0 = flat view of the marching kernels
     int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary
                                 // nodes; 0 = class-table kernel everywhere
     int extrapolate = 1;        // transient solves start CG from 2 u^n - u^{n-1} instead of u^n (fewer iterations, same tolerance)
@@ -223,6 +225,7 @@ bool stencil_all_dirichlet(const GridDev& g);
 GridDev stencil_flat2d_view(const GridDev& g);
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 int stencil_max_partials(pdegpu_ctx* ctx);
+int stencil_plane2d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);   // 2-D: CG_K1 / CG_K2 without marching
 
 int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
 void vec_free(DevVec* v);

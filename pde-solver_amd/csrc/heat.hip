@@ -23,6 +23,7 @@ struct pdegpu_session {
     HeatTables tabs{};
     double cM = 0, cK = 0;
     bool fast = false;
+    bool plane2d = false;          // 2-D: K1 / K2 through k_plane2d (one load round per tile) instead of the flat view
     bool hybrid = false;           // fast && some boundary node is free: marching kernel (interior) + class-table kernel (boundary nodes)
     int npt = 15;
     double hA[27 * 27];
@@ -124,6 +125,18 @@ void fast_weights(const double* tab, double* w, bool flat2d = false) {
         w[3] = w[2]; w[5] = w[4];
         w[2] = w[4] = w[6] = w[7] = 0.0;
     }
+}
+
+// in-plane weights of a 2-D interior stencil for k_plane2d: w0, wx, wy, wd1 = (+1,+1), wd2 = (-1,+1)
+void plane2d_weights(const double* tab, double* w) {
+    const double* c = tab + 13 * 27;
+    w[0] = c[13]; w[1] = c[14]; w[2] = c[16]; w[3] = c[17]; w[4] = c[15];
+    w[5] = w[6] = w[7] = 0.0;
+}
+bool plane2d_symmetric(const double* tab) {       // the kernel assumes w(-o) = w(o)
+    const double* c = tab + 13 * 27;
+    const double tol = 1e-13 * std::fabs(c[13]);
+    return std::fabs(c[12] - c[14]) <= tol && std::fabs(c[10] - c[16]) <= tol && std::fabs(c[9] - c[17]) <= tol && std::fabs(c[11] - c[15]) <= tol;
 }
 
 // Q1 interior stencil: the weight of an offset depends on |dx|, |dy|, |dz| only (checked before the 27-point marching
@@ -249,7 +262,12 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     int rc;
-    if (s->fast) {
+    if (s->plane2d) {
+        a.g = s->g;
+        plane2d_weights(s->hA, a.w);
+        a.dot_which = -1;
+        rc = stencil_plane2d(s->ctx, a, APPLY_CG_K1, li);
+    } else if (s->fast) {
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
@@ -280,6 +298,12 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         a.counter = s->d_counter;
         a.dot_which = s->ctx->inlaunch_dot ? 1 : -1;
         a.mask_dirichlet = 1;
+        if (s->plane2d) {
+            a.g = s->g;
+            plane2d_weights(s->hA, a.w);
+            a.dot_which = -1;
+            return stencil_plane2d(s->ctx, a, APPLY_CG_K2, li);
+        }
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
@@ -295,7 +319,7 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
 // (k_reduce); with the inlaunch_dot tunable the producing kernel has already done it (dot_finish.h) unless its grid
 // was empty (a slab without free planes), in which case the sum 0 still has to be recorded
 int empty_dot(pdegpu_session* s, const LaunchInfo& li, int which) {
-    if (s->ctx->inlaunch_dot && li.grid > 0 && !s->hybrid) return PDEGPU_OK;
+    if (s->ctx->inlaunch_dot && li.grid > 0 && !s->hybrid && !s->plane2d) return PDEGPU_OK;
     return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, which, 1);
 }
 int residual_finish(pdegpu_session* s, LaunchInfo* li) {
@@ -344,7 +368,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "plane2d_ry", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -370,6 +394,8 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "lazy_dot")) return &ctx->lazy_dot;
     if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
     if (!strcmp(key, "hybrid_bc")) return &ctx->hybrid_bc;
+    if (!strcmp(key, "plane2d")) return &ctx->plane2d;
+    if (!strcmp(key, "plane2d_ry")) return &ctx->plane2d_ry;
     if (!strcmp(key, "fast_minlen")) return &ctx->fast_minlen;
     if (!strcmp(key, "fast_small_mult")) return &ctx->fast_small_mult;
     if (!strcmp(key, "el_fast")) return &ctx->el_fast;
@@ -467,6 +493,7 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
             else s->fast = s->hybrid = false;
         }
     }
+    s->plane2d = s->fast && s->g.dim == 2 && ctx->plane2d != 0 && plane2d_symmetric(s->hA);
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
     for (DevVec* v : vecs)
         if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);

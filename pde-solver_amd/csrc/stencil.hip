@@ -492,6 +492,102 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     dot_finish(tot, DotSink{a.partials, a.counter, a.scal, a.dot_which}, sRed);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 2-D grids: the two CG kernels without marching
+// ---------------------------------------------------------------------------------------------
+// A 2-D grid has no third axis to march along: through the flat view every row is a "plane", so a wave's z-chunk is a chain of
+// dependent one-row load rounds (config 2: K1 = 17 us for 1 M nodes, all latency).  Here a wavefront owns a 128-node x RY-row
+// tile, requests its RY + 2 rows (r and p_{n-1}, or the stored p_n) in ONE round, forms p at every held row and applies the
+// in-plane stencil w0, wx, wy, wd1 (offsets +-(1,1), the P1 diagonal), wd2 (offsets +-(1,-1); Q1: wd2 = wd1) with the same DPP
+// x-shifts as the marching kernel.  The four waves of a workgroup are stacked in y, so their shared halo rows meet in one L1.
+// Every boundary node is Dirichlet here (the 2-D tools have one boundary value): CG vectors vanish on the boundary columns.
+template <int RY, int MODE>
+__global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty) {
+    __shared__ double sRed[4];
+    constexpr bool K1 = (MODE == APPLY_CG_K1);
+    constexpr int RH = RY + 2;
+    const GridDev& g = a.g;
+    double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
+    if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
+    else res_scale = cg_alpha_in(a.di, a.scal, sRed);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int xt = (int)blockIdx.x % ntx, yt = ((int)blockIdx.x / ntx) * 4 + wv;
+    const bool active = yt < nty;
+    const int i0 = xt * 128 + 2 * lane;
+    const int j0 = 1 + yt * RY;
+    const bool lane_ok = active && i0 < g.PX;
+    const bool ma = active && i0 >= 1 && i0 <= g.NX - 2;
+    const bool mb = active && i0 + 1 <= g.NX - 2;
+    const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wd1 = a.w[3], wd2 = a.w[4];
+    // tile-edge neighbours: lane 0 needs node i0-1, lane 63 node i0+2; they are zero on / beyond the Dirichlet columns
+    const bool el = lane == 0 && active && i0 - 1 >= 1;
+    const bool er = lane == 63 && active && i0 + 2 <= g.NX - 2;
+    const long long eoff = (lane == 0) ? -1 : 2;
+
+    double2 C[RH], PO[RH];
+    double E[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+        const int j = j0 - 1 + r;
+        C[r] = make_double2(0.0, 0.0);
+        PO[r] = make_double2(0.0, 0.0);
+        E[r] = 0.0;
+        if (j <= g.NY - 1) {
+            const long long off = (long long)j * g.PX + i0;
+            if (lane_ok) {
+                const double2 v = *reinterpret_cast<const double2*>(a.in + off);
+                if (K1) {
+                    PO[r] = *reinterpret_cast<const double2*>(a.p_old + off);
+                    C[r] = make_double2(v.x + beta * PO[r].x, v.y + beta * PO[r].y);
+                } else {
+                    C[r] = v;
+                }
+            }
+            if (el || er) E[r] = K1 ? a.in[off + eoff] + beta * a.p_old[off + eoff] : a.in[off + eoff];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 1; r <= RY; ++r) {
+        const int j = j0 - 1 + r;
+        if (j <= g.NY - 2) {                                  // wave-uniform
+            const long long off = (long long)j * g.PX + i0;
+            double lC = dpp_from_lower(C[r].y), rC = dpp_from_upper(C[r].x);
+            double lCm = dpp_from_lower(C[r - 1].y), rCm = dpp_from_upper(C[r - 1].x);
+            double lCp = dpp_from_lower(C[r + 1].y), rCp = dpp_from_upper(C[r + 1].x);
+            if (lane == 0) { lC = E[r]; lCm = E[r - 1]; lCp = E[r + 1]; }
+            if (lane == 63) { rC = E[r]; rCm = E[r - 1]; rCp = E[r + 1]; }
+            const double qa = w0 * C[r].x + wx * (lC + C[r].y) + wy * (C[r - 1].x + C[r + 1].x) + wd1 * (C[r + 1].y + lCm) +
+                              wd2 * (C[r - 1].y + lCp);
+            const double qb = w0 * C[r].y + wx * (C[r].x + rC) + wy * (C[r - 1].y + C[r + 1].y) + wd1 * (rCp + C[r - 1].x) +
+                              wd2 * (rCm + C[r + 1].x);
+            if (K1) {
+                if (lane_ok) {
+                    *reinterpret_cast<double2*>(a.p_new + off) = C[r];
+                    if (alpha_prev != 0.0) {
+                        double2 xv = *reinterpret_cast<double2*>(a.x + off);
+                        xv.x += alpha_prev * PO[r].x;
+                        xv.y += alpha_prev * PO[r].y;
+                        *reinterpret_cast<double2*>(a.x + off) = xv;
+                    }
+                }
+                const double2 o = make_double2(ma ? qa : 0.0, mb ? qb : 0.0);
+                acc += C[r].x * o.x + C[r].y * o.y;
+                if (lane_ok && a.out) *reinterpret_cast<double2*>(a.out + off) = o;
+            } else {
+                double2 rv = make_double2(0.0, 0.0);
+                if (lane_ok) rv = *reinterpret_cast<const double2*>(a.rhs + off);
+                const double2 o = make_double2(ma ? rv.x - res_scale * qa : 0.0, mb ? rv.y - res_scale * qb : 0.0);
+                acc += o.x * o.x + o.y * o.y;
+                if (lane_ok) *reinterpret_cast<double2*>(a.out + off) = o;
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+}
+
 FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
     FastGeom fg{};
     fg.ntx = (g.NX - 1 + 127) / 128;
@@ -594,6 +690,25 @@ int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* 
 }
 
 }  // namespace
+
+// the two CG kernels of a 2-D grid without marching (k_plane2d); a.g is the 2-D grid itself, a.w = {w0, wx, wy, wd1, wd2}
+template <int RY>
+static int launch_plane2d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    const int ntx = (a.g.NX - 1 + 127) / 128;
+    const int nty = (a.g.NY - 2 + RY - 1) / RY;
+    const int G = ntx * ((nty + 3) / 4);
+    if (li) { li->grid = G; li->block = 256; }
+    if (G == 0) return PDEGPU_OK;
+    if (mode == APPLY_CG_K1) hipLaunchKernelGGL((k_plane2d<RY, APPLY_CG_K1>), dim3(G), dim3(256), 0, ctx->stream, a, ntx, nty);
+    else hipLaunchKernelGGL((k_plane2d<RY, APPLY_CG_K2>), dim3(G), dim3(256), 0, ctx->stream, a, ntx, nty);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+int stencil_plane2d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    if (ctx->plane2d_ry == 2) return launch_plane2d<2>(ctx, a, mode, li);
+    if (ctx->plane2d_ry == 8) return launch_plane2d<8>(ctx, a, mode, li);
+    return launch_plane2d<4>(ctx, a, mode, li);
+}
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     const long long total = a.bnd_n > 0 ? a.bnd_n : (long long)a.g.nkl * a.g.PP;

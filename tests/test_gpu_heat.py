@@ -527,3 +527,32 @@ def test_q1_27_point_marching_kernel_matches_class_table_kernel(lib, gpu_ctx, ca
     a, b = run(True), run(False)
     assert a.meta["solver_path"] == ("fast+boundary" if case == "3d_natural_faces" else "fast") and b.meta["solver_path"] == "general"
     assert a.meta["element_mode"] == "q1" and rel_err(a.values, b.values) < TOL
+
+
+@pytest.mark.parametrize("steady", [False, True])
+@pytest.mark.parametrize("em", ["p1split", "q1"])
+def test_2d_tile_kernel_and_flat_view_agree(lib, gpu_ctx, steady, em):
+    """2-D CG kernels: one-round tile kernel k_plane2d (default; 2 / 4 / 8 rows per tile) vs the flat view of the marching
+    kernels (plane2d = 0) vs the class-table kernels, P1 (7-point incl. the (1,1) diagonal) and Q1 (9-point), steady
+    (5-point, stencil K2) and transient; awkward widths around the 128-node tile"""
+    from pdegpu import heat, _lib
+    emode = _lib.ELEM_Q1 if em == "q1" else _lib.ELEM_P1SPLIT
+    outs = []
+    try:
+        for nx in (129, 257, 100):
+            res = []
+            for cfg in (dict(plane2d=1, plane2d_ry=4), dict(plane2d=1, plane2d_ry=2), dict(plane2d=1, plane2d_ry=8), dict(plane2d=0), None):
+                for k, v in (cfg or {}).items():
+                    _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+                res.append(heat._solve_heat_2d_raw(1.3, 0.7, nx, 37, 0.8, 3.0, 20.0, 0.004, 2, steady=steady, source_type="constant",
+                                                   source_value=2.0, rtol=1e-12, element_mode=emode, fast_path=cfg is not None))
+            assert [r.meta["solver_path"] for r in res] == ["fast"] * 4 + ["general"]
+            for r in res[1:]:
+                assert rel_err(r.values, res[0].values) < TOL
+            outs.append(res[0])
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"plane2d", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"plane2d_ry", 4))
+    if em == "p1split":
+        ref = o.solve_heat_2d(1.3, 0.7, 100, 37, 0.8, 3.0, 20.0, 0.004, 2, steady=steady, source_type="constant", source_value=2.0)
+        assert rel_err(outs[2].values, ref.values) < TOL
