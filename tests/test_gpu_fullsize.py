@@ -151,3 +151,73 @@ def test_config4_grid_one_slab_vs_two_slabs(lib, gpu_ctx):
     h1, h2 = history(1), history(2)
     assert np.all(np.isfinite(h1)) and np.all(h1 > 0.0)          # (the residual norm of CG is not monotone: no ordering asserted)
     assert np.allclose(h2, h1, rtol=1e-11)
+
+
+def test_random_tiny_grids_all_paths_match_the_oracle(lib, gpu_ctx):
+    """edge shapes: 1-5 cells per axis (grids with no interior node, a single interior node, one-row tiles), random boundary
+    specifications, steady and transient — whatever path the library picks (marching, tile, hybrid, class-table, Thomas) must
+    reproduce the oracle"""
+    from oracle import fem_p1 as o
+    from pdegpu import heat, elasticity
+    rng = np.random.default_rng(20251004)
+    rel = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+    paths = set()
+    for case in range(36):
+        dim = int(rng.integers(1, 4))
+        n = [int(rng.integers(1, 6)) for _ in range(dim)]
+        Ls = [float(rng.uniform(0.3, 2.0)) for _ in range(dim)]
+        steady = bool(rng.integers(0, 2))
+        common = dict(diffusivity=float(rng.uniform(0.2, 2.0)), T_initial=float(rng.uniform(-5, 20)), dt=0.01, num_steps=2, steady=steady,
+                      source_type="constant", source_value=float(rng.uniform(-3, 3)))
+        if dim == 1:
+            kw = dict(length=Ls[0], nx=n[0], T_left=float(rng.uniform(-5, 5)), T_right=float(rng.uniform(-5, 5)), **common)
+            got, ref = heat._solve_heat_1d_raw(**kw, rtol=1e-13), o.solve_heat_1d(**kw)
+        elif dim == 2:
+            kw = dict(Lx=Ls[0], Ly=Ls[1], nx=n[0], ny=n[1], T_boundary=float(rng.uniform(-5, 5)), **common)
+            got, ref = heat._solve_heat_2d_raw(**kw, rtol=1e-13), o.solve_heat_2d(**kw)
+        else:
+            kw = dict(Lx=Ls[0], Ly=Ls[1], Lz=Ls[2], nx=n[0], ny=n[1], nz=n[2], T_boundary=float(rng.uniform(-5, 5)), **common)
+            mode = int(rng.integers(0, 3))
+            if mode == 1:
+                kw.update(T_left=float(rng.uniform(-5, 5)), T_right=None, T_side=None)
+            elif mode == 2:
+                kw.update(T_left=None, T_right=float(rng.uniform(-5, 5)), T_side=float(rng.uniform(-5, 5)))
+            got, ref = heat._solve_heat_3d_raw(**kw, rtol=1e-13), o.solve_heat_3d(**kw)
+        paths.add(got.meta["solver_path"])
+        assert rel(got.values, ref.values) < 1e-9, (case, dim, n, steady, got.meta["solver_path"])
+    assert {"tridiagonal-direct", "fast", "general"} <= paths
+    for case in range(8):
+        n = [int(rng.integers(1, 6)) for _ in range(3)]
+        body = [float(rng.uniform(-1e4, 1e4)) for _ in range(3)]
+        kw = dict(Lx=1.0, Ly=0.4, Lz=0.3, nx=n[0], ny=n[1], nz=n[2], E=210e9, nu=float(rng.uniform(0.0, 0.45)), body_fx=body[0], body_fy=body[1],
+                  body_fz=body[2], quantity="stress" if case % 2 else "strain")
+        got, ref = elasticity._solve_elasticity_3d_static(**kw, rtol=1e-13), o.solve_elasticity_3d(**kw)
+        assert rel(got.values, ref.values) < 1e-8, (case, n)
+
+
+def test_random_mid_grids_fast_paths_match_the_oracle(lib, gpu_ctx):
+    """3-18 cells per axis, anisotropic spacing, random boundary specification: the 2-D tile kernel, the marching kernels and
+    the hybrid (natural faces) path against the oracle"""
+    from oracle import fem_p1 as o
+    from pdegpu import heat
+    rng = np.random.default_rng(7771)
+    rel = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+    paths = []
+    for case in range(24):
+        dim = 2 + case % 2
+        n = [int(rng.integers(3, 19)) for _ in range(dim)]
+        Ls = [float(rng.uniform(0.3, 2.0)) for _ in range(dim)]
+        common = dict(diffusivity=float(rng.uniform(0.2, 2.0)), T_initial=float(rng.uniform(-5, 20)), dt=float(rng.uniform(0.002, 0.02)), num_steps=2,
+                      steady=bool(rng.integers(0, 2)), source_type="constant", source_value=float(rng.uniform(-3, 3)))
+        if dim == 2:
+            kw = dict(Lx=Ls[0], Ly=Ls[1], nx=n[0], ny=n[1], T_boundary=float(rng.uniform(-5, 5)), **common)
+            got, ref = heat._solve_heat_2d_raw(**kw, rtol=1e-13), o.solve_heat_2d(**kw)
+        else:
+            kw = dict(Lx=Ls[0], Ly=Ls[1], Lz=Ls[2], nx=n[0], ny=n[1], nz=n[2], T_boundary=float(rng.uniform(-5, 5)), **common)
+            if case % 4 == 1:
+                kw.update(T_left=float(rng.uniform(-5, 5)), T_right=float(rng.uniform(-5, 5)) if rng.integers(0, 2) else None,
+                          T_side=float(rng.uniform(-5, 5)) if rng.integers(0, 2) else None)
+            got, ref = heat._solve_heat_3d_raw(**kw, rtol=1e-13), o.solve_heat_3d(**kw)
+        paths.append(got.meta["solver_path"])
+        assert rel(got.values, ref.values) < 1e-9, (case, dim, n, got.meta["solver_path"])
+    assert paths.count("fast") >= 12 and "fast+boundary" in paths and "general" not in paths
