@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../pde-solver_amd"
 rm -rf build_asan && mkdir -p build_asan
-for f in tables stencil vecops heat elasticity weighted; do
+for f in tridiag tables stencil vecops heat elasticity weighted; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address -fno-omit-frame-pointer -c csrc/$f.hip -o build_asan/$f.o
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address build_asan/*.o -o build_asan/libpdegpu_asan.so
