@@ -209,6 +209,10 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     return stencil_general(s->ctx, a, APPLY_PLAIN, nullptr);
 }
 
+// the in-launch dot completion (tunable inlaunch_dot) applies to sessions whose dot-producing step is ONE launch; hybrid and
+// 2-D tile sessions append a second launch's partials, so they always use the reduce launch / the prologue sum
+bool use_inlaunch(const pdegpu_session* s) { return s->ctx->inlaunch_dot != 0 && !s->hybrid && !s->plane2d; }
+
 // out = P (rhs - A in), partials of out.out
 int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* out, LaunchInfo* li) {
     StencilArgs a{};
@@ -219,7 +223,7 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     a.partials = s->d_part;
     a.counter = s->d_counter;
     a.scal = s->d_scal;
-    a.dot_which = (s->weighted || !s->ctx->inlaunch_dot) ? -1 : 1;   // PCG forms rho = r.z in the follow-up k_k2_pc pass
+    a.dot_which = (s->weighted || !use_inlaunch(s)) ? -1 : 1;   // PCG forms rho = r.z in the follow-up k_k2_pc pass
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     if (s->weighted) {
@@ -258,7 +262,7 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
     a.scal = s->d_scal;
     a.partials = s->d_part;
     a.counter = s->d_counter;
-    a.dot_which = s->ctx->inlaunch_dot ? 0 : -1;
+    a.dot_which = use_inlaunch(s) ? 0 : -1;
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     int rc;
@@ -296,7 +300,7 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         a.scal = s->d_scal;
         a.partials = part_out;
         a.counter = s->d_counter;
-        a.dot_which = s->ctx->inlaunch_dot ? 1 : -1;
+        a.dot_which = use_inlaunch(s) ? 1 : -1;
         a.mask_dirichlet = 1;
         if (s->plane2d) {
             a.g = s->g;
@@ -309,7 +313,8 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         a.npt = s->npt;
         return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
     }
-    unsigned* cnt = s->ctx->inlaunch_dot ? s->d_counter : nullptr;      // nullptr: partials only, reduced by k_reduce
+    // nullptr: partials only, reduced by k_reduce (always so when K1's dot has a second launch to wait for: hybrid / 2-D tile sessions)
+    unsigned* cnt = use_inlaunch(s) ? s->d_counter : nullptr;
     if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, cnt, 1, li);
     return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, part_out, cnt, li, di);
 }
@@ -319,12 +324,12 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
 // (k_reduce); with the inlaunch_dot tunable the producing kernel has already done it (dot_finish.h) unless its grid
 // was empty (a slab without free planes), in which case the sum 0 still has to be recorded
 int empty_dot(pdegpu_session* s, const LaunchInfo& li, int which) {
-    if (s->ctx->inlaunch_dot && li.grid > 0 && !s->hybrid && !s->plane2d) return PDEGPU_OK;
+    if (use_inlaunch(s) && li.grid > 0) return PDEGPU_OK;
     return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, which, 1);
 }
 int residual_finish(pdegpu_session* s, LaunchInfo* li) {
     if (s->weighted) {
-        unsigned* cnt = s->ctx->inlaunch_dot ? s->d_counter : nullptr;
+        unsigned* cnt = use_inlaunch(s) ? s->d_counter : nullptr;
         PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, cnt, 0, li));
     }
     return empty_dot(s, *li, 1);
@@ -656,7 +661,7 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
     // slots alternate so that no launch overwrites a scalar its own workgroups still read, and one reduce launch at the
     // end of the chunk leaves the canonical layout (SC_RR current, SC_RR_PREV previous) for the host and for flush.
     const int64_t nslow = s->grid.dim == 3 ? (int64_t)s->grid.n[2] + 1 : 1;
-    const bool lazy = ctx->lazy_dot && !ctx->inlaunch_dot && !s->weighted && s->g.k0 == 0 && s->g.nkl == nslow &&
+    const bool lazy = ctx->lazy_dot && !use_inlaunch(s) && !s->weighted && s->g.k0 == 0 && s->g.nkl == nslow &&
                       done < iters;
     if (lazy) {
         int cur = SC_RR;

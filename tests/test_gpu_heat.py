@@ -556,3 +556,32 @@ def test_2d_tile_kernel_and_flat_view_agree(lib, gpu_ctx, steady, em):
     if em == "p1split":
         ref = o.solve_heat_2d(1.3, 0.7, 100, 37, 0.8, 3.0, 20.0, 0.004, 2, steady=steady, source_type="constant", source_value=2.0)
         assert rel_err(outs[2].values, ref.values) < TOL
+
+
+@pytest.mark.parametrize("knob", ["use_graph", "inlaunch_dot"])
+@pytest.mark.parametrize("case", ["3d_fast", "3d_general", "2d", "3d_natural_faces", "weighted_2d_cylindrical", "3d_steady_64B"])
+def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, case):
+    """the two measured-slower variants kept as tunables — CG chunks replayed from a captured hipGraph, dot products finished
+    inside the producing launch by the last workgroup — produce bitwise the default results (all of them sum the partials in
+    the same order)"""
+    from pdegpu import heat, _lib
+    def run():
+        if case == "2d":
+            return heat._solve_heat_2d_raw(1.0, 0.7, 90, 50, 0.8, 3.0, 20.0, 0.004, 3, rtol=1e-11)
+        if case == "weighted_2d_cylindrical":
+            from pdegpu import curvilinear as cv
+            return cv._solve_heat_2d_cylindrical_raw(r_inner=0.1, r_outer=1.0, z_length=2.0, nr=24, nz=18, diffusivity=1.0, T_boundary=0.0,
+                                                     T_initial=20.0, dt=0.01, num_steps=3, rtol=1e-11)
+        if case == "3d_steady_64B":
+            return heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 40, 21, 17, 0.9, 1.5, 20.0, 0.003, 1, steady=True, source_type="constant",
+                                           source_value=2.0, rtol=1e-11)
+        kw = dict(T_left=4.0, T_right=None, T_side=None) if case == "3d_natural_faces" else {}
+        return heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 40, 21, 17, 0.9, 1.5, 20.0, 0.003, 3, rtol=1e-11, fast_path=(case != "3d_general"), **kw)
+    base = run()
+    try:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, knob.encode(), 1))
+        alt = run()
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, knob.encode(), 0))
+    assert alt.meta["cg_iterations"] == base.meta["cg_iterations"] > 0
+    assert np.array_equal(alt.values, base.values)
