@@ -585,3 +585,30 @@ def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, ca
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, knob.encode(), 0))
     assert alt.meta["cg_iterations"] == base.meta["cg_iterations"] > 0
     assert np.array_equal(alt.values, base.values)
+
+
+@pytest.mark.parametrize("setting", [dict(fast_ry=1), dict(fast_ry=4), dict(fast_ry=8), dict(fast_nt=0), dict(fast_nt=3), dict(fast_ex=0),
+                                     dict(fast_wg_per_cu=2), dict(fast_wg_per_cu_k2=3), dict(grid_mult=2), dict(k2_grid_mult=8),
+                                     dict(extrapolate=0), dict(hybrid_bc=0), dict(fast_minlen=4), dict(fast_small_mult=4),
+                                     dict(cg_variant=0), dict(cg_variant=0, fast_ex=0, fast_ry=4)])
+def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting):
+    """'results do not depend on the tunables' (include/pdegpu.h): each one, away from its default, on a 3-D steady (7-point,
+    64-B variant), a 3-D transient (15-point) and a natural-face problem, against the default run"""
+    from pdegpu import heat, _lib
+    defaults = dict(fast_ry=2, fast_nt=-1, fast_ex=1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, extrapolate=1,
+                    hybrid_bc=1, fast_minlen=1, fast_small_mult=1, cg_variant=1)
+    def runs():
+        a = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 140, 13, 11, 0.9, 1.5, 20.0, 0.003, 1, steady=True, source_type="constant", source_value=2.0, rtol=1e-12)
+        b = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 30, 17, 12, 0.9, 1.5, 20.0, 0.003, 3, rtol=1e-12)
+        c = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 30, 17, 12, 0.9, 0.0, 20.0, 0.003, 2, rtol=1e-12, T_left=4.0, T_right=None, T_side=None)
+        return a, b, c
+    base = runs()
+    try:
+        for k, v in setting.items():
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+        alt = runs()
+    finally:
+        for k in setting:
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), defaults[k]))
+    for x, y in zip(alt, base):
+        assert rel_err(x.values, y.values) < TOL
