@@ -129,7 +129,9 @@ const char* pdegpu_version(void);
  * z-marching block stencil), "el_fast_ry" (1|2 rows per column), "el_fast_waves" (wavefront target of the marching part),
  * "el_fast_yx" (1 = y-halo rows handed between the workgroup's waves through LDS), "hybrid_bc" (1 = 3-D grids with natural faces: marching kernel on the interior + class-table
  * kernel on the boundary nodes), "extrapolate" (1 = transient solves start CG from 2 u^n - u^{n-1}), "fast_minlen" /
- * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2".
+ * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2",
+ * "plane2d" / "plane2d_ry" (2-D grids: CG kernels as one-round tiles), "tile3d_max_nodes" (3-D grids up to this many nodes:
+ * CG kernels as one-round tiles; 0 = always march).
  * Results do not depend on them beyond the solver tolerance. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 

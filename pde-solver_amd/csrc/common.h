@@ -36,6 +36,7 @@ struct pdegpu_ctx {
     int el_fast_yx = 1;         // k_el_fast: 1 = the 4 waves of a workgroup are y-neighbours and hand their y-halo rows through LDS
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
+    int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never
     int plane2d_ry = 4;         // rows per wavefront tile of k_plane2d (2 | 4 | 8)
     int plane2d = 1;            // 2-D grids: 1 = the two CG kernels load their tile in one round (k_plane2d); 0 = flat view of the marching kernels
     int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary
@@ -225,6 +226,8 @@ bool stencil_all_dirichlet(const GridDev& g);
 GridDev stencil_flat2d_view(const GridDev& g);
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 int stencil_max_partials(pdegpu_ctx* ctx);
+int stencil_tile3d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);     // small 3-D grids: CG_K1 / CG_K2 as one-round tiles
+long long stencil_tile3d_grid(const GridDev& g);
 int stencil_plane2d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);   // 2-D: CG_K1 / CG_K2 without marching
 
 int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);

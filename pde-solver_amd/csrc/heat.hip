@@ -23,6 +23,7 @@ struct pdegpu_session {
     HeatTables tabs{};
     double cM = 0, cK = 0;
     bool fast = false;
+    bool tile3d = false;           // small 3-D grid: K1 / K2 through k_tile3d (one load round per tile) instead of marching
     bool plane2d = false;          // 2-D: K1 / K2 through k_plane2d (one load round per tile) instead of the flat view
     bool hybrid = false;           // fast && some boundary node is free: marching kernel (interior) + class-table kernel (boundary nodes)
     int npt = 15;
@@ -211,7 +212,7 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
 
 // the in-launch dot completion (tunable inlaunch_dot) applies to sessions whose dot-producing step is ONE launch; hybrid and
 // 2-D tile sessions append a second launch's partials, so they always use the reduce launch / the prologue sum
-bool use_inlaunch(const pdegpu_session* s) { return s->ctx->inlaunch_dot != 0 && !s->hybrid && !s->plane2d; }
+bool use_inlaunch(const pdegpu_session* s) { return s->ctx->inlaunch_dot != 0 && !s->hybrid && !s->plane2d && !s->tile3d; }
 
 // out = P (rhs - A in), partials of out.out
 int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* out, LaunchInfo* li) {
@@ -271,6 +272,12 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
         plane2d_weights(s->hA, a.w);
         a.dot_which = -1;
         rc = stencil_plane2d(s->ctx, a, APPLY_CG_K1, li);
+    } else if (s->tile3d) {
+        a.g = s->g;
+        fast_weights(s->hA, a.w, false);
+        a.npt = s->npt;
+        a.dot_which = -1;
+        rc = stencil_tile3d(s->ctx, a, APPLY_CG_K1, li);
     } else if (s->fast) {
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
@@ -307,6 +314,13 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
             plane2d_weights(s->hA, a.w);
             a.dot_which = -1;
             return stencil_plane2d(s->ctx, a, APPLY_CG_K2, li);
+        }
+        if (s->tile3d) {
+            a.g = s->g;
+            fast_weights(s->hA, a.w, false);
+            a.npt = s->npt;
+            a.dot_which = -1;
+            return stencil_tile3d(s->ctx, a, APPLY_CG_K2, li);
         }
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
@@ -373,7 +387,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "plane2d_ry", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -400,6 +414,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
     if (!strcmp(key, "hybrid_bc")) return &ctx->hybrid_bc;
     if (!strcmp(key, "plane2d")) return &ctx->plane2d;
+    if (!strcmp(key, "tile3d_max_nodes")) return &ctx->tile3d_max_nodes;
     if (!strcmp(key, "plane2d_ry")) return &ctx->plane2d_ry;
     if (!strcmp(key, "fast_minlen")) return &ctx->fast_minlen;
     if (!strcmp(key, "fast_small_mult")) return &ctx->fast_small_mult;
@@ -499,6 +514,8 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
         }
     }
     s->plane2d = s->fast && s->g.dim == 2 && ctx->plane2d != 0 && plane2d_symmetric(s->hA);
+    s->tile3d = s->fast && !s->hybrid && s->g.dim == 3 && s->g.k0 == 0 && s->g.nkl == s->g.NZ && ctx->tile3d_max_nodes > 0 &&
+                (long long)s->g.NX * s->g.NY * s->g.NZ <= ctx->tile3d_max_nodes && stencil_tile3d_grid(s->g) <= stencil_max_partials(ctx);
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
     for (DevVec* v : vecs)
         if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);

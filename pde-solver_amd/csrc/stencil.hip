@@ -588,6 +588,143 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// small 3-D grids: the two CG kernels without marching
+// ---------------------------------------------------------------------------------------------
+// On a grid whose vectors fit in L2 the marching kernel has nothing to save (every re-read is an L2 hit) and pays for its
+// serial plane steps with memory latency: with chunks of one or two planes a 64^3 K1 is three dependent load rounds.  This
+// form gives a wavefront ONE plane of a 128-node x RY-row tile: the RY + 2 rows of the three planes it needs are requested in a
+// single round, p is formed at every held position and the same 7- / 15- / 27-point formulas are applied.  Uniform Dirichlet
+// boundary, one slab (no ghost planes to maintain); the four waves of a workgroup are stacked in y.
+template <int NPT, int RY, int MODE>
+__global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty) {
+    __shared__ double sRed[4];
+    constexpr bool K1 = (MODE == APPLY_CG_K1);
+    constexpr bool W27 = (NPT == 27), WD = (NPT != 7);        // WD: diagonal neighbours -> every held row of every plane
+    constexpr int RH = RY + 2;
+    const GridDev& g = a.g;
+    double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
+    if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
+    else res_scale = cg_alpha_in(a.di, a.scal, sRed);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nyg = (nty + 3) / 4;
+    const int xt = (int)blockIdx.x % ntx, yt = (((int)blockIdx.x / ntx) % nyg) * 4 + wv;
+    const int lk = 1 + (int)blockIdx.x / (ntx * nyg);         // interior planes 1 .. NZ-2
+    const bool active = yt < nty;
+    const int i0 = xt * 128 + 2 * lane;
+    const int j0 = 1 + yt * RY;
+    const bool lane_ok = active && i0 < g.PX;
+    const bool ma = active && i0 >= 1 && i0 <= g.NX - 2;
+    const bool mb = active && i0 + 1 <= g.NX - 2;
+    const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wz = a.w[3];
+    const double wxy = a.w[4], wxz = a.w[5], wyz = a.w[6], wxyz = a.w[7];
+    const bool el = lane == 0 && active && i0 - 1 >= 1;       // CG vectors vanish on / beyond the Dirichlet columns
+    const bool er = lane == 63 && active && i0 + 2 <= g.NX - 2;
+    const long long eoff = (lane == 0) ? -1 : 2;
+
+    double2 P[RH], C[RH], N[RH], PO[RH];
+    double EP[RH], EC[RH], EN[RH];
+    auto value = [&](long long off, double2* po) {
+        const double2 v = *reinterpret_cast<const double2*>(a.in + off);
+        if (K1) {
+            const double2 o = *reinterpret_cast<const double2*>(a.p_old + off);
+            if (po) *po = o;
+            return make_double2(v.x + beta * o.x, v.y + beta * o.y);
+        }
+        return v;
+    };
+    auto edge = [&](long long off) { return K1 ? a.in[off + eoff] + beta * a.p_old[off + eoff] : a.in[off + eoff]; };
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+        const int j = j0 - 1 + r;
+        const bool own = r >= 1 && r <= RY;
+        P[r] = C[r] = N[r] = PO[r] = make_double2(0.0, 0.0);
+        EP[r] = EC[r] = EN[r] = 0.0;
+        if (j <= g.NY - 1) {
+            const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
+            if (lane_ok) {
+                C[r] = value(off, &PO[r]);
+                if (WD || own) {
+                    P[r] = value(off - g.PP, nullptr);
+                    N[r] = value(off + g.PP, nullptr);
+                }
+            }
+            if (el || er) {
+                if (WD || own) EC[r] = edge(off);
+                if (WD) {
+                    EP[r] = edge(off - g.PP);
+                    EN[r] = edge(off + g.PP);
+                }
+            }
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 1; c <= RY; ++c) {
+        const int j = j0 - 1 + c;
+        if (j <= g.NY - 2) {                                  // wave-uniform
+            const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
+            double qa, qb;
+            if (W27) {
+                const double2 Sy = make_double2(C[c - 1].x + C[c + 1].x, C[c - 1].y + C[c + 1].y);
+                const double2 Sz = make_double2(P[c].x + N[c].x, P[c].y + N[c].y);
+                const double2 Syz = make_double2((P[c - 1].x + P[c + 1].x) + (N[c - 1].x + N[c + 1].x),
+                                                 (P[c - 1].y + P[c + 1].y) + (N[c - 1].y + N[c + 1].y));
+                const double2 T = make_double2(wx * C[c].x + wxy * Sy.x + wxz * Sz.x + wxyz * Syz.x,
+                                               wx * C[c].y + wxy * Sy.y + wxz * Sz.y + wxyz * Syz.y);
+                const double Te = wx * EC[c] + wxy * (EC[c - 1] + EC[c + 1]) + wxz * (EP[c] + EN[c]) +
+                                  wxyz * ((EP[c - 1] + EP[c + 1]) + (EN[c - 1] + EN[c + 1]));
+                double lT = dpp_from_lower(T.y), rT = dpp_from_upper(T.x);
+                lT = (lane == 0) ? Te : lT;
+                rT = (lane == 63) ? Te : rT;
+                qa = w0 * C[c].x + wy * Sy.x + wz * Sz.x + wyz * Syz.x + lT + T.y;
+                qb = w0 * C[c].y + wy * Sy.y + wz * Sz.y + wyz * Syz.y + T.x + rT;
+            } else if (WD) {
+                const double2 U = make_double2(wx * C[c].x + wxy * C[c + 1].x + wxz * N[c].x + wxyz * N[c + 1].x,
+                                               wx * C[c].y + wxy * C[c + 1].y + wxz * N[c].y + wxyz * N[c + 1].y);
+                const double2 Lw = make_double2(wx * C[c].x + wxy * C[c - 1].x + wxz * P[c].x + wxyz * P[c - 1].x,
+                                                wx * C[c].y + wxy * C[c - 1].y + wxz * P[c].y + wxyz * P[c - 1].y);
+                const double Ue = wx * EC[c] + wxy * EC[c + 1] + wxz * EN[c] + wxyz * EN[c + 1];
+                const double Le = wx * EC[c] + wxy * EC[c - 1] + wxz * EP[c] + wxyz * EP[c - 1];
+                double lL = dpp_from_lower(Lw.y), rU = dpp_from_upper(U.x);
+                lL = (lane == 0) ? Le : lL;
+                rU = (lane == 63) ? Ue : rU;
+                qa = w0 * C[c].x + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x) + wyz * (N[c + 1].x + P[c - 1].x) + U.y + lL;
+                qb = w0 * C[c].y + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y) + wyz * (N[c + 1].y + P[c - 1].y) + rU + Lw.x;
+            } else {
+                double lC = dpp_from_lower(C[c].y), rC = dpp_from_upper(C[c].x);
+                lC = (lane == 0) ? EC[c] : lC;
+                rC = (lane == 63) ? EC[c] : rC;
+                qa = w0 * C[c].x + wx * (lC + C[c].y) + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x);
+                qb = w0 * C[c].y + wx * (C[c].x + rC) + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y);
+            }
+            if (K1) {
+                if (lane_ok) {
+                    *reinterpret_cast<double2*>(a.p_new + off) = C[c];
+                    if (alpha_prev != 0.0) {
+                        double2 xv = *reinterpret_cast<double2*>(a.x + off);
+                        xv.x += alpha_prev * PO[c].x;
+                        xv.y += alpha_prev * PO[c].y;
+                        *reinterpret_cast<double2*>(a.x + off) = xv;
+                    }
+                }
+                const double2 o = make_double2(ma ? qa : 0.0, mb ? qb : 0.0);
+                acc += C[c].x * o.x + C[c].y * o.y;
+                if (lane_ok && a.out) *reinterpret_cast<double2*>(a.out + off) = o;
+            } else {
+                double2 rv = make_double2(0.0, 0.0);
+                if (lane_ok) rv = *reinterpret_cast<const double2*>(a.rhs + off);
+                const double2 o = make_double2(ma ? rv.x - res_scale * qa : 0.0, mb ? rv.y - res_scale * qb : 0.0);
+                acc += o.x * o.x + o.y * o.y;
+                if (lane_ok) *reinterpret_cast<double2*>(a.out + off) = o;
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+}
+
 FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
     FastGeom fg{};
     fg.ntx = (g.NX - 1 + 127) / 128;
@@ -690,6 +827,32 @@ int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* 
 }
 
 }  // namespace
+
+// small 3-D grids: CG_K1 / CG_K2 as one-round tiles (k_tile3d); a.g is the full single-slab grid with uniform Dirichlet boundary
+template <int NPT>
+static int launch_tile3d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    constexpr int RY = 2;
+    const int ntx = (a.g.NX - 1 + 127) / 128;
+    const int nty = (a.g.NY - 2 + RY - 1) / RY;
+    const long long G = (long long)ntx * ((nty + 3) / 4) * (a.g.NZ - 2);
+    if (li) { li->grid = (int)G; li->block = 256; }
+    if (G <= 0) return PDEGPU_OK;
+    if (mode == APPLY_CG_K1) hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K1>), dim3((unsigned)G), dim3(256), 0, ctx->stream, a, ntx, nty);
+    else hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K2>), dim3((unsigned)G), dim3(256), 0, ctx->stream, a, ntx, nty);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+int stencil_tile3d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    if (a.npt == 27) return launch_tile3d<27>(ctx, a, mode, li);
+    if (a.npt == 7) return launch_tile3d<7>(ctx, a, mode, li);
+    return launch_tile3d<15>(ctx, a, mode, li);
+}
+// workgroups (= partials) the tile form would launch: the session uses it only when they fit the partial buffer
+long long stencil_tile3d_grid(const GridDev& g) {
+    const int ntx = (g.NX - 1 + 127) / 128, nty = (g.NY - 2 + 1) / 2;
+    return (long long)ntx * ((nty + 3) / 4) * (g.NZ - 2);
+}
+
 
 // the two CG kernels of a 2-D grid without marching (k_plane2d); a.g is the 2-D grid itself, a.w = {w0, wx, wy, wd1, wd2}
 template <int RY>

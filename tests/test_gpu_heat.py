@@ -13,6 +13,19 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 
 
+@pytest.fixture(params=["tile", "march"])
+def cg_kernel_form(request, lib, gpu_ctx):
+    """small grids run their two CG kernels as one-round tiles (k_tile3d / k_plane2d) by default; "march" switches both off so
+    that the z-marching K1 / K2 (the kernels of the large grids) are exercised on the same small problems"""
+    from pdegpu import _lib
+    if request.param == "march":
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 0))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"plane2d", 0))
+    yield request.param
+    _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 3000000))
+    _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"plane2d", 1))
+
+
 def rel_err(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
 
@@ -132,7 +145,7 @@ def test_heat_1d_direct_tridiagonal_path(lib, gpu_ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("steady", [False, True])
-def test_heat_2d_matches_oracle(lib, gpu_ctx, steady):
+def test_heat_2d_matches_oracle(lib, gpu_ctx, steady, cg_kernel_form):
     from pdegpu import heat
     kw = dict(Lx=1.0, Ly=0.5, nx=24, ny=17, diffusivity=0.8, T_boundary=3.0, T_initial=20.0, dt=0.004, num_steps=4,
               steady=steady, source_type="constant", source_value=5.0)
@@ -146,7 +159,7 @@ def test_heat_2d_matches_oracle(lib, gpu_ctx, steady):
 
 @pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("steady", [False, True])
-def test_heat_3d_uniform_bc_matches_oracle(lib, gpu_ctx, fast, steady):
+def test_heat_3d_uniform_bc_matches_oracle(lib, gpu_ctx, fast, steady, cg_kernel_form):
     from pdegpu import heat
     kw = dict(Lx=1.0, Ly=0.8, Lz=0.5, nx=14, ny=11, nz=9, diffusivity=1.2, T_boundary=2.0, T_initial=20.0, dt=0.003,
               num_steps=3, steady=steady, source_type="constant", source_value=4.0)
@@ -159,7 +172,7 @@ def test_heat_3d_uniform_bc_matches_oracle(lib, gpu_ctx, fast, steady):
         assert got.meta[k] == ref.meta[k]
 
 
-def test_heat_3d_wide_grid_fast_path(lib, gpu_ctx):
+def test_heat_3d_wide_grid_fast_path(lib, gpu_ctx, cg_kernel_form):
     """several 128-node x-tiles and a ragged last tile; two z-chunks"""
     from pdegpu import heat
     kw = dict(Lx=2.0, Ly=0.3, Lz=0.4, nx=150, ny=6, nz=20, diffusivity=1.0, T_boundary=0.0, T_initial=20.0, dt=0.002,
@@ -485,7 +498,7 @@ def test_heat_2d_uses_the_fused_kernels(lib, gpu_ctx):
 
 
 @pytest.mark.parametrize("case", ["3d_fast", "3d_fast_72B", "3d_general", "2d_fast", "3d_transient_15pt"])
-def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, case):
+def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, case, cg_kernel_form):
     """default CG loop (the next kernel's prologue sums the previous launch's partials, no reduce launches) vs
     lazy_dot=0 (k_reduce after every dot-producing kernel): same summation order, so identical iterates bit for bit"""
     from pdegpu import heat, _lib
@@ -510,7 +523,7 @@ def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, case):
 
 
 @pytest.mark.parametrize("case", ["3d_transient", "3d_steady", "3d_natural_faces", "2d_transient", "3d_wide"])
-def test_q1_27_point_marching_kernel_matches_class_table_kernel(lib, gpu_ctx, case):
+def test_q1_27_point_marching_kernel_matches_class_table_kernel(lib, gpu_ctx, case, cg_kernel_form):
     """Q1 element mode: the 27-point (2-D: 9-point) form of the marching kernel — two x-shifts per node, weights by
     |dx|,|dy|,|dz| — against the class-table kernel on anisotropic cells; and the bare operator against the host tables"""
     from pdegpu import heat, _lib
@@ -560,7 +573,7 @@ def test_2d_tile_kernel_and_flat_view_agree(lib, gpu_ctx, steady, em):
 
 @pytest.mark.parametrize("knob", ["use_graph", "inlaunch_dot"])
 @pytest.mark.parametrize("case", ["3d_fast", "3d_general", "2d", "3d_natural_faces", "weighted_2d_cylindrical", "3d_steady_64B"])
-def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, case):
+def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, case, cg_kernel_form):
     """the two measured-slower variants kept as tunables — CG chunks replayed from a captured hipGraph, dot products finished
     inside the producing launch by the last workgroup — produce bitwise the default results (all of them sum the partials in
     the same order)"""
@@ -591,7 +604,7 @@ def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, ca
                                      dict(fast_wg_per_cu=2), dict(fast_wg_per_cu_k2=3), dict(grid_mult=2), dict(k2_grid_mult=8),
                                      dict(extrapolate=0), dict(hybrid_bc=0), dict(fast_minlen=4), dict(fast_small_mult=4),
                                      dict(cg_variant=0), dict(cg_variant=0, fast_ex=0, fast_ry=4)])
-def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting):
+def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kernel_form):
     """'results do not depend on the tunables' (include/pdegpu.h): each one, away from its default, on a 3-D steady (7-point,
     64-B variant), a 3-D transient (15-point) and a natural-face problem, against the default run"""
     from pdegpu import heat, _lib
