@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the hot path (BASELINE.json): matrix-free CG on the 3-D heat system,
-512 x 512 x 512 cells per GPU, fp64, on N GPUs of one node (one process per GPU, slabs along z, RCCL halo
-exchange + dot-product all-reduce).
+"""bench.py — headline benchmark of the hot path (BASELINE.json): matrix-free CG on the 3-D heat system, fp64, on N GPUs of
+one node (one process per GPU, slabs along the slowest axis, RCCL halo exchange + dot-product all-reduce).
 
-A "step" is ONE CG iteration (fused K1: x-update + p-update + 7-point SpMV + p.q; K2: r-update + r.r) of the
-steady system  kappa K u = f m  with f = 1, T_boundary = 0 on synthetic data of that
-shape.  value = free unknowns x K / wall time of the K timed iterations (max over ranks).
+A "step" is ONE CG iteration (fused K1: x-update + p-update + 7-point SpMV + p.q; K2: r-update + r.r) of the steady system
+kappa K u = f m with f = 1, T_boundary = 0 on synthetic data.  value = free unknowns x K / wall time of the K timed iterations
+(max over ranks).  Every N — N = 1 included — is driven by the SAME loop: pdegpu.dist.SlabCG stepping the HIP session
+(exchange posted -> K1 on the planes away from the ghosts -> exchange done -> K1 edge planes -> all-reduce -> K2 -> all-reduce).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  At N = 1 it carries `roofline` (dominant kernel timed live with HIP events on the
-library's stream) and `cpu_baseline` (the oracle's C/OpenMP port of the same CG timed on this host's cores on a
-bounded sample)."""
+Workloads (--workload / --scaling):
+    config3 weak   (default) BASELINE configs[2] per GPU: 512 x 512 x (512 N) cells, 512 planes of cells per rank
+    config3 strong           the 512^3 grid itself split over N slabs
+    config4                  BASELINE configs[3]: 1024 x 512 x 512 cells over N slabs cut across the 1024-cell axis (strong by nature)
+Unless --no-extras, the line also carries `extras`: the other two workloads measured right after the main one in the same
+process group (north_star asks for DoF/s at 1/2/4/8 GPUs on the 512^3 solve and names the config-4 grid).
+
+Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel (K1) timed live with HIP events on the library's stream INSIDE the
+timed region (rank 0's slab); at N = 1 the line also carries the in-run streaming ceilings, the bare SpMV, the native single-GPU
+loop and `cpu_baseline` (the oracle's C/OpenMP port of the same CG, plus one step of the reference's own algorithm —
+assemble + sparse LU — on a small grid, both on this host's cores)."""
 from __future__ import annotations
 
 import argparse
@@ -21,6 +29,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -30,6 +39,8 @@ for p in (ROOT, ROOT / "pde-solver_amd"):
         sys.path.insert(0, str(p))
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+os.environ.setdefault("OMP_PROC_BIND", "close")               # CPU baseline: threads stay where their pages were first touched
+os.environ.setdefault("OMP_PLACES", "cores")                  # (must be set before the first OpenMP runtime loads, i.e. before torch)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -37,11 +48,32 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(n_cells: int, budget_s: float = 20.0):
+def effective_cpus() -> int:
+    """host cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when one is set (a GPU box
+    gives one GPU's share of the host, and 128 OpenMP threads on a 16-CPU quota only measure the throttling)"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(n_cells: int, budget_s: float = 12.0):
     """same-algorithm CPU baseline: oracle/cg_port.c (classic matrix-free CG, OpenMP) on this host's cores.
     Bounded sample: the same n^3 grid, as many iterations as fit in ~budget_s (at least 3)."""
     from oracle import cg_port
-    threads = min(cg_port.max_threads(), len(os.sched_getaffinity(0)))
+    threads = max(1, min(cg_port.max_threads(), effective_cpus()))
     nodes = n_cells + 1
     h = 1.0 / n_cells
     w = cg_port.p1_weights((h, h, h), 0.0, 1.0)
@@ -50,11 +82,165 @@ def cpu_baseline(n_cells: int, budget_s: float = 20.0):
     per_iter = max(secs / 2, 1e-6)
     iters = int(max(3, min(200, budget_s / per_iter)))
     secs, rr, _ = cg_port.run((nodes,) * 3, w, h ** 3, 0.0, iters, threads)
+    # classic unfused CG: apply (read p, write q) + p.q (read p, q) + x, r updates (read x, p, r, q; write x, r) + r.r (read r)
+    # + p update (read r, p; write p) = 14 vector passes of 8 B = 112 B per unknown and iteration
     return {"value": unknowns * iters / secs, "unit": "DoF/s", "cores": threads, "kind": "port",
             "sample": f"{iters} CG iterations of the same {n_cells}^3 steady heat system (oracle/cg_port.c, "
                       f"classic unfused CG, OpenMP static, {threads} threads); the reference's own algorithm "
-                      f"(sparse LU per step, FEniCS 2019.1.0) is not installable offline",
-            "ms_per_step": secs / iters * 1e3}
+                      f"(sparse LU per step, FEniCS 2019.1.0) is not installable offline: see reference_algorithm",
+            "ms_per_step": secs / iters * 1e3, "achieved_GBps": 112.0 * nodes ** 3 * iters / secs / 1e9,
+            "bytes_per_dof_model": 112}
+
+
+def reference_algorithm_baseline(n: int = 32):
+    """B1: ONE backward-Euler step of the reference's own algorithm (fenics_mcp_server.py:702-716 — assemble + sparse LU
+    factorisation + solve every step) through the oracle's restatement (vectorised P1 assembly + scipy splu) on this host."""
+    import numpy as np
+    from oracle import fem_p1 as o
+    t0 = time.perf_counter()
+    ts = o.solve_heat_3d(1.0, 1.0, 1.0, n, n, n, 1.0, 0.0, 20.0, 0.0025, 1)
+    secs = time.perf_counter() - t0
+    unknowns = (n - 1) ** 3
+    assert np.isfinite(ts.values).all()
+    return {"value": unknowns / secs, "unit": "DoF/s per step", "cores": 1, "kind": "port",
+            "sample": f"one backward-Euler step at {n}^3 cells ({unknowns} unknowns): assemble + scipy.sparse.linalg.splu + solve "
+                      f"(oracle/fem_p1.py, SuperLU/COLAMD, one thread); time grows ~N^2.3 and the LU fill ~N^1.6, so the reference's "
+                      f"algorithm cannot run the 512^3 workload at all (profiles/r01_b1_reference_algorithm.json)",
+            "seconds_per_step": secs}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def make_case(workload: str, scaling: str, n: int, world: int):
+    """global cell counts (x, y, z) with z the slab axis, box lengths, label"""
+    if workload == "config4":
+        cells, Ls = (n, n, 2 * n), (1.0, 1.0, 2.0)          # 1024 x 512 x 512 relabelled so that the slabs cut the 1024-cell axis
+        label = (f"3D heat {2 * n}x{n}x{n} cells (BASELINE configs[3]) over {world} slab(s) across the {2 * n}-cell axis "
+                 f"(axes relabelled: halo planes are {n + 1}x{n + 1} nodes), steady kappa*K u = f*m, one CG iteration per step")
+        return dict(cells=cells, L=Ls, label=label, scaling="strong", workload="config4")
+    if scaling == "strong":
+        cells, Ls = (n, n, n), (1.0, 1.0, 1.0)
+        label = (f"3D heat {n}x{n}x{n} cells in total (BASELINE configs[2]: 512^3 P1 grid) split over {world} slab(s), steady "
+                 f"kappa*K u = f*m, f=1, T_boundary=0, one CG iteration per step")
+        return dict(cells=cells, L=Ls, label=label, scaling="strong", workload="config3")
+    cells, Ls = (n, n, n * world), (1.0, 1.0, float(world))
+    label = (f"3D heat {n}x{n}x{n} cells per GPU (BASELINE configs[2]: 512^3 P1 grid, steady kappa*K u = f*m, f=1, "
+             f"T_boundary=0), one CG iteration per step")
+    return dict(cells=cells, L=Ls, label=label, scaling="weak", workload="config3")
+
+
+class Runner:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from pdegpu import _lib as L
+        self.torch, self.dist, self.L, self.args = torch, dist, L, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        # PDEGPU_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, planes
+        # are staged through the host by pdegpu.dist); the measured configuration is always nccl = RCCL, one rank per GPU
+        self.backend = os.environ.get("PDEGPU_BENCH_BACKEND", "nccl")
+        if self.backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device(f"cuda:{local_rank}"))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.stream = torch.cuda.Stream(device=local_rank)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def run_case(self, case, steps, warmup, extras_n1=False):
+        """one workload through SlabCG: returns the timing dict (every rank), rank 0's kernel stats included"""
+        torch, dist, L = self.torch, self.dist, self.L
+        from pdegpu.dist import GpuSlabEngine, SlabCG, slab_range
+        world, rank = self.world, self.rank
+        nx, ny, nz = case["cells"]
+        k0, nk = slab_range(nz + 1, world, rank)
+        grid = L.make_grid(3, (nx, ny, nz), case["L"])
+        heat = L.Heat()
+        heat.kappa, heat.dt, heat.steady, heat.source = 1.0, 0.0, 1, 1.0
+        heat.bc_mode, heat.fast_path = L.BC_UNIFORM, 0 if self.args.general else 1
+        heat.bc_present[0] = 1
+        unknowns = (nx - 1) * (ny - 1) * (nz - 1)
+        res = {"unknowns": unknowns, "cells": [nx, ny, nz], "planes_rank0": nk}
+        with torch.cuda.stream(self.stream):
+            eng = GpuSlabEngine(grid, heat, k0, nk, self.local_rank, self.stream)
+            cg = SlabCG(eng, rank, world, overlap=not self.args.no_overlap)
+            if extras_n1:
+                # in-run streaming ceilings and the bare SpMV are measured FIRST (they use r, q, b as scratch, so they must precede
+                # the CG set-up; they also bring the device to its sustained clocks before the warm-up steps)
+                vec_bytes = eng.plane * nk * 8
+                ceil = {}
+                for which, name, nvec in ((1, "read_1R", 1), (2, "write_1W", 1), (0, "copy_1R1W", 2), (3, "triad_2R1W", 3)):
+                    mb = C.c_double()
+                    L.check(eng.ctx, eng.lib.pdegpu_session_membench(eng.s, which, 20, C.byref(mb)))
+                    ceil[name] = nvec * vec_bytes / (mb.value * 1e-3) / 1e9
+                ms = C.c_double()
+                L.check(eng.ctx, eng.lib.pdegpu_session_time_apply(eng.s, 50, C.byref(ms)))
+                res["ceilings"], res["spmv_ms"] = ceil, ms.value
+            cg.start(0.0)
+            cg.iterate(warmup)
+            self.fence()
+            eng.set_timing(True)
+            t0 = time.perf_counter()
+            cg.iterate(steps)
+            self.fence()
+            elapsed = time.perf_counter() - t0
+            stats = L.Stats()
+            eng.get_stats(stats)
+            eng.set_timing(False)
+            res["rr_after"] = eng.rr()
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            res["elapsed"] = elapsed
+            res["k1_ms"] = stats.kernel_ms[0] / max(1, stats.kernel_launches[0])
+            res["k2_ms"] = stats.kernel_ms[1] / max(1, stats.kernel_launches[1])
+            nodes_local = (nx + 1) * (ny + 1) * nk
+            res["k1_per_dof"] = round(stats.alg_bytes[0] / max(1, stats.kernel_launches[0]) / nodes_local)      # 40 or 48
+            res["unknowns_rank0"] = (nx - 1) * (ny - 1) * max(0, min(k0 + nk, nz) - max(k0, 1))
+            res["split_k1"] = bool(eng.can_split_k1()) and not self.args.no_overlap
+            if extras_n1:
+                # the native single-GPU loop of the product's one-shot solves (pdegpu_session_iterate: no reduce launches, C loop)
+                eng.iterate_native(warmup, False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.iterate_native(steps, False)
+                torch.cuda.synchronize()
+                res["native_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+            eng.close()
+        return res
+
+
+def roofline_of(res, general):
+    """K1 (the SpMV-bearing fused kernel) and K2 of rank 0's slab, algorithmic bytes over the HIP-event time of the timed region"""
+    unk = res["unknowns_rank0"]
+    k1_bytes, k2_bytes = float(res["k1_per_dof"]) * unk, 24.0 * unk
+    ach = k1_bytes / (res["k1_ms"] * 1e-3) / 1e9 if res["k1_ms"] > 0 else 0.0
+    k2a = k2_bytes / (res["k2_ms"] * 1e-3) / 1e9 if res["k2_ms"] > 0 else 0.0
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "kernel": ("k_fast<7,2,CG_K1,nt,ex> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)" if not general else "k_general<CG_K1>") +
+                      (" — rank 0's slab; a split K1 counts its parts together" if res.get("split_k1") else ""),
+            "alg_bytes_per_launch": k1_bytes, "avg_ms": res["k1_ms"],
+            "other_kernels": [{"kernel": "k_fast<7,2,CG_K2,nt,ex> (r-=a*(A p); r.r)" if res["k1_per_dof"] == 40 else "k_k2 (r-=a*q; r.r)",
+                               "alg_bytes_per_launch": k2_bytes, "avg_ms": res["k2_ms"], "achieved": k2a, "frac": k2a / HBM_PEAK_GBS}],
+            "cg_iteration_alg_bytes_per_dof": res["k1_per_dof"] + 24}
 
 
 def main():
@@ -62,153 +248,106 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cells", type=int, default=512, help="cells per axis per GPU (BASELINE config 3: 512)")
+    ap.add_argument("--cells", type=int, default=512, help="cells per axis (BASELINE config 3: 512; config 4 uses 2*cells on the long axis)")
+    ap.add_argument("--workload", choices=("config3", "config4"), default="config3")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="config3 only: per-GPU grid fixed (weak) or total grid fixed (strong)")
+    ap.add_argument("--no-extras", action="store_true", help="do not measure the other workloads after the main one")
+    ap.add_argument("--extras-timeout", type=float, default=240.0, help="seconds the extra legs may take before the main line is printed without them")
+    ap.add_argument("--no-overlap", action="store_true", help="exchange halos before K1 instead of overlapping them with its bulk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general", action="store_true", help="force the class-table kernels (diagnostic)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from pdegpu import _lib as L
-    from pdegpu.dist import GpuSlabEngine, SlabCG, slab_range
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # PDEGPU_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, planes are
-    # staged through the host by pdegpu.dist); the measured configuration is always nccl = RCCL, one rank per GPU
-    backend = os.environ.get("PDEGPU_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    R = Runner(args)
+    world, rank, n = R.world, R.rank, args.cells
+    case = make_case(args.workload, args.scaling, n, world)
+    res = R.run_case(case, args.steps, args.warmup, extras_n1=(world == 1))
+    ms_per_step = res["elapsed"] / args.steps * 1e3
+    rehearsal = "" if R.backend == "nccl" else f" (REHEARSAL over {R.backend}, shared GPU: not a measurement)"
+    out = {
+        "metric": "CG DoF/s (3D heat, matrix-free CG)", "value": res["unknowns"] * args.steps / res["elapsed"], "unit": "DoF/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": case["scaling"] if world > 1 else "n/a", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": case["label"], "global_cells": res["cells"], "unknowns": res["unknowns"], "element_mode": "p1split",
+                   "parallelism": (f"z-slabs x{world}" + rehearsal) if world > 1 else "single GPU",
+                   "driver": "pdegpu.dist.SlabCG over the stepwise C-ABI session (the same loop at every N)" +
+                             ("; K1 split: bulk overlaps the halo exchange" if res["split_k1"] else ""),
+                   "kernel_path": "general" if args.general else "fused z-marching", "rr_after": res["rr_after"]},
+    }
+    rl = roofline_of(res, args.general)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        per_gpu = float(res["k1_per_dof"] + 24) * res["unknowns"] / world / (res["elapsed"] / args.steps) / 1e9
+        rl["whole_iteration_per_gpu"] = {"achieved": per_gpu, "frac": per_gpu / HBM_PEAK_GBS,
+                                         "note": "K1 + K2 algorithmic bytes per GPU over the whole iteration incl. halo exchange and the two 8-byte all-reduces"}
+    else:
+        pmc = ROOT / "profiles" / "pmc_latest.json"
+        if pmc.exists():
+            try:
+                j = json.loads(pmc.read_text())
+                rl["traffic"] = j.get("k1_hbm_bytes_per_launch")
+                rl["traffic_source"] = (f"profiles/pmc_latest.json ({j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')}, "
+                                        f"collected at {j.get('commit', 'an earlier commit')}): a committed counter value, NOT taken in this run")
+            except Exception:
+                pass
+        rl["in_run_ceiling_GBps"] = res["ceilings"]
+        sp = res["spmv_ms"]
+        rl["spmv_only"] = {"kernel": "bare matrix-free SpMV q = A p (16 B/DoF)", "avg_ms": sp,
+                           "achieved": 16.0 * res["unknowns"] / (sp * 1e-3) / 1e9, "frac": 16.0 * res["unknowns"] / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        out["native_loop"] = {"ms_per_step": res["native_ms_per_step"], "value": res["unknowns"] / (res["native_ms_per_step"] * 1e-3),
+                              "note": "pdegpu_session_iterate: the C loop of the one-shot solves (dot products summed in the next kernel's prologue, "
+                                      "no reduce launches) — the same kernels without the stepwise driver"}
+    out["roofline"] = rl
 
-    n = args.cells
-    # weak scaling: every GPU owns a 512-cell-thick slab; the global grid is n x n x (n*N) cells
-    nz_global = n * world
-    planes = nz_global + 1
-    k0, nk = slab_range(planes, world, rank)
-    grid = L.make_grid(3, (n, n, nz_global), (1.0, 1.0, float(world)))
-    heat = L.Heat()
-    heat.kappa, heat.dt, heat.steady, heat.source = 1.0, 0.0, 1, 1.0
-    heat.bc_mode, heat.fast_path = L.BC_UNIFORM, 0 if args.general else 1
-    heat.bc_present[0] = 1
-    unknowns = (n - 1) * (n - 1) * (nz_global - 1)
+    # ---- the other workloads, same process group, after the main measurement ----------------------------------------
+    printed = threading.Event()
 
-    stream = torch.cuda.Stream(device=local_rank)
-    with torch.cuda.stream(stream):
-        eng = GpuSlabEngine(grid, heat, k0, nk, local_rank, stream)
-        cg = SlabCG(eng, rank, world)
-        # in-run streaming ceilings and the bare SpMV are measured FIRST (they use r, q, b as scratch, so they must precede the
-        # CG set-up; they also bring the device to its sustained clocks before the warm-up steps)
-        ceil, spmv_ms = {}, None
-        if world == 1:
-            vec_bytes = eng.plane * nk * 8
-            for which, name, nvec in ((1, "read_1R", 1), (2, "write_1W", 1), (0, "copy_1R1W", 2), (3, "triad_2R1W", 3)):
-                mb = C.c_double()
-                L.check(eng.ctx, eng.lib.pdegpu_session_membench(eng.s, which, 20, C.byref(mb)))
-                ceil[name] = nvec * vec_bytes / (mb.value * 1e-3) / 1e9
-            ms = C.c_double()
-            L.check(eng.ctx, eng.lib.pdegpu_session_time_apply(eng.s, 50, C.byref(ms)))
-            spmv_ms = ms.value
-        cg.start(0.0)
-        stats = L.Stats()
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(out), flush=True)
 
-        def run(iters, timed):
-            if world == 1:
-                eng.iterate_native(iters, timed, stats if timed else None)
-            else:
-                cg.iterate(iters)
-
-        def fence():
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-                torch.cuda.synchronize()
-
-        run(args.warmup, False)
-        fence()
-        t0 = time.perf_counter()
-        run(args.steps, True)
-        fence()
-        elapsed = time.perf_counter() - t0
-        rr = eng.rr()
-
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-
-        out = {
-            "metric": "CG DoF/s (3D heat, matrix-free CG)", "value": unknowns * args.steps / elapsed, "unit": "DoF/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3D heat {n}x{n}x{n} cells per GPU (BASELINE configs[2]: 512^3 P1 grid, steady "
-                                   f"kappa*K u = f*m, f=1, T_boundary=0), one CG iteration per step",
-                       "global_cells": [n, n, nz_global], "unknowns": unknowns, "element_mode": "p1split",
-                       "parallelism": (f"z-slabs x{world}" + ("" if backend == "nccl" else f" (REHEARSAL over {backend}, shared GPU: not a measurement)")) if world > 1 else "single GPU",
-                       "kernel_path": "general" if args.general else "fused z-marching",
-                       "rr_after": rr},
-        }
-
-        if world > 1:
-            # per-GPU view of the whole iteration (kernels + halo exchange + two all-reduces); the per-kernel roofline is the N=1 line's
-            per_gpu = 64.0 * unknowns / world / (elapsed / args.steps) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBS,
-                               "traffic": None, "kernel": "whole CG iteration per GPU: K1 + K2 (64 B/DoF algorithmic) + r-plane halo exchange + "
-                                                          "two 8-byte all-reduces; kernel-level figures are in the n_gpus=1 line"}
-        if world == 1:
-            # ---- roofline of the dominant kernel (K1 = the SpMV-bearing fused kernel), HIP events ----------
-            k1_ms = stats.kernel_ms[0] / max(1, stats.kernel_launches[0])
-            k2_ms = stats.kernel_ms[1] / max(1, stats.kernel_launches[1])
-            # K1 reads r, p, x and writes p, x (+ q in the 72-B variant); K2 reads r and p (or q), writes r
-            nodes_local = (n + 1) * (n + 1) * nk
-            k1_per_dof = round(stats.alg_bytes[0] / max(1, stats.kernel_launches[0]) / nodes_local)      # 40 or 48
-            k1_bytes = float(k1_per_dof) * unknowns
-            k2_bytes = 24.0 * unknowns
-            ach = k1_bytes / (k1_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = ROOT / "profiles" / "pmc_latest.json"
-            if pmc.exists():
-                try:
-                    traffic = json.loads(pmc.read_text()).get("k1_hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_fast<7,2,CG_K1,nt,ex> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)" if not args.general else "k_general<CG_K1>",
-                               "alg_bytes_per_launch": k1_bytes, "avg_ms": k1_ms,
-                               "other_kernels": [{"kernel": "k_fast<7,2,CG_K2,nt,ex> (r-=a*(A p); r.r)" if k1_per_dof == 40 else "k_k2 (r-=a*q; r.r)", "alg_bytes_per_launch": k2_bytes,
-                                                  "avg_ms": k2_ms, "achieved": k2_bytes / (k2_ms * 1e-3) / 1e9,
-                                                  "frac": k2_bytes / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}],
-                               "cg_iteration_alg_bytes_per_dof": k1_per_dof + 24}
-            out["roofline"]["in_run_ceiling_GBps"] = ceil
-            # SpMV alone (16 B/DoF) for the north-star statement
-            out["roofline"]["spmv_only"] = {"kernel": "k_fast<7,2,PLAIN,nt> (q = A p, 16 B/DoF)", "avg_ms": spmv_ms,
-                                            "achieved": 16.0 * unknowns / (spmv_ms * 1e-3) / 1e9,
-                                            "frac": 16.0 * unknowns / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        eng.close()
+    if not args.no_extras:
+        def bail():
+            # an extra leg is stuck (a collective that never completes would otherwise hold the main line back for ever)
+            out.setdefault("extras", {})["aborted"] = f"extras did not finish within {args.extras_timeout:.0f} s"
+            emit()
+            os._exit(0)
+        wd = threading.Timer(args.extras_timeout, bail)
+        wd.daemon = True
+        wd.start()
+        extras = {}
+        todo = [("config3", "strong"), ("config3", "weak"), ("config4", "strong")]
+        for wl, sc in todo:
+            c2 = make_case(wl, sc, n, world)
+            if c2["workload"] == case["workload"] and c2["scaling"] == case["scaling"]:
+                continue
+            if world == 1 and wl == "config3":
+                continue                                    # weak == strong == the main line on one GPU
+            try:
+                r2 = R.run_case(c2, max(20, args.steps // 2), max(5, args.warmup // 2))
+                st2 = max(20, args.steps // 2)
+                extras[f"{wl}_{c2['scaling']}"] = {
+                    "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
+                    "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
+                    "k1_ms": r2["k1_ms"], "k2_ms": r2["k2_ms"], "planes_rank0": r2["planes_rank0"], "rr_after": r2["rr_after"]}
+            except Exception as e:                          # an extra must never void the main number
+                extras[f"{wl}_{sc}"] = {"failed": repr(e)}
+                break
+        wd.cancel()
+        out["extras"] = extras
 
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(n)
         except Exception as e:                                   # the baseline must never void the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "DoF/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        try:
+            out["cpu_baseline"]["reference_algorithm"] = reference_algorithm_baseline(32)
+        except Exception as e:
+            out["cpu_baseline"]["reference_algorithm"] = {"value": None, "sample": f"failed: {e}"}
+    emit()
     if world > 1:
-        dist.destroy_process_group()
+        R.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

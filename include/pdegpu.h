@@ -119,7 +119,7 @@ const char* pdegpu_last_error(const pdegpu_ctx* ctx);
 int         pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen);
 const char* pdegpu_version(void);
 /* performance tunables of a context (also read from PDEGPU_<KEY> at pdegpu_create): "fast_ry" rows per thread of
- * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_ex" (1 = LDS hand-off of tile-edge values in the CG kernels), "fast_wg_per_cu" (0 = occupancy API),
+ * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_ex" (1 = LDS hand-off of tile-edge values in the CG kernels), "fast_ex_all" (1 = also in the bare apply / residual pass), "fast_pf" (1 = the one-vector marching modes request plane k+2 before computing plane k), "fast_wg_per_cu" (0 = occupancy API),
  * "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
  * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF), "use_graph"
  * (1 = replay the CG inner loop from a captured hipGraph), "inlaunch_dot" (1 = finish dot products inside the producing
@@ -216,6 +216,11 @@ int     pdegpu_el_session_scalars_host(pdegpu_el_session* s, double* out4);   /*
 int64_t pdegpu_el_session_plane_doubles(const pdegpu_el_session* s);
 void*   pdegpu_el_session_plane_ptr(pdegpu_el_session* s, int vec, int comp, int64_t which);
 int     pdegpu_el_session_get_u(pdegpu_el_session* s, double* u_out /* host [nk * plane nodes][3] */);
+/* the halo of one exchange as ONE contiguous message per neighbour: device buffers [r0 r1 r2 p0 p1 p2][plane_doubles] per side
+ * (side 0 = lower neighbour, 1 = upper; which 0 = send, 1 = receive).  halo_pack(s, 0) copies the first / last owned plane of r
+ * and p into the send buffers, halo_pack(s, 1) the receive buffers into the ghost planes (one launch each). */
+void*   pdegpu_el_session_halo_buffer(pdegpu_el_session* s, int which, int side);
+int     pdegpu_el_session_halo_pack(pdegpu_el_session* s, int unpack);
 /* von Mises + project() (:1840-1866) on one GPU from a displacement field gathered on the host, disp [N][dim] */
 int     pdegpu_elasticity_postprocess(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, const double* disp,
                                       double* field_out);
@@ -251,6 +256,24 @@ double* pdegpu_session_scalars(pdegpu_session* s);
 int  pdegpu_session_residual(pdegpu_session* s);            /* r = P(b - A x), rr_local */
 int  pdegpu_session_k1(pdegpu_session* s);                  /* x+=a*p; p=r+beta*p; q=A p; pq_local */
 int  pdegpu_session_k2(pdegpu_session* s);                  /* r-=alpha*q; rr_local */
+/* k1 in two steps, so that the halo exchange overlaps the bulk of it: part 0 = the owned planes whose stencil touches no ghost
+ * plane (call it right after posting the exchange), part 1 = the one or two planes next to the ghosts (after the exchange has
+ * completed) + the sum of all partials -> pq_local.  can_split_k1 = 1 for the fused z-marching kernels; other sessions do
+ * nothing in part 0 and the whole k1 in part 1, so a driver may always call part 0 then part 1. */
+int  pdegpu_session_can_split_k1(const pdegpu_session* s);
+int  pdegpu_session_k1_part(pdegpu_session* s, int part);
+/* kernel timing of the stepwise protocol: set_timing(s, 1) starts a fresh measurement (hipEvent pairs around every k1 / k1_part
+ * / k2 launch on the context stream), get_stats synchronises and ADDS kernel_ms[0] (k1), kernel_ms[1] (k2), launch counts and
+ * algorithmic bytes since then to *stats. */
+int  pdegpu_session_set_timing(pdegpu_session* s, int on);
+int  pdegpu_session_get_stats(pdegpu_session* s, pdegpu_stats* stats);
+/* transient steps on a slab — the time loop of _solve_heat_3d_raw (:702-716) distributed over slabs.  Per step the host
+ * exchanges the ghost planes of x (vector 0) and calls step_rhs (b = M (x + dt f)), lift_norm (r = P (b - A g) with g = the
+ * Dirichlet values; its r.r, the reference norm of the step, lands in the rr slots to be all-reduced and read), reset_cg,
+ * residual, then iterates k1 / k2 as for the steady system and flushes. */
+int  pdegpu_session_step_rhs(pdegpu_session* s);
+int  pdegpu_session_lift_norm(pdegpu_session* s);
+int  pdegpu_session_reset_cg(pdegpu_session* s);
 int  pdegpu_session_reduce_local(pdegpu_session* s, int which /*0 pq, 1 rr*/, int copy_to_global);
 int  pdegpu_session_flush(pdegpu_session* s);               /* pending x += alpha*p */
 /* run `iters` full CG iterations on a single slab without the host in the loop (k1,k2 back to back).

@@ -57,16 +57,18 @@ double cgport_run(int NX, int NY, int NZ, const double* w, int full15, double rh
     double* q = (double*)malloc(n * sizeof(double));
     if (!x || !r || !p || !q) { free(x); free(r); free(p); free(q); return -1.0; }
     const long sz = (long)NX * NY;
-    /* first touch in the same static distribution the sweeps use */
+    /* first touch in the distribution the sweeps use: the vector updates run over the flat index with schedule(static) and the
+     * operator over collapse(2)(k, j) with schedule(static), i.e. both give thread t the t-th contiguous slice of the arrays
+     * (a static loop over the 513 planes alone would hand 5 planes each to 103 of 128 threads and leave the pages of the
+     * other threads' slices on the wrong NUMA node) */
 #pragma omp parallel for schedule(static)
-    for (int k = 0; k < NZ; ++k)
-        for (long e = 0; e < sz; ++e) {
-            const long c = (long)k * sz + e;
-            const int j = (int)(e / NX), i = (int)(e % NX);
-            const int bnd = (i == 0) | (i == NX - 1) | (j == 0) | (j == NY - 1) | (k == 0) | (k == NZ - 1);
-            x[c] = bnd ? bc_value : 0.0;
-            r[c] = p[c] = q[c] = 0.0;
-        }
+    for (long c = 0; c < n; ++c) {
+        const long e = c % sz;
+        const int k = (int)(c / sz), j = (int)(e / NX), i = (int)(e % NX);
+        const int bnd = (i == 0) | (i == NX - 1) | (j == 0) | (j == NY - 1) | (k == 0) | (k == NZ - 1);
+        x[c] = bnd ? bc_value : 0.0;
+        r[c] = p[c] = q[c] = 0.0;
+    }
     /* r = P(b - A x0); Dirichlet rows stay 0 */
     apply(x, q, NX, NY, NZ, w, full15);
 #pragma omp parallel for collapse(2) schedule(static)
@@ -77,7 +79,8 @@ double cgport_run(int NX, int NY, int NZ, const double* w, int full15, double rh
                 r[c] = rhs_const - q[c];
                 p[c] = r[c];
             }
-    memset(q, 0, n * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (long c = 0; c < n; ++c) q[c] = 0.0;
     double rr = dot(r, r, n);
     if (rr_hist) rr_hist[0] = rr;
     const double t0 = now_s();

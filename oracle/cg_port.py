@@ -15,6 +15,11 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
+        # pin the OpenMP threads before libgomp reads its environment: the first-touch placement of cg_port.c only holds while
+        # a thread stays on its core
+        import os
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
         if not SO.exists():
             subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
         _lib = C.CDLL(str(SO))

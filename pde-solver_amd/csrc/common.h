@@ -21,6 +21,12 @@ struct pdegpu_ctx {
                                 // (3 when one slab vector exceeds 64 MiB, i.e. nothing stays cache-resident)
     int fast_ex = 1;            // 1: CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
                                 // instead of 2-lane global loads (measured: 1.65 -> 1.52 ms per 512^3 CG iteration)
+    int fast_ex_all = 0;        // 1: the bare apply / residual pass use the LDS edge hand-off too (default: CG kernels only)
+    int fast_pf = 0;            // 1: bare apply / residual / stencil K2 (7-point) request plane lk+2 before computing plane lk
+    // per-mode overrides of the marching kernels, index = ApplyMode (PLAIN, RESIDUAL, CG_K1, CG_K2); -1 = follow the global tunables.
+    // value = ry + 16 * wg_per_cu + 256 * ex + 512 * pf  (ry in {1, 2, 4, 8}, wg_per_cu 0 = occupancy API)
+    int fast_cfg[4] = {-1, -1, -1, -1};
+    int fast_zlen = 0;          // > 0: planes per z-chunk of the marching kernels (0 = chosen by fast_geom)
     int fast_minlen = 1;        // shortest z-chunk of the marching kernels on grids too small to fill the device
     int fast_small_mult = 1;    // such grids may launch this many resident rounds of workgroups
     int fast_wg_per_cu_k2 = 0;  // the same for the stencil K2 alone (0 = follow fast_wg_per_cu)
@@ -37,6 +43,7 @@ struct pdegpu_ctx {
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
     int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never
+    int tile3d_plain = 1;       // tile sessions: the bare masked apply uses the tile form too
     int plane2d_ry = 4;         // rows per wavefront tile of k_plane2d (2 | 4 | 8)
     int plane2d = 1;            // 2-D grids: 1 = the two CG kernels load their tile in one round (k_plane2d); 0 = flat view of the marching kernels
     int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary
@@ -191,6 +198,8 @@ struct StencilArgs {
     int bnd_ring = 0;         // boundary nodes of such a plane: 2 NX + 2 (NY - 2)
     int bnd_xcover = 0;       // columns [0, bnd_xcover) of interior rows get p / x from the marching kernel (128-node tiles)
     int free_x = 0;           // marching kernel: the x-faces carry unknowns (their CG vectors are not zero: load them)
+    int lk_lo = 0, lk_hi = 0; // marching kernel: restrict the launch to the local planes [lk_lo, lk_hi) (lk_hi > lk_lo; 0, 0 = all).  The
+                              // multi-GPU loop launches K1 on the planes away from the ghosts first (halo exchange in flight)
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
 };
@@ -216,8 +225,9 @@ struct CgGraph {
     }
 };
 inline long long tunable_key(const pdegpu_ctx* c) {
-    return ((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 128 + c->grid_mult) * 128 + c->k2_grid_mult) * 4 +
-            c->cg_variant) * 2 + c->fast_ex;
+    return (((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 128 + c->grid_mult) * 128 + c->k2_grid_mult) * 4 +
+            c->cg_variant) * 8 + c->fast_ex * 4 + c->fast_ex_all * 2 + c->fast_pf) * 1024 + c->fast_zlen +
+           (((long long)c->fast_cfg[0] * 1031 + c->fast_cfg[1]) * 1031 + c->fast_cfg[2]) * 1031 + c->fast_cfg[3];
 }
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);

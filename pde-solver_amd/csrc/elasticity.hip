@@ -809,6 +809,26 @@ __global__ __launch_bounds__(256) void k_el_apply_mfma(GridDev g, long long stri
     }
 }
 
+// halo planes of the slab loop as ONE contiguous message per neighbour: [side][r0 r1 r2 p0 p1 p2][PP].  pack: first / last owned
+// plane -> send buffer; unpack: receive buffer -> ghost planes.  PP is a multiple of 16 doubles, origins are 128-B aligned.
+__global__ __launch_bounds__(256) void k_el_halo(double* __restrict__ r, double* __restrict__ p, long long stride, long long PP, int nkl,
+                                                  int lo, int hi, double* __restrict__ buf, int unpack) {
+    const long long per2 = PP / 2;                       // double2 per plane
+    const long long total = 12 * per2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int slot = (int)(e / per2);                // side * 6 + vector * 3 + component
+        const long long w = e % per2;
+        const int side = slot / 6, vc = slot % 6;
+        if ((side == 0 && !lo) || (side == 1 && !hi)) continue;
+        double* v = (vc < 3 ? r : p) + (long long)(vc % 3) * stride;
+        const long long plane = unpack ? (side == 0 ? -1 : nkl) : (side == 0 ? 0 : nkl - 1);
+        double2* g2 = reinterpret_cast<double2*>(v + plane * PP) + w;
+        double2* b2 = reinterpret_cast<double2*>(buf) + e;
+        if (unpack) *g2 = *b2;
+        else *b2 = *g2;
+    }
+}
+
 inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
     long long nb = (n + 255) / 256;
     const long long cap = 8LL * ctx->num_cu;
@@ -854,6 +874,7 @@ struct ElSession {
     ElFastGeom fgeom{};
     unsigned* d_mask = nullptr;
     int last_apply_blocks = 1;      // workgroups (= partials) of the most recent apply launch
+    double *halo_send = nullptr, *halo_recv = nullptr;      // [2 sides][6 planes][PP] each (slab loop, allocated on first use)
 
     double* alloc_vec() {
         double* base = nullptr;
@@ -872,6 +893,8 @@ struct ElSession {
         if (part2) (void)hipFree(part2);
         if (part3) (void)hipFree(part3);
         if (d_mask) (void)hipFree(d_mask);
+        if (halo_send) (void)hipFree(halo_send);
+        if (halo_recv) (void)hipFree(halo_recv);
         if (h_pin) (void)hipHostFree(h_pin);
         tables_free(&ht);
     }
@@ -1499,6 +1522,36 @@ extern "C" void* pdegpu_el_session_plane_ptr(pdegpu_el_session* h, int vec, int 
         default: return nullptr;
     }
     return base + (long long)comp * h->s.stride + which * h->s.g.PP;
+}
+
+// one contiguous halo message per neighbour: buffers [2 sides][r0 r1 r2 p0 p1 p2][plane_doubles]; side 0 = lower neighbour.
+// which = 0 send, 1 receive; side_doubles = 6 * plane_doubles
+extern "C" void* pdegpu_el_session_halo_buffer(pdegpu_el_session* h, int which, int side) {
+    if (!h || (which != 0 && which != 1) || (side != 0 && side != 1)) return nullptr;
+    ElSession& s = h->s;
+    const size_t bytes = (size_t)12 * s.g.PP * sizeof(double);
+    if (!s.halo_send) {
+        (void)hipSetDevice(s.ctx->device);
+        if (hipMalloc(&s.halo_send, bytes) != hipSuccess || hipMalloc(&s.halo_recv, bytes) != hipSuccess) return nullptr;
+        (void)hipMemsetAsync(s.halo_send, 0, bytes, s.ctx->stream);
+        (void)hipMemsetAsync(s.halo_recv, 0, bytes, s.ctx->stream);
+    }
+    return (which == 0 ? s.halo_send : s.halo_recv) + (size_t)side * 6 * s.g.PP;
+}
+// unpack = 0: first / last owned plane of r and p (current) -> send buffers; 1: receive buffers -> ghost planes.  Sides
+// without a slab neighbour are skipped.
+extern "C" int pdegpu_el_session_halo_pack(pdegpu_el_session* h, int unpack) {
+    if (!h) return PDEGPU_EINVAL;
+    ElSession& s = h->s;
+    if (!pdegpu_el_session_halo_buffer(h, 0, 0)) return pdegpu_set_err(s.ctx, PDEGPU_EHIP, "hipMalloc of the halo buffers failed");
+    const int lo = s.g.k0 > 0 ? 1 : 0, hi = (s.g.k0 + s.g.nkl < s.g.NZ) ? 1 : 0;
+    if (!lo && !hi) return PDEGPU_OK;
+    const long long total = 12 * (s.g.PP / 2);
+    const int nb = (int)std::min<long long>((total + 255) / 256, 2LL * s.ctx->num_cu);
+    hipLaunchKernelGGL(k_el_halo, dim3(nb), dim3(256), 0, s.ctx->stream, s.r, s.p[s.pcur], s.stride, s.g.PP, s.g.nkl, lo, hi,
+                       unpack ? s.halo_recv : s.halo_send, unpack);
+    PG_HIP(s.ctx, hipGetLastError());
+    return PDEGPU_OK;
 }
 
 // synchronises; out4 = {p.q, r.z, r.r, r.z of the previous iteration} (global values once the host has all-reduced them)

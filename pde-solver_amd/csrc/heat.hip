@@ -41,6 +41,13 @@ struct pdegpu_session {
     CgGraph cg_graph;
     int last_iters = 0;            // CG iterations of the previous linear solve of this session (first poll of the next one)
     long long eager_iters = 0;     // iterations launched eagerly so far (occupancy queries etc. are done)
+    // per-call kernel timing of the stepwise protocol (pdegpu_session_set_timing): event pairs around every k1 part / k2 launch
+    bool timing = false;
+    std::vector<hipEvent_t> tev;   // pairs: [2 i] start, [2 i + 1] stop
+    std::vector<int> tev_kind;     // 0 K1 (a split K1 contributes several pairs), 1 K2
+    size_t tev_used = 0;
+    long long timed_k1 = 0, timed_k2 = 0;
+    int k1_parts = 0;              // workgroups (partials) launched by the parts of a split K1 so far
     // weighted (curvilinear) operators: per-node coefficients + Jacobi-PCG
     bool weighted = false;
     double *ellA = nullptr, *ellM = nullptr, *dinv = nullptr;   // origins (same indexing as the vectors)
@@ -199,6 +206,12 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
         a.ell = which == 0 ? s->ellA : s->ellM;
         a.ell_stride = s->ell_stride;
     }
+    if (s->tile3d && mask && s->ctx->tile3d_plain) {            // bare SpMV of a tile session (masked: Dirichlet rows give 0)
+        a.g = s->g;
+        fast_weights(htab, a.w, false);
+        a.npt = s->grid.element_mode == PDEGPU_ELEM_Q1 ? 27 : (is_seven_point(a.w) ? 7 : 15);
+        return stencil_tile3d(s->ctx, a, APPLY_PLAIN, nullptr);
+    }
     if (s->fast) {
         a.g = s->gk;
         fast_weights(htab, a.w, s->gk.flat2d != 0);
@@ -248,7 +261,9 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
 // 15-point operator the second stencil pass costs more than the 8 B/DoF it saves (measured)
 bool k2_is_stencil(const pdegpu_session* s) { return s->fast && !s->hybrid && s->ctx->cg_variant == 1 && s->npt == 7; }
 
-int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
+// lk_lo < lk_hi: one part of a split K1 (marching sessions only) — the launch covers the local planes [lk_lo, lk_hi), appends its
+// partials at part_off and leaves the p ping-pong alone (the caller flips it after the last part)
+int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_lo = 0, int lk_hi = 0, int part_off = 0) {
     StencilArgs a{};
     a.di = di;
     a.g = s->g;
@@ -262,11 +277,17 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
     a.x = s->x.v;
     a.out = k2_is_stencil(s) ? nullptr : s->q.v;     // 64-B variant: q is recomputed by K2
     a.scal = s->d_scal;
-    a.partials = s->d_part;
+    a.partials = s->d_part + part_off;
     a.counter = s->d_counter;
     a.dot_which = use_inlaunch(s) ? 0 : -1;
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
+    const bool part = lk_hi > lk_lo;
+    if (part) {
+        a.lk_lo = lk_lo;
+        a.lk_hi = lk_hi;
+        a.dot_which = -1;
+    }
     int rc;
     if (s->plane2d) {
         a.g = s->g;
@@ -290,7 +311,7 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn()) {
     } else {
         rc = stencil_general(s->ctx, a, APPLY_CG_K1, li);
     }
-    if (rc == PDEGPU_OK) s->pcur ^= 1;
+    if (rc == PDEGPU_OK && !part) s->pcur ^= 1;
     return rc;
 }
 
@@ -388,7 +409,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -402,6 +423,14 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_ry")) return &ctx->fast_ry;
     if (!strcmp(key, "fast_nt")) return &ctx->fast_nt;
     if (!strcmp(key, "fast_ex")) return &ctx->fast_ex;
+    if (!strcmp(key, "fast_ex_all")) return &ctx->fast_ex_all;
+    if (!strcmp(key, "fast_pf")) return &ctx->fast_pf;
+    if (!strcmp(key, "fast_zlen")) return &ctx->fast_zlen;
+    if (!strcmp(key, "fast_cfg_plain")) return &ctx->fast_cfg[APPLY_PLAIN];
+    if (!strcmp(key, "fast_cfg_res")) return &ctx->fast_cfg[APPLY_RESIDUAL];
+    if (!strcmp(key, "fast_cfg_k1")) return &ctx->fast_cfg[APPLY_CG_K1];
+    if (!strcmp(key, "fast_cfg_k2")) return &ctx->fast_cfg[APPLY_CG_K2];
+    if (!strcmp(key, "tile3d_plain")) return &ctx->tile3d_plain;
     if (!strcmp(key, "fast_wg_per_cu")) return &ctx->fast_wg_per_cu;
     if (!strcmp(key, "fast_wg_per_cu_k2")) return &ctx->fast_wg_per_cu_k2;
     if (!strcmp(key, "grid_mult")) return &ctx->grid_mult;
@@ -466,6 +495,7 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     if (s->d_dense) (void)hipFree(s->d_dense);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->tev) (void)hipEventDestroy(e);
     s->cg_graph.reset();
     for (double* b0 : s->ell_base)
         if (b0) (void)hipFree(b0);
@@ -516,11 +546,12 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     }
     s->plane2d = s->fast && s->g.dim == 2 && ctx->plane2d != 0 && plane2d_symmetric(s->hA);
     s->tile3d = s->fast && !s->hybrid && s->g.dim == 3 && s->g.k0 == 0 && s->g.nkl == s->g.NZ && ctx->tile3d_max_nodes > 0 &&
-                (long long)s->g.NX * s->g.NY * s->g.NZ <= ctx->tile3d_max_nodes && stencil_tile3d_grid(s->g) <= stencil_max_partials(ctx);
+                (long long)s->g.NX * s->g.NY * s->g.NZ <= ctx->tile3d_max_nodes && stencil_tile3d_grid(s->g) <= 0x3fffffffLL;
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
     for (DevVec* v : vecs)
         if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);
-    const int npart = stencil_max_partials(ctx);
+    int npart = stencil_max_partials(ctx);
+    if (s->tile3d && stencil_tile3d_grid(s->g) > npart) npart = (int)stencil_tile3d_grid(s->g);
     if (rc == PDEGPU_OK && hipMalloc(&s->d_scal, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc scal");
     s->npart = npart;
     if (rc == PDEGPU_OK && hipMalloc(&s->d_part, 2 * (size_t)npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
@@ -576,20 +607,120 @@ extern "C" int pdegpu_session_residual(pdegpu_session* s) {
     return residual_finish(s, &li);
 }
 
+namespace {
+// event pair around one launch of the stepwise protocol (timing on): returns the index of the start event, -1 when off
+int timed_begin(pdegpu_session* s, int kind) {
+    if (!s->timing) return -1;
+    if (s->tev_used + 2 > s->tev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            s->tev.push_back(e);
+        }
+        s->tev_kind.push_back(kind);
+    }
+    const int at = (int)s->tev_used;
+    s->tev_kind[at / 2] = kind;
+    s->tev_used += 2;
+    (void)hipEventRecord(s->tev[at], s->ctx->stream);
+    return at;
+}
+void timed_end(pdegpu_session* s, int at) {
+    if (at >= 0) (void)hipEventRecord(s->tev[at + 1], s->ctx->stream);
+}
+// a K1 that can be split into plane ranges: marching kernel alone (no boundary pass, no one-round tiles), 3-D
+bool k1_splittable(const pdegpu_session* s) { return s->fast && !s->hybrid && !s->tile3d && !s->plane2d && s->g.dim == 3 && !s->weighted; }
+}  // namespace
+
 extern "C" int pdegpu_session_k1(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
+    const int at = timed_begin(s, 0);
     PG_TRY(op_k1(s, &li));
+    timed_end(s, at);
+    if (s->timing) ++s->timed_k1;
     return empty_dot(s, li, 0);
+}
+
+extern "C" int pdegpu_session_can_split_k1(const pdegpu_session* s) { return (s && k1_splittable(s)) ? 1 : 0; }
+
+// K1 in two steps for the multi-GPU loop: part 0 = the owned planes whose stencil does not touch a ghost plane (launched while
+// the halo exchange is in flight), part 1 = the one or two planes next to the ghosts + the sum of all partials.  Sessions
+// whose K1 cannot be split do nothing in part 0 and the whole K1 in part 1, so a driver may always call 0 then 1.
+extern "C" int pdegpu_session_k1_part(pdegpu_session* s, int part) {
+    if (!s || (part != 0 && part != 1)) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    if (!k1_splittable(s)) return part == 0 ? PDEGPU_OK : pdegpu_session_k1(s);
+    const GridDev& g = s->g;
+    const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;      // slab neighbours below / above
+    LaunchInfo li;
+    if (part == 0) {
+        s->k1_parts = 0;
+        const int a0 = lo, a1 = g.nkl - hi;
+        if (a1 > a0) {
+            const int at = timed_begin(s, 0);
+            PG_TRY(op_k1(s, &li, DotIn(), a0, a1, 0));
+            timed_end(s, at);
+            s->k1_parts = li.grid;
+        }
+        return PDEGPU_OK;
+    }
+    // edge planes: plane 0 (needs ghost -1) and plane nkl-1 (needs ghost nkl); one plane can be both
+    const int edges[2][2] = {{0, lo ? 1 : 0}, {hi ? std::max(g.nkl - 1, lo ? 1 : 0) : 0, hi ? g.nkl : 0}};
+    for (int e = 0; e < 2; ++e) {
+        if (edges[e][1] <= edges[e][0]) continue;
+        const int at = timed_begin(s, 0);
+        PG_TRY(op_k1(s, &li, DotIn(), edges[e][0], edges[e][1], s->k1_parts));
+        timed_end(s, at);
+        s->k1_parts += li.grid;
+    }
+    s->pcur ^= 1;
+    if (s->timing) ++s->timed_k1;
+    li.grid = s->k1_parts;
+    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 0, 1);
 }
 
 extern "C" int pdegpu_session_k2(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
+    const int at = timed_begin(s, 1);
     PG_TRY(op_k2(s, &li));
+    timed_end(s, at);
+    if (s->timing) ++s->timed_k2;
     return empty_dot(s, li, 1);
+}
+
+// kernel timing of the stepwise protocol (k1 / k1_part / k2): on = 1 starts a fresh measurement; get_stats synchronises and
+// ADDS the elapsed kernel time, launch counts and algorithmic bytes since set_timing(1) to *stats (kernel_ms[0] K1, [1] K2)
+extern "C" int pdegpu_session_set_timing(pdegpu_session* s, int on) {
+    if (!s) return PDEGPU_EINVAL;
+    s->timing = on != 0;
+    s->tev_used = 0;
+    s->timed_k1 = s->timed_k2 = 0;
+    return PDEGPU_OK;
+}
+extern "C" int pdegpu_session_get_stats(pdegpu_session* s, pdegpu_stats* stats) {
+    if (!s || !stats) return PDEGPU_EINVAL;
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t at = 0; at + 1 < s->tev_used; at += 2) {
+        float ms = 0;
+        PG_HIP(ctx, hipEventElapsedTime(&ms, s->tev[at], s->tev[at + 1]));
+        stats->kernel_ms[s->tev_kind[at / 2] == 0 ? 0 : 1] += ms;
+    }
+    const double nloc = (double)s->g.nkl * s->g.NY * s->g.NX;
+    stats->kernel_launches[0] += s->timed_k1;
+    stats->kernel_launches[1] += s->timed_k2;
+    stats->alg_bytes[0] += (k2_is_stencil(s) ? 40.0 : 48.0) * nloc * (double)s->timed_k1;
+    stats->alg_bytes[1] += 24.0 * nloc * (double)s->timed_k2;
+    stats->cg_iterations += s->timed_k2;
+    stats->path = s->hybrid ? 3 : (s->fast ? 1 : 0);
+    s->tev_used = 0;
+    s->timed_k1 = s->timed_k2 = 0;
+    return PDEGPU_OK;
 }
 
 // k1 / k2 / residual already leave this slab's sum in BOTH the local and the global slot (the multi-GPU host then
@@ -599,6 +730,34 @@ extern "C" int pdegpu_session_reduce_local(pdegpu_session* s, int which, int cop
     if (!copy_to_global) return PDEGPU_OK;
     const int src = which == 0 ? SC_PQ_LOCAL : SC_RR_LOCAL, dst = which == 0 ? SC_PQ : SC_RR;
     PG_HIP(s->ctx, hipMemcpyAsync(s->d_scal + dst, s->d_scal + src, sizeof(double), hipMemcpyDeviceToDevice, s->ctx->stream));
+    return PDEGPU_OK;
+}
+
+// ---- transient steps on a slab (multi-GPU time loop, fenics_mcp_server.py:702-716): the host exchanges the ghost planes of x
+// (vector 0), then  step_rhs: b = M (x + dt f);  lift_norm: r = P (b - A g), g = Dirichlet values, its r.r (the reference norm
+// of the step) in the rr slots;  reset_cg + residual start the solve of the step.
+extern "C" int pdegpu_session_step_rhs(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    if (s->heat.steady) return pdegpu_set_err(s->ctx, PDEGPU_EINVAL, "step_rhs: the session is a steady system");
+    return op_plain(s, 1, s->x.v, s->heat.dt * s->heat.source, s->b.v, 0);
+}
+extern "C" int pdegpu_session_lift_norm(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    pdegpu_ctx* ctx = s->ctx;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    LaunchInfo li;
+    PG_TRY(vec_zero(ctx, s->g, &s->q));
+    PG_TRY(set_bc_ext(s, s->q.v, 0.0, nullptr, 0));
+    PG_TRY(op_residual(s, s->q.v, s->b.v, s->r.v, &li));
+    PG_TRY(residual_finish(s, &li));
+    return vec_zero(ctx, s->g, &s->q);
+}
+extern "C" int pdegpu_session_reset_cg(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    PG_HIP(s->ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), s->ctx->stream));
+    s->pcur = 0;      // the old p only ever meets beta = 0 (see linear_solve)
     return PDEGPU_OK;
 }
 
@@ -679,8 +838,9 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
     // slots alternate so that no launch overwrites a scalar its own workgroups still read, and one reduce launch at the
     // end of the chunk leaves the canonical layout (SC_RR current, SC_RR_PREV previous) for the host and for flush.
     const int64_t nslow = s->grid.dim == 3 ? (int64_t)s->grid.n[2] + 1 : 1;
+    // (every workgroup of the consuming launch sums ALL partials: only sensible while they are a few thousand)
     const bool lazy = ctx->lazy_dot && !use_inlaunch(s) && !s->weighted && s->g.k0 == 0 && s->g.nkl == nslow &&
-                      done < iters;
+                      done < iters && !(s->tile3d && stencil_tile3d_grid(s->g) > stencil_max_partials(ctx));
     if (lazy) {
         int cur = SC_RR;
         bool pend = false;
@@ -860,9 +1020,16 @@ int cg_solve(pdegpu_session* s, double bnorm2, double rr, double rtol, int max_i
     // consecutive solves of a session (time steps) need nearly the same number of iterations: the first poll of this solve is
     // placed at 85 % of the previous count, the remaining ones by the rate predictor
     int chunk = s->last_iters > 16 ? (int)(0.85 * s->last_iters) : 8;
-    hipEvent_t e0, e1;
-    PG_HIP(ctx, hipEventCreate(&e0));
-    PG_HIP(ctx, hipEventCreate(&e1));
+    struct Events {                // destroyed on every exit path (a failed iterate / rr returns through PG_TRY)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } ev;
+    PG_HIP(ctx, hipEventCreate(&ev.a));
+    PG_HIP(ctx, hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
     while (rr > target && it < max_iter && std::isfinite(rr)) {
         const int n = std::min(chunk, max_iter - it);
@@ -878,8 +1045,6 @@ int cg_solve(pdegpu_session* s, double bnorm2, double rr, double rtol, int max_i
     PG_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0;
     PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (st) {
         st->cg_iterations += it;
         st->cg_ms += ms;

@@ -25,6 +25,7 @@
 // there), so in the multi-GPU loop only r needs a halo exchange.
 #include "common.h"
 #include "dot_finish.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -217,7 +218,9 @@ __device__ __forceinline__ double2 load_pair_x(const double* p) {
 // EX = 1: the tile-edge x-neighbours are handed between the x-adjacent wavefronts of the workgroup through 512 B of
 // LDS (one barrier per z-step; the waves march in lockstep anyway) instead of 2-lane global loads; columns outside
 // the free range of a CG vector (Dirichlet / beyond the grid) need no load at all.
-template <int NPT, int RY, int MODE, int NT, int EX>
+// PF = 1 (bare apply / residual / stencil K2 only): the loads of plane lk+2 are issued before the stencil of plane lk, so a wave
+// waits for a plane one whole z-step after requesting it (these modes hold one vector, the registers are there).
+template <int NPT, int RY, int MODE, int NT, int EX, int PF>
 __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     __shared__ double sRed[4];
     __shared__ double sEdge[EX ? 2 : 1][4][RY + 2][2];
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr bool K1 = (MODE == APPLY_CG_K1);
     constexpr bool K2 = (MODE == APPLY_CG_K2);
+    static_assert(!(PF && MODE == APPLY_CG_K1), "the deeper prefetch is for the one-vector modes");
     constexpr bool RES = (MODE == APPLY_RESIDUAL) || K2;      // out = rhs - scale * (A in)
     constexpr bool W15 = (NPT == 15) || (NPT == 27);     // every held row of every plane is needed (x-diagonals)
     constexpr bool W27 = (NPT == 27);                     // Q1: all 26 neighbours, weights symmetric under every sign flip
@@ -268,31 +272,34 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         auto load_pair = [&](const double* v, long long off) {
             return *reinterpret_cast<const double2*>(v + off);
         };
+        // Loads are UNCONDITIONAL and their values are NOT masked: a lane / row outside the grid reads offset 0 of the vector (always
+        // mapped, finite) and whatever it reads only ever reaches outputs that are masked or never stored — every row a computed
+        // output uses lies inside the grid, pad lanes read the zero pads, and the lanes beyond the padded row only feed the masked
+        // node PX-1.  A load inside an exec-masked branch is followed by `s_waitcnt vmcnt(0)` as soon as its value is used in
+        // that branch (p = r + beta p, in + shift), and a `cond ? f(load) : 0` select is turned back into such a branch by the
+        // compiler: every row of a plane then costs its own memory round trip.  This way all loads of a z-step are in flight
+        // together and the first wait sits in front of the stencil.
         auto value_row = [&](int lk, int j, double2* po_out) {
-            double2 val = make_double2(0.0, 0.0);
-            if (row_ok(j) && lane_ok) {
-                const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
-                if (K1) {
-                    const double2 rr = load_pair(a.in, off), po = load_pair(a.p_old, off);
-                    val.x = rr.x + beta * po.x;
-                    val.y = rr.y + beta * po.y;
-                    if (po_out) *po_out = po;
-                } else {
-                    const double2 v = load_pair(a.in, off);
-                    val.x = v.x + shift;
-                    val.y = v.y + shift;
-                }
+            const bool ok = row_ok(j) && lane_ok;
+            const long long off = ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0;
+            double2 val;
+            if (K1) {
+                const double2 rr = load_pair(a.in, off), po = load_pair(a.p_old, off);
+                val.x = rr.x + beta * po.x;
+                val.y = rr.y + beta * po.y;
+                if (po_out) *po_out = po;
+            } else {
+                const double2 v = load_pair(a.in, off);
+                val.x = v.x + shift;
+                val.y = v.y + shift;
             }
             return val;
         };
         auto edge_value = [&](int lk, int j) {
-            double e = 0.0;
-            if (row_ok(j) && edge_lane) {
-                const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0 + edge_off;
-                if (K1) e = a.in[off] + beta * a.p_old[off];
-                else e = a.in[off] + shift;
-            }
-            return e;
+            const bool ok = row_ok(j) && edge_lane;
+            const long long off = ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 + edge_off : 0;
+            if (K1) return a.in[off] + beta * a.p_old[off];
+            return a.in[off] + shift;
         };
         // edge values of one plane: E[r] = value at node i0-1 (lane 0) / i0+2 (lane 63) of row r
         auto plane_edges = [&](int lk, const double2* rows, double* E, bool all_rows) {
@@ -344,14 +351,19 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             }
         };
 
-        // K1: x += alpha p_{n-1}, store p_n for an owned row-plane
-        auto own_update = [&](int lk, int j, const double2& pn, const double2& po) {
+        // K1: x += alpha p_{n-1}, store p_n for an owned row-plane.  The x row is requested together with the plane's r / p rows
+        // (own_xload, unconditional like them) and consumed here, after the stencil.
+        auto own_xload = [&](int lk, int j) {
+            const bool ok = j <= fg.jmax && lane_ok;
+            const long long off = ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0;
+            return load_pair_x<NT>(a.x + off);
+        };
+        auto own_update = [&](int lk, int j, const double2& pn, const double2& po, double2 xv) {
             if (K1) {
                 if (j <= fg.jmax && lane_ok) {
                     const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
                     store_pair<NT>(a.p_new + off, pn);
                     if (alpha_prev != 0.0) {
-                        double2 xv = load_pair_x<NT>(a.x + off);
                         xv.x += alpha_prev * po.x;
                         xv.y += alpha_prev * po.y;
                         store_pair<NT>(a.x + off, xv);
@@ -373,10 +385,18 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             EP[r] = 0.0;
             double2 po = make_double2(0.0, 0.0);
             C[r] = value_row(lk0, j, &po);
-            if (own) own_update(lk0, j, C[r], po);
+            if (K1 && own) own_update(lk0, j, C[r], po, own_xload(lk0, j));
         }
         if (W15) plane_edges(lk0 - 1, P, EP, true);
         plane_edges(lk0, C, EC, W15);
+        if (PF) {
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                N[r] = value_row(lk0 + 1, j0 - 1 + r, nullptr);
+                EN[r] = 0.0;
+            }
+            if (!EX) plane_edges(lk0 + 1, N, EN, W15);
+        }
 
         // K1 keeps p_n valid on the ghost planes of the slab (same formula, same inputs as the neighbour rank)
         auto ghost_store = [&](int lk, const double2* rows) {
@@ -392,23 +412,42 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         if (K1 && lk0 == fg.lkb && lk0 == 0 && g.k0 > 0) ghost_store(-1, P);
 
         for (int lk = lk0; lk < lk1; ++lk) {
-            // ---- issue the loads of plane lk+1 -------------------------------------------------
+            // ---- issue the loads of plane lk+1 (PF: of plane lk+2; lk1 + 1 would leave the allocation and is never used) ----
             double2 PO[RH];
+            double2 XV[RY];
+            double2 N2[PF ? RH : 1];
+            double EN2[PF ? RH : 1];
+            if (PF) {
+                const int lkn = min(lk + 2, lk1);
 #pragma unroll
-            for (int r = 0; r < RH; ++r) {
-                const int j = j0 - 1 + r;
-                PO[r] = make_double2(0.0, 0.0);
-                N[r] = value_row(lk + 1, j, &PO[r]);
+                for (int r = 0; r < RH; ++r) {
+                    N2[r] = value_row(lkn, j0 - 1 + r, nullptr);
+                    EN2[r] = 0.0;
+                }
+                if (!EX) plane_edges(lkn, N2, EN2, W15);
+            } else {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const int j = j0 - 1 + r;
+                    PO[r] = make_double2(0.0, 0.0);
+                    N[r] = value_row(lk + 1, j, &PO[r]);
+                }
+                if (K1 && lk + 1 < lk1) {
+#pragma unroll
+                    for (int r = 0; r < RY; ++r) XV[r] = own_xload(lk + 1, j0 + r);
+                }
+                if (!EX) plane_edges(lk + 1, N, EN, W15);      // global edge loads: issue them with the plane's loads
             }
-            if (!EX) plane_edges(lk + 1, N, EN, W15);          // global edge loads: issue them with the plane's loads
             double2 RHS[RY];
             if (RES) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     const int j = j0 + r;
                     RHS[r] = make_double2(a.rhs_const, a.rhs_const);
-                    if (a.rhs && j <= fg.jmax && lane_ok)
-                        RHS[r] = load_pair(a.rhs, (long long)lk * g.PP + (long long)j * g.PX + i0);
+                    if (a.rhs) {                                   // kernel-uniform; the load itself is unconditional (see value_row)
+                        const bool ok = j <= fg.jmax && lane_ok;
+                        RHS[r] = load_pair(a.rhs, ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0);
+                    }
                 }
             }
 
@@ -473,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             // ---- K1: owned rows of plane lk+1: x update + p_n store ------------------------------
             if (K1 && lk + 1 < lk1) {
 #pragma unroll
-                for (int r = 1; r <= RY; ++r) own_update(lk + 1, j0 - 1 + r, N[r], PO[r]);
+                for (int r = 1; r <= RY; ++r) own_update(lk + 1, j0 - 1 + r, N[r], PO[r], XV[r - 1]);
             }
             // ---- rotate planes -----------------------------------------------------------------
 #pragma unroll
@@ -482,6 +521,10 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 EP[r] = EC[r];
                 C[r] = N[r];
                 EC[r] = EN[r];
+                if (PF) {
+                    N[r] = N2[r];
+                    if (!EX) EN[r] = EN2[r];
+                }
             }
         }
         // after the last rotation C holds plane lk1: the upper ghost plane when this is the slab's last chunk
@@ -520,9 +563,9 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
     const bool ma = active && i0 >= 1 && i0 <= g.NX - 2;
     const bool mb = active && i0 + 1 <= g.NX - 2;
     const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wd1 = a.w[3], wd2 = a.w[4];
-    // tile-edge neighbours: lane 0 needs node i0-1, lane 63 node i0+2; they are zero on / beyond the Dirichlet columns
-    const bool el = lane == 0 && active && i0 - 1 >= 1;
-    const bool er = lane == 63 && active && i0 + 2 <= g.NX - 2;
+    // tile-edge neighbours: lane 0 needs node i0-1, lane 63 node i0+2 (CG vectors are zero in memory on the Dirichlet columns and
+    // the pads; what lies beyond only reaches masked outputs)
+    const bool elane = (lane == 0 || lane == 63) && active;
     const long long eoff = (lane == 0) ? -1 : 2;
 
     double2 C[RH], PO[RH];
@@ -533,18 +576,21 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
         C[r] = make_double2(0.0, 0.0);
         PO[r] = make_double2(0.0, 0.0);
         E[r] = 0.0;
-        if (j <= g.NY - 1) {
-            const long long off = (long long)j * g.PX + i0;
-            if (lane_ok) {
-                const double2 v = *reinterpret_cast<const double2*>(a.in + off);
-                if (K1) {
-                    PO[r] = *reinterpret_cast<const double2*>(a.p_old + off);
-                    C[r] = make_double2(v.x + beta * PO[r].x, v.y + beta * PO[r].y);
-                } else {
-                    C[r] = v;
-                }
+        {
+            // unconditional loads, unmasked values (see k_fast::value_row): rows / lanes outside the grid read offset 0 and only
+            // reach outputs that are masked or not stored; all rows of the tile are requested in ONE round
+            const bool rok = j <= g.NY - 1;
+            const long long off = (rok && lane_ok) ? (long long)j * g.PX + i0 : 0;
+            const long long offe = (rok && elane) ? (long long)j * g.PX + i0 + eoff : 0;
+            const double2 v = *reinterpret_cast<const double2*>(a.in + off);
+            if (K1) {
+                PO[r] = *reinterpret_cast<const double2*>(a.p_old + off);
+                C[r] = make_double2(v.x + beta * PO[r].x, v.y + beta * PO[r].y);
+                E[r] = a.in[offe] + beta * a.p_old[offe];
+            } else {
+                C[r] = v;
+                E[r] = a.in[offe];
             }
-            if (el || er) E[r] = K1 ? a.in[off + eoff] + beta * a.p_old[off + eoff] : a.in[off + eoff];
         }
     }
     double acc = 0.0;
@@ -576,8 +622,7 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
                 acc += C[r].x * o.x + C[r].y * o.y;
                 if (lane_ok && a.out) *reinterpret_cast<double2*>(a.out + off) = o;
             } else {
-                double2 rv = make_double2(0.0, 0.0);
-                if (lane_ok) rv = *reinterpret_cast<const double2*>(a.rhs + off);
+                const double2 rv = *reinterpret_cast<const double2*>(a.rhs + (lane_ok ? off : 0));
                 const double2 o = make_double2(ma ? rv.x - res_scale * qa : 0.0, mb ? rv.y - res_scale * qb : 0.0);
                 acc += o.x * o.x + o.y * o.y;
                 if (lane_ok) *reinterpret_cast<double2*>(a.out + off) = o;
@@ -597,30 +642,50 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
 // form gives a wavefront ONE plane of a 128-node x RY-row tile: the RY + 2 rows of the three planes it needs are requested in a
 // single round, p is formed at every held position and the same 7- / 15- / 27-point formulas are applied.  Uniform Dirichlet
 // boundary, one slab (no ghost planes to maintain); the four waves of a workgroup are stacked in y.
-template <int NPT, int RY, int MODE>
+// XM = 1 (grids beyond L2): XCD-aware order.  Workgroups b and b + 8 share an XCD (round-robin dispatch, speed only): XCD x owns the
+// y-range [x, x+1) * nyg/8 of every plane and takes its tiles plane by plane in dispatch order, so the three planes a tile reads are
+// the ones its own XCD's L2 has just streamed (0.27 MB per plane and vector at 513^2 / 8) — every input plane leaves HBM once although
+// no workgroup lives longer than one tile.  Streaming stores are non-temporal.  PLAIN: out = A (in + shift), inputs carry the
+// boundary values (tile-edge loads reach the Dirichlet columns).
+template <int NPT, int RY, int MODE, int XM>
 __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty) {
     __shared__ double sRed[4];
     constexpr bool K1 = (MODE == APPLY_CG_K1);
+    constexpr bool K2 = (MODE == APPLY_CG_K2);
+    constexpr bool PL = (MODE == APPLY_PLAIN);
     constexpr bool W27 = (NPT == 27), WD = (NPT != 7);        // WD: diagonal neighbours -> every held row of every plane
     constexpr int RH = RY + 2;
     const GridDev& g = a.g;
     double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
     if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
-    else res_scale = cg_alpha_in(a.di, a.scal, sRed);
+    if (K2) res_scale = cg_alpha_in(a.di, a.scal, sRed);
+    const double shift = PL ? a.in_shift : 0.0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nyg = (nty + 3) / 4;
-    const int xt = (int)blockIdx.x % ntx, yt = (((int)blockIdx.x / ntx) % nyg) * 4 + wv;
-    const int lk = 1 + (int)blockIdx.x / (ntx * nyg);         // interior planes 1 .. NZ-2
+    int xt, yg, lk;
+    if (XM) {
+        const int xcd = (int)blockIdx.x & 7, t = (int)(blockIdx.x >> 3), ny8 = (nyg + 7) / 8;
+        xt = t % ntx;
+        yg = xcd * ny8 + (t / ntx) % ny8;
+        lk = 1 + t / (ntx * ny8);
+        if (yg >= nyg) yg = 0x3fffffff;                        // surplus workgroup of the last XCD range: inactive
+    } else {
+        xt = (int)blockIdx.x % ntx;
+        yg = ((int)blockIdx.x / ntx) % nyg;
+        lk = 1 + (int)blockIdx.x / (ntx * nyg);               // interior planes 1 .. NZ-2
+    }
+    const int yt = (yg < 0x10000000) ? yg * 4 + wv : 0x3fffffff;
     const bool active = yt < nty;
     const int i0 = xt * 128 + 2 * lane;
-    const int j0 = 1 + yt * RY;
+    const int j0 = active ? 1 + yt * RY : 1;
     const bool lane_ok = active && i0 < g.PX;
     const bool ma = active && i0 >= 1 && i0 <= g.NX - 2;
     const bool mb = active && i0 + 1 <= g.NX - 2;
     const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wz = a.w[3];
     const double wxy = a.w[4], wxz = a.w[5], wyz = a.w[6], wxyz = a.w[7];
-    const bool el = lane == 0 && active && i0 - 1 >= 1;       // CG vectors vanish on / beyond the Dirichlet columns
-    const bool er = lane == 63 && active && i0 + 2 <= g.NX - 2;
+    // tile-edge neighbours (lane 0: node i0-1, lane 63: node i0+2): CG vectors are zero in memory on the Dirichlet columns and the
+    // pads, a PLAIN input carries the boundary values there; what lies beyond only reaches masked outputs
+    const bool elane = (lane == 0 || lane == 63) && active;
     const long long eoff = (lane == 0) ? -1 : 2;
 
     double2 P[RH], C[RH], N[RH], PO[RH];
@@ -632,30 +697,38 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
             if (po) *po = o;
             return make_double2(v.x + beta * o.x, v.y + beta * o.y);
         }
-        return v;
+        return make_double2(v.x + shift, v.y + shift);
     };
-    auto edge = [&](long long off) { return K1 ? a.in[off + eoff] + beta * a.p_old[off + eoff] : a.in[off + eoff]; };
+    auto edge = [&](long long off) { return K1 ? a.in[off + eoff] + beta * a.p_old[off + eoff] : a.in[off + eoff] + shift; };
+    auto put = [&](double* p, const double2& v) {
+        if (XM) {
+            dbl2 t = {v.x, v.y};
+            __builtin_nontemporal_store(t, reinterpret_cast<dbl2*>(p));
+        } else {
+            *reinterpret_cast<double2*>(p) = v;
+        }
+    };
 #pragma unroll
     for (int r = 0; r < RH; ++r) {
         const int j = j0 - 1 + r;
         const bool own = r >= 1 && r <= RY;
         P[r] = C[r] = N[r] = PO[r] = make_double2(0.0, 0.0);
         EP[r] = EC[r] = EN[r] = 0.0;
-        if (j <= g.NY - 1) {
-            const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
-            if (lane_ok) {
-                C[r] = value(off, &PO[r]);
-                if (WD || own) {
-                    P[r] = value(off - g.PP, nullptr);
-                    N[r] = value(off + g.PP, nullptr);
-                }
+        {
+            // unconditional loads, unmasked values (see k_fast::value_row): everything a tile needs is requested in ONE round.  The
+            // fall-back address is plane 1, row 0 (its planes 0 and 2 exist for every tile session)
+            const bool rok = j <= g.NY - 1;
+            const long long off = (rok && lane_ok) ? (long long)lk * g.PP + (long long)j * g.PX + i0 : g.PP;
+            const long long offe = (rok && elane) ? (long long)lk * g.PP + (long long)j * g.PX + i0 : g.PP + 1;
+            C[r] = value(off, &PO[r]);
+            if (WD || own) {
+                P[r] = value(off - g.PP, nullptr);
+                N[r] = value(off + g.PP, nullptr);
+                EC[r] = edge(offe);
             }
-            if (el || er) {
-                if (WD || own) EC[r] = edge(off);
-                if (WD) {
-                    EP[r] = edge(off - g.PP);
-                    EN[r] = edge(off + g.PP);
-                }
+            if (WD) {
+                EP[r] = edge(offe - g.PP);
+                EN[r] = edge(offe + g.PP);
             }
         }
     }
@@ -701,23 +774,26 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
             }
             if (K1) {
                 if (lane_ok) {
-                    *reinterpret_cast<double2*>(a.p_new + off) = C[c];
+                    put(a.p_new + off, C[c]);
                     if (alpha_prev != 0.0) {
                         double2 xv = *reinterpret_cast<double2*>(a.x + off);
                         xv.x += alpha_prev * PO[c].x;
                         xv.y += alpha_prev * PO[c].y;
-                        *reinterpret_cast<double2*>(a.x + off) = xv;
+                        put(a.x + off, xv);
                     }
                 }
                 const double2 o = make_double2(ma ? qa : 0.0, mb ? qb : 0.0);
                 acc += C[c].x * o.x + C[c].y * o.y;
-                if (lane_ok && a.out) *reinterpret_cast<double2*>(a.out + off) = o;
+                if (lane_ok && a.out) put(a.out + off, o);
+            } else if (PL) {
+                const double2 o = make_double2(ma ? qa : 0.0, mb ? qb : 0.0);
+                acc += (C[c].x - shift) * o.x + (C[c].y - shift) * o.y;
+                if (lane_ok) put(a.out + off, o);
             } else {
-                double2 rv = make_double2(0.0, 0.0);
-                if (lane_ok) rv = *reinterpret_cast<const double2*>(a.rhs + off);
+                const double2 rv = *reinterpret_cast<const double2*>(a.rhs + (lane_ok ? off : 0));
                 const double2 o = make_double2(ma ? rv.x - res_scale * qa : 0.0, mb ? rv.y - res_scale * qb : 0.0);
                 acc += o.x * o.x + o.y * o.y;
-                if (lane_ok) *reinterpret_cast<double2*>(a.out + off) = o;
+                if (lane_ok) put(a.out + off, o);
             }
         }
     }
@@ -725,7 +801,7 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
-FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
+FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0) {
     FastGeom fg{};
     fg.ntx = (g.NX - 1 + 127) / 128;
     fg.jbase = g.flat2d ? 0 : 1;
@@ -737,6 +813,10 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     fg.nyg = (fg.nty + fg.wyt - 1) / fg.wyt;
     fg.lkb = g.k0 >= 1 ? 0 : 1 - g.k0;
     fg.lke = (g.NZ - 1 - g.k0) < g.nkl ? (g.NZ - 1 - g.k0) : g.nkl;
+    if (lk_hi > lk_lo) {                       // plane-range launch (K1 split of the multi-GPU loop)
+        if (lk_lo > fg.lkb) fg.lkb = lk_lo;
+        if (lk_hi < fg.lke) fg.lke = lk_hi;
+    }
     int planes = fg.lke - fg.lkb;
     if (planes < 0) planes = 0;
     const int xy = fg.nxg * fg.nyg;
@@ -768,39 +848,62 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
             nzc = c;
         }
     }
+    if (ctx->fast_zlen > 0 && planes > 0) nzc = (planes + ctx->fast_zlen - 1) / ctx->fast_zlen;      // forced chunk length (tuning)
+    {   // one partial per workgroup: the grid must fit the session's partial buffer
+        const long long cap = stencil_max_partials(const_cast<pdegpu_ctx*>(ctx));
+        if ((long long)xy * nzc > cap) nzc = (int)std::max<long long>(1, cap / (xy > 0 ? xy : 1));
+    }
     fg.zlen = planes > 0 ? (planes + nzc - 1) / nzc : 1;
     fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
     return fg;
 }
 
-template <int NPT, int RY, int NT, int EX>
+struct ModeCfg { int ry, wg, ex, pf; };
+// rows per thread, resident workgroups per CU, LDS edge hand-off and deeper prefetch of one marching-kernel mode
+ModeCfg mode_cfg(const pdegpu_ctx* ctx, int mode) {
+    ModeCfg c;
+    c.ry = ctx->fast_ry;
+    c.wg = (mode == APPLY_CG_K2 && ctx->fast_wg_per_cu_k2 >= 1) ? ctx->fast_wg_per_cu_k2 : ctx->fast_wg_per_cu;
+    c.ex = ctx->fast_ex && (mode == APPLY_CG_K1 || mode == APPLY_CG_K2 || ctx->fast_ex_all);
+    c.pf = ctx->fast_pf != 0 && mode != APPLY_CG_K1;
+    const int v = ctx->fast_cfg[mode & 3];
+    if (v >= 0) {
+        c.ry = v & 15;
+        c.wg = (v >> 4) & 15;
+        c.ex = (v >> 8) & 1;
+        c.pf = ((v >> 9) & 1) && mode != APPLY_CG_K1;
+    }
+    return c;
+}
+
+template <int NPT, int RY, int NT, int EX, int PF>
 int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     static int occ[4] = {0, 0, 0, 0};   // resident workgroups per CU of each instantiation
     if (occ[mode] == 0) {
         int nb = 0;
         hipError_t e = hipSuccess;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT, EX>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX>, 256, 0); break;
-            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K2, NT, EX>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT, EX>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>, 256, 0); break;
+            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
         if (nb > 8) nb = 8;
         occ[mode] = nb;
     }
     int wg_per_cu = occ[mode];
-    if (ctx->fast_wg_per_cu >= 1 && ctx->fast_wg_per_cu <= 16) wg_per_cu = ctx->fast_wg_per_cu;
-    if (mode == APPLY_CG_K2 && ctx->fast_wg_per_cu_k2 >= 1 && ctx->fast_wg_per_cu_k2 <= 16) wg_per_cu = ctx->fast_wg_per_cu_k2;
-    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu);
+    const ModeCfg mc = mode_cfg(ctx, mode);
+    if (mc.wg >= 1 && mc.wg <= 16) wg_per_cu = mc.wg;
+    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, a.lk_lo, a.lk_hi);
     const int G = fg.nxg * fg.nyg * fg.nzc;
     if (li) { li->grid = G; li->block = 256; }
     if (G == 0) return PDEGPU_OK;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -810,47 +913,66 @@ template <int NPT, int RY>
 int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     int nt = ctx->fast_nt;
     if (nt < 0) nt = ((long long)a.g.nkl * a.g.PP * 8 > (64LL << 20)) ? 3 : 0;
-    // the LDS edge hand-off pays in the CG kernels (K1 / K2: measured -3 % / -15 %); the bare apply and the residual
-    // pass do less work per z-step and lose to the extra barrier (measured +5 %)
-    if (ctx->fast_ex && (mode == APPLY_CG_K1 || mode == APPLY_CG_K2)) {
+    const ModeCfg mc = mode_cfg(ctx, mode);
+    // deeper prefetch: one-vector modes of the 7-point operator, RY <= 4
+    const bool pf = mc.pf && NPT == 7 && RY <= 4;
+    if (mc.ex) {
+        if constexpr (NPT == 7 && RY <= 4) {
+            if (pf) return (nt & 3) == 3 ? launch_fast<NPT, RY, 3, 1, 1>(ctx, a, mode, li) : launch_fast<NPT, RY, 0, 1, 1>(ctx, a, mode, li);
+        }
         switch (nt & 3) {
-            case 3: return launch_fast<NPT, RY, 3, 1>(ctx, a, mode, li);
-            default: return launch_fast<NPT, RY, 0, 1>(ctx, a, mode, li);
+            case 3: return launch_fast<NPT, RY, 3, 1, 0>(ctx, a, mode, li);
+            default: return launch_fast<NPT, RY, 0, 1, 0>(ctx, a, mode, li);
         }
     }
+    if constexpr (NPT == 7 && RY <= 4) {
+        if (pf) return (nt & 3) == 3 ? launch_fast<NPT, RY, 3, 0, 1>(ctx, a, mode, li) : launch_fast<NPT, RY, 0, 0, 1>(ctx, a, mode, li);
+    }
     switch (nt & 3) {
-        case 1: return launch_fast<NPT, RY, 1, 0>(ctx, a, mode, li);
-        case 2: return launch_fast<NPT, RY, 2, 0>(ctx, a, mode, li);
-        case 3: return launch_fast<NPT, RY, 3, 0>(ctx, a, mode, li);
-        default: return launch_fast<NPT, RY, 0, 0>(ctx, a, mode, li);
+        case 1: return launch_fast<NPT, RY, 1, 0, 0>(ctx, a, mode, li);
+        case 2: return launch_fast<NPT, RY, 2, 0, 0>(ctx, a, mode, li);
+        case 3: return launch_fast<NPT, RY, 3, 0, 0>(ctx, a, mode, li);
+        default: return launch_fast<NPT, RY, 0, 0, 0>(ctx, a, mode, li);
     }
 }
 
 }  // namespace
 
-// small 3-D grids: CG_K1 / CG_K2 as one-round tiles (k_tile3d); a.g is the full single-slab grid with uniform Dirichlet boundary
+// 3-D grids: CG_K1 / CG_K2 / PLAIN as one-round tiles (k_tile3d); a.g is the full single-slab grid with uniform Dirichlet boundary.
+// Grids beyond L2 (more than 4 M nodes) take the XCD-aware order with non-temporal stores.
+static bool tile3d_xm(const GridDev& g) { return (long long)g.NX * g.NY * g.NZ > 4000000LL; }
 template <int NPT>
 static int launch_tile3d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     constexpr int RY = 2;
     const int ntx = (a.g.NX - 1 + 127) / 128;
     const int nty = (a.g.NY - 2 + RY - 1) / RY;
-    const long long G = (long long)ntx * ((nty + 3) / 4) * (a.g.NZ - 2);
+    const long long G = stencil_tile3d_grid(a.g);
     if (li) { li->grid = (int)G; li->block = 256; }
     if (G <= 0) return PDEGPU_OK;
-    if (mode == APPLY_CG_K1) hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K1>), dim3((unsigned)G), dim3(256), 0, ctx->stream, a, ntx, nty);
-    else hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K2>), dim3((unsigned)G), dim3(256), 0, ctx->stream, a, ntx, nty);
+    const dim3 grid((unsigned)G), blk(256);
+    if (tile3d_xm(a.g)) {
+        if (mode == APPLY_CG_K1) hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K1, 1>), grid, blk, 0, ctx->stream, a, ntx, nty);
+        else if (mode == APPLY_CG_K2) hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K2, 1>), grid, blk, 0, ctx->stream, a, ntx, nty);
+        else hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_PLAIN, 1>), grid, blk, 0, ctx->stream, a, ntx, nty);
+    } else {
+        if (mode == APPLY_CG_K1) hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K1, 0>), grid, blk, 0, ctx->stream, a, ntx, nty);
+        else if (mode == APPLY_CG_K2) hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_CG_K2, 0>), grid, blk, 0, ctx->stream, a, ntx, nty);
+        else hipLaunchKernelGGL((k_tile3d<NPT, RY, APPLY_PLAIN, 0>), grid, blk, 0, ctx->stream, a, ntx, nty);
+    }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }
 int stencil_tile3d(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    if (mode != APPLY_CG_K1 && mode != APPLY_CG_K2 && mode != APPLY_PLAIN) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "tile form: K1, K2 or PLAIN");
     if (a.npt == 27) return launch_tile3d<27>(ctx, a, mode, li);
     if (a.npt == 7) return launch_tile3d<7>(ctx, a, mode, li);
     return launch_tile3d<15>(ctx, a, mode, li);
 }
-// workgroups (= partials) the tile form would launch: the session uses it only when they fit the partial buffer
+// workgroups (= partials) the tile form launches
 long long stencil_tile3d_grid(const GridDev& g) {
-    const int ntx = (g.NX - 1 + 127) / 128, nty = (g.NY - 2 + 1) / 2;
-    return (long long)ntx * ((nty + 3) / 4) * (g.NZ - 2);
+    const int ntx = (g.NX - 1 + 127) / 128, nty = (g.NY - 2 + 1) / 2, nyg = (nty + 3) / 4;
+    if (tile3d_xm(g)) return 8LL * ntx * ((nyg + 7) / 8) * (g.NZ - 2);
+    return (long long)ntx * nyg * (g.NZ - 2);
 }
 
 
@@ -926,14 +1048,15 @@ GridDev stencil_flat2d_view(const GridDev& g) {
 
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
+    const int ry = mode_cfg(ctx, mode).ry;
     if (a.npt == 7) {
-        if (ctx->fast_ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
-        if (ctx->fast_ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);
-        if (ctx->fast_ry == 8) return launch_fast_nt<7, 8>(ctx, a, mode, li);
+        if (ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
+        if (ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);
+        if (ry == 8) return launch_fast_nt<7, 8>(ctx, a, mode, li);
         return launch_fast_nt<7, 4>(ctx, a, mode, li);
     }
-    if (ctx->fast_ry == 1) return launch_fast_nt<15, 1>(ctx, a, mode, li);
-    if (ctx->fast_ry == 2) return launch_fast_nt<15, 2>(ctx, a, mode, li);
+    if (ry == 1) return launch_fast_nt<15, 1>(ctx, a, mode, li);
+    if (ry == 2) return launch_fast_nt<15, 2>(ctx, a, mode, li);
     return launch_fast_nt<15, 4>(ctx, a, mode, li);
 }
 

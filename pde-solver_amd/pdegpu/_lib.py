@@ -100,6 +100,8 @@ SYMBOLS = {
     "pdegpu_el_session_plane_doubles": (C.c_int64, [_vp]),
     "pdegpu_el_session_plane_ptr": (_vp, [_vp, C.c_int, C.c_int, C.c_int64]),
     "pdegpu_el_session_get_u": (C.c_int, [_vp, _dp]),
+    "pdegpu_el_session_halo_buffer": (_vp, [_vp, C.c_int, C.c_int]),
+    "pdegpu_el_session_halo_pack": (C.c_int, [_vp, C.c_int]),
     "pdegpu_elasticity_postprocess": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp]),
     "pdegpu_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "pdegpu_session_destroy": (None, [_vp]),
@@ -111,6 +113,13 @@ SYMBOLS = {
     "pdegpu_session_residual": (C.c_int, [_vp]),
     "pdegpu_session_k1": (C.c_int, [_vp]),
     "pdegpu_session_k2": (C.c_int, [_vp]),
+    "pdegpu_session_can_split_k1": (C.c_int, [_vp]),
+    "pdegpu_session_k1_part": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_session_set_timing": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_session_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "pdegpu_session_step_rhs": (C.c_int, [_vp]),
+    "pdegpu_session_lift_norm": (C.c_int, [_vp]),
+    "pdegpu_session_reset_cg": (C.c_int, [_vp]),
     "pdegpu_session_reduce_local": (C.c_int, [_vp, C.c_int, C.c_int]),
     "pdegpu_session_flush": (C.c_int, [_vp]),
     "pdegpu_session_iterate": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(Stats)]),
@@ -210,3 +219,48 @@ def element_mode_from_env() -> int:
     if v == "q1":
         return ELEM_Q1
     raise ValueError(f"PDEGPU_ELEMENT must be p1split or q1, got {v!r}")
+
+
+# ---- output-volume policy ------------------------------------------------------------------------------------------------
+# The reference stores EVERY step (fenics_mcp_server.py:300-315, 694-696, 711-713); at the grid sizes this build solves that is
+# hundreds of GB (config 3 at the dispatcher's defaults: 201 states x 1.08 GB = 217 GB).  Policy: the host array may take at most
+# PDEGPU_MAX_OUTPUT_GB (default: half of the physical memory, at most 64 GB).  A request beyond it is strided automatically to the
+# smallest stride that fits (first and last state always kept) and the stride actually used is recorded in meta; with
+# PDEGPU_OUTPUT_POLICY=error it raises instead, naming snapshot_stride.
+def output_budget_bytes() -> int:
+    v = os.environ.get("PDEGPU_MAX_OUTPUT_GB")
+    if v:
+        return int(float(v) * 1e9)
+    try:
+        phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        phys = 16 << 30
+    return int(min(0.5 * phys, 64e9))
+
+
+def count_snapshots(num_steps: int, stride: int) -> int:
+    """states stored for steps 0 .. num_steps with `stride` (the last step is always stored) — pdegpu_heat_num_snapshots"""
+    return sum(1 for s in range(num_steps + 1) if s % stride == 0 or s == num_steps)
+
+
+def snapshot_policy(num_steps: int, n_nodes: int, requested_stride: int, steady: bool):
+    """-> (stride to use, meta additions).  Raises PdeGpuError when not even the first and last state fit, or when the request
+    does not fit and PDEGPU_OUTPUT_POLICY=error."""
+    req = max(1, int(requested_stride))
+    if steady:
+        return req, {"snapshot_stride": req}
+    budget = output_budget_bytes()
+    need = count_snapshots(num_steps, req) * n_nodes * 8
+    if need <= budget:
+        return req, {"snapshot_stride": req}
+    msg = (f"{count_snapshots(num_steps, req)} stored states x {n_nodes} nodes x 8 B = {need / 1e9:.1f} GB exceed the output budget "
+           f"of {budget / 1e9:.1f} GB (PDEGPU_MAX_OUTPUT_GB)")
+    if os.environ.get("PDEGPU_OUTPUT_POLICY", "auto").lower() == "error":
+        raise PdeGpuError(EINVAL, msg + "; pass snapshot_stride=k (or PDEGPU_SNAPSHOT_STRIDE) to keep every k-th state")
+    if 2 * n_nodes * 8 > budget:
+        raise PdeGpuError(EINVAL, msg + "; not even the first and the last state fit")
+    stride = req
+    while count_snapshots(num_steps, stride) * n_nodes * 8 > budget:
+        stride += 1
+    return stride, {"snapshot_stride": stride, "snapshot_stride_requested": req,
+                    "snapshot_policy": f"auto-strided: {msg}; every {stride}-th state (and the last) is kept"}

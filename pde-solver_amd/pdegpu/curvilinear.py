@@ -35,7 +35,9 @@ def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady,
     h.bc_mode = bc_mode
     for r in range(3):
         h.bc_value[r], h.bc_present[r] = float(bc_value[r]), int(bc_present[r])
-    h.snapshot_stride = int(snapshot_stride if snapshot_stride is not None else os.environ.get("PDEGPU_SNAPSHOT_STRIDE", 1))
+    stride, stride_meta = L.snapshot_policy(int(num_steps), N, int(snapshot_stride if snapshot_stride is not None else
+                                                                   os.environ.get("PDEGPU_SNAPSHOT_STRIDE", 1)), bool(steady))
+    h.snapshot_stride = stride
     h.rtol = float(rtol if rtol is not None else os.environ.get("PDEGPU_RTOL", 1e-10))
     h.max_iter = int(max_iter if max_iter is not None else os.environ.get("PDEGPU_MAX_ITER", 400000))
     h.fast_path = 0
@@ -43,7 +45,9 @@ def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady,
     values, times = np.empty((n_snap, N)), np.empty(n_snap)
     st = L.Stats()
     L.check(ctx, lib.pdegpu_heat_solve_weighted(ctx, grid, w, h, L.dptr(values), L.dptr(times), st))
-    return values, times, st.as_dict()
+    d = st.as_dict()
+    d["snapshot_meta"] = stride_meta
+    return values, times, d
 
 
 def _axes(n, origin, lengths):
@@ -56,6 +60,7 @@ def _meta(coord_sys, geom, r_inner, r_outer, source_type, source_value, steady, 
     m.update(extra)
     m.update({"source_type": source_type, "source_value": source_value, "steady": steady})
     m.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"])})
+    m.update(st.get("snapshot_meta", {"snapshot_stride": 1}))
     return m
 
 

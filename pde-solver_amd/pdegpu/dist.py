@@ -8,7 +8,11 @@ RCCL over xGMI) for the only two exchanges the path has —
     xGMI links to the slab neighbours;
   * dot products: one 8-byte all-reduce after K1 (p.q) and one after K2 (r.r).  They are latency-bound, the
     result stays on the device, alpha / beta are formed inside the kernels: the host never synchronises in
-    the loop.
+    the loop;
+  * overlap: the exchange is posted first, K1 then runs on the owned planes whose stencil touches no ghost plane
+    (engine.k1_part(0)) while the planes travel (RCCL works on its own stream), and the one or two planes next to the
+    ghosts follow once the transfer has completed (engine.k1_part(1)).  Elasticity sends ONE packed message per
+    neighbour (r and p, 3 components each).
 
 The compute engine is abstract so that the same driver runs (a) the HIP session through the C-ABI on GPUs and
 (b) under the `gloo` backend on CPU tensors in the test-suite (tests/ supply a numpy engine built on the
@@ -52,6 +56,7 @@ class GpuSlabEngine:
         self.lib = L.load_library()
         self.device = device
         self.stream = stream
+        self.grid = grid
         self.k0, self.nk = k0, nk
         self.ctx = C.c_void_p()
         sp = C.c_void_p(stream.cuda_stream) if stream is not None and stream.cuda_stream else None
@@ -84,11 +89,45 @@ class GpuSlabEngine:
     def k1(self):
         self._ck(self.lib.pdegpu_session_k1(self.s))
 
+    def k1_part(self, part: int):
+        """part 0: planes away from the ghosts (halo exchange in flight); part 1: the planes next to them + the p.q sum"""
+        self._ck(self.lib.pdegpu_session_k1_part(self.s, part))
+
+    def can_split_k1(self) -> bool:
+        return bool(self.lib.pdegpu_session_can_split_k1(self.s))
+
     def k2(self):
         self._ck(self.lib.pdegpu_session_k2(self.s))
 
     def flush(self):
         self._ck(self.lib.pdegpu_session_flush(self.s))
+
+    # transient steps (the time loop of _solve_heat_3d_raw distributed over slabs)
+    def step_rhs(self):
+        self._ck(self.lib.pdegpu_session_step_rhs(self.s))
+
+    def lift_norm(self):
+        self._ck(self.lib.pdegpu_session_lift_norm(self.s))
+
+    def reset_cg(self):
+        self._ck(self.lib.pdegpu_session_reset_cg(self.s))
+
+    def x_halo_tensors(self, which: int):
+        return [self.plane_tensor(VEC_X, which)]
+
+    def set_timing(self, on: bool):
+        self._ck(self.lib.pdegpu_session_set_timing(self.s, 1 if on else 0))
+
+    def get_stats(self, stats):
+        self._ck(self.lib.pdegpu_session_get_stats(self.s, stats))
+
+    def owned_x(self):
+        """solution on the owned planes, numpy [nk, ny+1, nx+1] (synchronises)"""
+        import numpy as np
+        g = self.grid
+        out = np.empty((self.nk, g.n[1] + 1, g.n[0] + 1))
+        self._ck(self.lib.pdegpu_session_get_x(self.s, L.dptr(out)))
+        return out
 
     def local_to_global(self, which: int):
         pass            # residual / k1 / k2 already left the slab's sum in the global slot (no extra device op)
@@ -189,6 +228,24 @@ class GpuElasticitySlabEngine:
     def halo_tensors(self, which: int):
         return [self.plane_tensor(v, c, which) for v in (1, 2) for c in range(3)]       # r and p, 3 components each (z = D^-1 r is formed by the p-update)
 
+    # one contiguous message per neighbour (the driver prefers this protocol when an engine offers it)
+    def halo_pack(self):
+        self._ck(self.lib.pdegpu_el_session_halo_pack(self.s, 0))
+
+    def halo_unpack(self):
+        self._ck(self.lib.pdegpu_el_session_halo_pack(self.s, 1))
+
+    def halo_buffer(self, which: int, side: int) -> torch.Tensor:
+        """which 0 send / 1 receive; side 0 lower / 1 upper neighbour: [r0 r1 r2 p0 p1 p2] x plane, contiguous"""
+        key = ("buf", which, side)
+        t = self._planes.get(key)
+        if t is None:
+            ptr = self.lib.pdegpu_el_session_halo_buffer(self.s, which, side)
+            if not ptr:
+                raise L.PdeGpuError(L.EHIP, "halo buffers could not be allocated")
+            t = self._planes[key] = torch.as_tensor(_DevArray(ptr, 6 * self.plane), device=f"cuda:{self.device}")
+        return t
+
     def global_slots(self, which: int):
         return (0, 1) if which == 0 else (1, 3)          # p.q | r.z and r.r as one 16-byte message
 
@@ -211,8 +268,9 @@ class GpuElasticitySlabEngine:
 class SlabCG:
     """CG over a 1-D slab decomposition.  `engine` owns planes [k0, k0+nk) plus one ghost plane per side."""
 
-    def __init__(self, engine, rank: int, world: int, group=None):
+    def __init__(self, engine, rank: int, world: int, group=None, overlap: bool = True):
         self.e, self.rank, self.world, self.group = engine, rank, world, group
+        self.overlap = overlap
         self.iterations = 0
 
     # ---- the two exchanges -------------------------------------------------------------------------
@@ -223,25 +281,50 @@ class SlabCG:
         vecs = (VEC_R, VEC_P) if getattr(self.e, "needs_p_halo", lambda: True)() else (VEC_R,)
         return [self.e.plane_tensor(v, which) for v in vecs]
 
-    def exchange_halos(self):
-        """first / last owned plane -> the neighbours' ghost planes, all vectors in ONE batch (one ncclGroup)"""
-        if self.world == 1:
-            return
+    def _post(self, lo_pairs, hi_pairs):
+        """post sends / receives with the slab neighbours as ONE batch (one ncclGroup); returns the pending work"""
         ops: List[dist.P2POp] = []
         lo, hi = self.rank - 1, self.rank + 1
-        nk = self.e.nk
         if lo >= 0:
-            for t, (snd, rcv) in enumerate(zip(self._halo(0), self._halo(-1))):
+            for t, (snd, rcv) in enumerate(lo_pairs):
                 ops.append(dist.P2POp(dist.isend, snd, lo, self.group, tag=2 * t))
                 ops.append(dist.P2POp(dist.irecv, rcv, lo, self.group, tag=2 * t + 1))
         if hi < self.world:
-            for t, (snd, rcv) in enumerate(zip(self._halo(nk - 1), self._halo(nk))):
+            for t, (snd, rcv) in enumerate(hi_pairs):
                 ops.append(dist.P2POp(dist.isend, snd, hi, self.group, tag=2 * t + 1))
                 ops.append(dist.P2POp(dist.irecv, rcv, hi, self.group, tag=2 * t))
-        if ops and ops[0].tensor.is_cuda and dist.get_backend(self.group) == "gloo":
-            return self._exchange_staged(ops)
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()          # stream-ordered for NCCL (no host block); completes the copy for gloo
+        if not ops:
+            return []
+        if ops[0].tensor.is_cuda and dist.get_backend(self.group) == "gloo":
+            self._exchange_staged(ops)
+            return []
+        return dist.batch_isend_irecv(ops)
+
+    def exchange_begin(self, halo=None):
+        """first / last owned plane -> the neighbours' ghost planes.  Returns a token for exchange_end; between the two calls
+        the engine may compute on everything that does not read a ghost plane."""
+        if self.world == 1:
+            return None
+        e, nk = self.e, self.e.nk
+        if halo is None and hasattr(e, "halo_pack"):          # packed protocol: one contiguous message per neighbour
+            e.halo_pack()
+            works = self._post([(e.halo_buffer(0, 0), e.halo_buffer(1, 0))], [(e.halo_buffer(0, 1), e.halo_buffer(1, 1))])
+            return ("packed", works)
+        halo = halo or self._halo
+        works = self._post(list(zip(halo(0), halo(-1))), list(zip(halo(nk - 1), halo(nk))))
+        return ("planes", works)
+
+    def exchange_end(self, token):
+        if token is None:
+            return
+        kind, works = token
+        for w in works:
+            w.wait()          # stream-ordered for NCCL (the compute stream waits, the host does not); completes the copy for gloo
+        if kind == "packed":
+            self.e.halo_unpack()
+
+    def exchange_halos(self, halo=None):
+        self.exchange_end(self.exchange_begin(halo))
 
     def _exchange_staged(self, ops):
         """gloo cannot send device memory: stage the planes through host buffers.  Only for rehearsing the multi-rank
@@ -288,17 +371,158 @@ class SlabCG:
         self.iterations = 0
 
     def iterate(self, iters: int):
-        # K1 needs r_n (z_n) and p_{n-1} on the ghost planes; engines whose K1 maintains p there itself only exchange r
+        # K1 needs r_n (z_n) and p_{n-1} on the ghost planes; engines whose K1 maintains p there itself only exchange r.
+        # Engines that can split K1 run its bulk while the planes travel.
+        split = self.overlap and hasattr(self.e, "k1_part")
         for _ in range(iters):
-            self.exchange_halos()
-            self.e.k1()
+            if split:
+                token = self.exchange_begin()
+                self.e.k1_part(0)
+                self.exchange_end(token)
+                self.e.k1_part(1)
+            else:
+                self.exchange_halos()
+                self.e.k1()
             self.allreduce(0)
             self.e.k2()
             self.allreduce(1)
         self.iterations += iters
 
+    # ---- one backward-Euler step on slabs (fenics_mcp_server.py:702-716) ---------------------------
+    def begin_step(self) -> float:
+        """x holds u^n on the owned planes: exchange its ghost planes, b = M (u^n + dt f), reference norm, r = P (b - A x).
+        Returns ||P (b - A g)||^2 (host value; the one synchronisation of the step set-up)."""
+        e = self.e
+        self.exchange_halos(getattr(e, "x_halo_tensors"))
+        e.step_rhs()
+        e.lift_norm()
+        self.allreduce(1)
+        bnorm2 = e.rr()
+        e.reset_cg()
+        e.residual()
+        self.allreduce(1)
+        return bnorm2
+
+    def solve(self, bnorm2: float, rtol: float, max_iter: int = 100000, first_chunk: int = 8):
+        """iterate until r.r <= rtol^2 bnorm2 (host polls once per chunk); returns (iterations, relative residual)"""
+        target = rtol * rtol * bnorm2
+        rr, it, chunk = self.e.rr(), 0, first_chunk
+        while rr > target and it < max_iter:
+            n = min(chunk, max_iter - it)
+            self.iterate(n)
+            it += n
+            rr = self.e.rr()
+            chunk = min(2 * chunk, 64)
+        self.finish()
+        return it, (rr / bnorm2) ** 0.5 if bnorm2 > 0 else rr ** 0.5
+
     def finish(self):
         self.e.flush()
+
+
+def gather_slabs(local, n_planes: int, rank: int, world: int, group=None, device: int = 0):
+    """owned planes of every rank -> rank 0, as fp64 tensors (no pickling): `local` is numpy [nk, ...]; returns the
+    concatenation [n_planes, ...] on rank 0 and None elsewhere.  Slabs differ by at most one plane, so every rank sends a
+    buffer of the largest slab (dist.gather needs equal sizes)."""
+    import numpy as np
+    if world == 1:
+        return local
+    counts = [slab_range(n_planes, world, r)[1] for r in range(world)]
+    nmax = max(counts)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device(f"cuda:{device}") if on_gpu else torch.device("cpu")
+    buf = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=torch.float64, device=dev)
+    buf[: local.shape[0]].copy_(torch.from_numpy(np.ascontiguousarray(local)))
+    recv = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, recv, dst=0, group=group)
+    if rank != 0:
+        return None
+    return np.concatenate([recv[r][: counts[r]].cpu().numpy() for r in range(world)], axis=0)
+
+
+def longest_axis_last(n_cells, lengths):
+    """Permutation that makes the axis with the most cells the slowest one (z): the slabs then cut the longest axis and the halo
+    planes are the smallest faces of the box (config 4, 1024 x 512 x 512: 513 x 513 planes instead of 1025 x 513).  The P1 split
+    of a box (six Kuhn tetrahedra around the main diagonal) and a uniform Dirichlet boundary are invariant under a relabelling
+    of the axes, so only n and L are permuted.  Returns (perm, n', L') with n'[i] = n[perm[i]]."""
+    ax = max(range(3), key=lambda a: (n_cells[a], a))
+    perm = [a for a in range(3) if a != ax] + [ax]
+    return perm, tuple(n_cells[a] for a in perm), tuple(lengths[a] for a in perm)
+
+
+def solve_heat_slabs(n_cells, lengths, diffusivity: float, T_boundary: float, T_initial: float = 0.0, dt: float = 0.0,
+                     num_steps: int = 0, steady: bool = False, source: float = 0.0, rtol: float = 1e-10, max_iter: int = 100000,
+                     snapshot_stride: int = 1, group=None, engine_factory=None, permute: bool = True):
+    """`_solve_heat_3d_raw` (box, uniform Dirichlet value; fenics_mcp_server.py:475-762) over the ranks of the default process
+    group, one slab per GPU: the backward-Euler loop (:702-716) with one x-halo exchange per step, the CG of every step through
+    SlabCG.  Rank 0 returns {"values": [n_snap, nz+1, ny+1, nx+1] in the caller's axis order, "times", "iterations"}; the other
+    ranks the iteration counts only.  engine_factory(grid_n, grid_L, heat_kwargs, k0, nk) -> engine replaces the HIP session
+    (the CPU test-suite passes the numpy engine)."""
+    import numpy as np
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    perm = [0, 1, 2]
+    n_p, L_p = tuple(n_cells), tuple(lengths)
+    if permute:
+        perm, n_p, L_p = longest_axis_last(n_cells, lengths)
+    k0, nk = slab_range(n_p[2] + 1, world, rank)
+    hk = dict(kappa=diffusivity, dt=dt, steady=steady, source=source, T_boundary=T_boundary)
+    local = 0
+    stream = None
+    if engine_factory is not None:
+        eng = engine_factory(n_p, L_p, hk, k0, nk)
+    else:
+        local = int(L.os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+        if world > 1 and dist.get_backend(group) == "gloo":
+            local %= torch.cuda.device_count()
+        grid = L.make_grid(3, n_p, L_p)
+        heat = L.Heat()
+        heat.kappa, heat.dt, heat.steady, heat.source = diffusivity, dt if not steady else 0.0, 1 if steady else 0, source
+        heat.bc_mode, heat.fast_path = L.BC_UNIFORM, 1
+        heat.bc_present[0], heat.bc_value[0] = 1, T_boundary
+        stream = torch.cuda.Stream(device=local)
+        torch.cuda.set_device(local)
+        eng = GpuSlabEngine(grid, heat, k0, nk, local, stream)
+
+    def run():
+        cg = SlabCG(eng, rank, world, group)
+        snaps, times, iters = [], [], []
+
+        def snapshot(t):
+            part = gather_slabs(eng.owned_x(), n_p[2] + 1, rank, world, group, local)
+            if rank == 0:
+                # back to the caller's axis order: array axes are (z', y', x') = (perm[2], perm[1], perm[0]) of the original
+                src = [2 - perm[2], 2 - perm[1], 2 - perm[0]]          # original array axis held by each current axis
+                snaps.append(np.ascontiguousarray(np.transpose(part, np.argsort(src))))
+                times.append(t)
+
+        if steady:
+            cg.start(0.0)
+            bnorm2 = eng.rr()
+            it, _ = cg.solve(bnorm2, rtol, max_iter)
+            iters.append(it)
+            snapshot(0.0)
+        else:
+            eng.begin(T_initial)
+            snapshot(0.0)
+            for step in range(1, num_steps + 1):
+                bnorm2 = cg.begin_step()
+                it, _ = cg.solve(bnorm2, rtol, max_iter)
+                iters.append(it)
+                if step % snapshot_stride == 0 or step == num_steps:
+                    snapshot(step * dt)
+        out = {"iterations": iters}
+        if rank == 0:
+            out.update(values=np.stack(snaps), times=np.array(times))
+        return out
+
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            out = run()
+            eng.close()
+    else:
+        out = run()
+    return out
 
 
 def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int = 400000, group=None):
@@ -327,14 +551,11 @@ def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int 
             rr = eng.rr()                       # the only host synchronisation: once per chunk
             chunk = min(2 * chunk, 256)
         cg.finish()
-        u_local = eng.get_u((nx + 1) * (ny + 1))
-        parts = [u_local]
-        if world > 1:
-            parts = [None] * world
-            dist.all_gather_object(parts, u_local, group=group)
+        u_local = eng.get_u((nx + 1) * (ny + 1)).reshape(nk, (nx + 1) * (ny + 1), 3)
+        u_all = gather_slabs(u_local, nz + 1, rank, world, group, local)
         out = {"iterations": it, "rel_residual": (rr / rr0) ** 0.5 if rr0 > 0 else 0.0}
         if rank == 0:
-            u = np.ascontiguousarray(np.concatenate(parts, axis=0))
+            u = np.ascontiguousarray(u_all.reshape(-1, 3))
             field = np.empty(u.shape[0])
             ctx = eng.ctx
             L.check(ctx, eng.lib.pdegpu_elasticity_postprocess(ctx, grid, el, L.dptr(u), L.dptr(field)))

@@ -44,13 +44,17 @@ def run_heat(dim, n, Ls, *, kappa, dt, num_steps, steady, source_type, source_va
     for r in range(3):
         h.bc_value[r] = float(bc_value[r])
         h.bc_present[r] = int(bc_present[r])
-    h.snapshot_stride = int(snapshot_stride if snapshot_stride is not None else _env_int("PDEGPU_SNAPSHOT_STRIDE", 1))
     h.rtol = float(rtol if rtol is not None else _env_float("PDEGPU_RTOL", 1e-10))
     h.max_iter = int(max_iter if max_iter is not None else _env_int("PDEGPU_MAX_ITER", 200000))
     h.fast_path = 1 if fast_path else 0
     N = int(lib.pdegpu_grid_num_nodes(grid))
     if N < 0:
         raise L.PdeGpuError(L.EINVAL, f"invalid grid dim={dim} n={tuple(n)} (every axis needs >= 1 cell)")
+    # output volume: the stride actually used (argument > PDEGPU_SNAPSHOT_STRIDE > 1, widened when the states would not fit the host
+    # budget) travels back in the stats dict and is what meta records
+    stride, stride_meta = L.snapshot_policy(int(num_steps), N, snapshot_stride if snapshot_stride is not None else
+                                            _env_int("PDEGPU_SNAPSHOT_STRIDE", 1), bool(steady))
+    h.snapshot_stride = stride
 
     u0 = None
     if steady:
@@ -74,14 +78,17 @@ def run_heat(dim, n, Ls, *, kappa, dt, num_steps, steady, source_type, source_va
     stats = L.Stats()
     L.check(ctx, lib.pdegpu_heat_solve(ctx, grid, h, L.dptr(u0) if u0 is not None else None, L.dptr(values),
                                        L.dptr(times), stats))
-    return values, times, stats.as_dict()
+    st = stats.as_dict()
+    st["snapshot_meta"] = stride_meta
+    return values, times, st
 
 
-def _extra_meta(stats, element_mode, stride):
+def _extra_meta(stats, element_mode):
     """Build-side additions go into meta only."""
-    return {"backend": "pdegpu-hip-gfx950", "element_mode": "q1" if element_mode == L.ELEM_Q1 else "p1split",
-            "cg_iterations": int(stats["cg_iterations"]), "snapshot_stride": int(stride),
-            "solver_path": stats["path"]}
+    m = {"backend": "pdegpu-hip-gfx950", "element_mode": "q1" if element_mode == L.ELEM_Q1 else "p1split",
+         "cg_iterations": int(stats["cg_iterations"]), "solver_path": stats["path"]}
+    m.update(stats.get("snapshot_meta", {"snapshot_stride": 1}))
+    return m
 
 
 def _solve_heat_1d_raw(length: float, nx: int, diffusivity: float, T_left: float, T_right: float, T_initial: float,
@@ -98,7 +105,7 @@ def _solve_heat_1d_raw(length: float, nx: int, diffusivity: float, T_left: float
                                  bc_value=(T_left, T_right, 0.0), bc_present=(1, 1, 0), **opts)
     meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cartesian", "length": length,
             "source_type": source_type, "source_value": source_value, "steady": steady}
-    meta.update(_extra_meta(st, em, opts.get("snapshot_stride") or 1))
+    meta.update(_extra_meta(st, em))
     return TimeSeriesField(coords=grid_coords(1, (nx,), (length,)), values=values, times=times, dim=1, meta=meta)
 
 
@@ -115,7 +122,7 @@ def _solve_heat_2d_raw(Lx: float, Ly: float, nx: int, ny: int, diffusivity: floa
                                  bc_value=(T_boundary, 0.0, 0.0), bc_present=(1, 0, 0), **opts)
     meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cartesian", "Lx": Lx, "Ly": Ly,
             "source_type": source_type, "source_value": source_value, "steady": steady}
-    meta.update(_extra_meta(st, em, opts.get("snapshot_stride") or 1))
+    meta.update(_extra_meta(st, em))
     return TimeSeriesField(coords=grid_coords(2, (nx, ny), (Lx, Ly)), values=values, times=times, dim=2, meta=meta)
 
 
@@ -165,6 +172,6 @@ def _solve_heat_3d_raw(Lx: float, Ly: float, Lz: float, nx: int, ny: int, nz: in
     else:
         meta["T_boundary"] = T_boundary
     meta["diffusivity"] = diffusivity                                                   # :753
-    meta.update(_extra_meta(st, em, opts.get("snapshot_stride") or 1))
+    meta.update(_extra_meta(st, em))
     return TimeSeriesField(coords=grid_coords(3, (nx, ny, nz), (Lx, Ly, Lz)), values=values, times=times, dim=3,
                            meta=meta)

@@ -11,11 +11,14 @@ SC_PQ_LOCAL, SC_RR_LOCAL, SC_PQ, SC_RR, SC_RR_PREV = 0, 1, 2, 3, 4
 
 
 class NumpySlabEngine:
-    def __init__(self, n, Ls, kappa, source, T_boundary, k0, nk):
+    def __init__(self, n, Ls, kappa, source, T_boundary, k0, nk, dt=None):
+        """dt = None: steady system kappa K u = f m;  dt > 0: one backward-Euler step matrix M + dt kappa K (15-point)"""
         self.n, self.k0, self.nk = n, k0, nk
         self.NX, self.NY, self.NZ = n[0] + 1, n[1] + 1, n[2] + 1
         h = [Ls[r] / n[r] for r in range(3)]
-        self.w = cg_port.p1_weights(h, 0.0, kappa)
+        self.w = cg_port.p1_weights(h, 0.0, kappa) if dt is None else cg_port.p1_weights(h, 1.0, dt * kappa)
+        self.wM = cg_port.p1_weights(h, 1.0, 0.0)
+        self.dt, self.source = dt, source
         self.rhs_const = source * h[0] * h[1] * h[2]
         self.Tb = T_boundary
         shape = (nk + 2, self.NY, self.NX)                       # planes -1 .. nk
@@ -32,13 +35,18 @@ class NumpySlabEngine:
         self.own = slice(1, nk + 1)
 
     # --- helpers ---
-    def _apply(self, v):
-        """A v on the owned planes (needs the ghost planes of v), zero on Dirichlet rows"""
-        w = self.w
+    def _apply(self, v, w=None):
+        """A v on the owned planes (needs the ghost planes of v), zero on Dirichlet rows; 15-point when the diagonal weights
+        +-(1,1,0), +-(1,0,1), +-(0,1,1), +-(1,1,1) are non-zero"""
+        w = self.w if w is None else w
         c = v[1:-1, 1:-1, 1:-1]
         out = np.zeros((self.nk, self.NY, self.NX))
-        out[:, 1:-1, 1:-1] = (w[0] * c + w[1] * (v[1:-1, 1:-1, :-2] + v[1:-1, 1:-1, 2:]) +
-                              w[2] * (v[1:-1, :-2, 1:-1] + v[1:-1, 2:, 1:-1]) + w[3] * (v[:-2, 1:-1, 1:-1] + v[2:, 1:-1, 1:-1]))
+        acc = (w[0] * c + w[1] * (v[1:-1, 1:-1, :-2] + v[1:-1, 1:-1, 2:]) +
+               w[2] * (v[1:-1, :-2, 1:-1] + v[1:-1, 2:, 1:-1]) + w[3] * (v[:-2, 1:-1, 1:-1] + v[2:, 1:-1, 1:-1]))
+        if np.any(np.asarray(w[4:]) != 0.0):
+            acc = acc + (w[4] * (v[1:-1, 2:, 2:] + v[1:-1, :-2, :-2]) + w[5] * (v[2:, 1:-1, 2:] + v[:-2, 1:-1, :-2]) +
+                         w[6] * (v[2:, 2:, 1:-1] + v[:-2, :-2, 1:-1]) + w[7] * (v[2:, 2:, 2:] + v[:-2, :-2, :-2]))
+        out[:, 1:-1, 1:-1] = acc
         out[~self.free[self.own]] = 0.0
         return out
 
@@ -78,6 +86,79 @@ class NumpySlabEngine:
         self.q.numpy()[self.own] = q
         self.pcur ^= 1
         self.scal[SC_PQ_LOCAL] = float((pn[self.own] * q).sum())
+
+    def k1_part(self, part):
+        """the split K1 of the HIP session: part 0 may only touch planes whose stencil reads no ghost plane — checked here by
+        running it on copies of r and p whose ghost planes are NaN (the receives may land in the real ones meanwhile)"""
+        if part == 0:
+            self._pq_parts = 0.0
+            pq, rr, rr_prev = (float(self.scal[i]) for i in (SC_PQ, SC_RR, SC_RR_PREV))
+            self._alpha_prev = rr_prev / pq if (pq > 0 and rr_prev > 0) else 0.0
+            self._beta = rr / rr_prev if rr_prev > 0 else 0.0
+            lo = 1 if self.k0 > 0 else 0
+            hi = 1 if self.k0 + self.nk < self.NZ else 0
+            r, p_old = self.r.numpy().copy(), self.p[self.pcur].numpy().copy()
+            if lo:
+                r[0] = p_old[0] = np.nan
+            if hi:
+                r[-1] = p_old[-1] = np.nan
+            self._k1_planes(lo, self.nk - hi, r, p_old)
+            self._edges = ([0] if lo else []) + ([self.nk - 1] if hi and not (lo and self.nk == 1) else [])
+            return
+        for lk in self._edges:
+            self._k1_planes(lk, lk + 1, self.r.numpy(), self.p[self.pcur].numpy())
+        self.pcur ^= 1
+        self.scal[SC_PQ_LOCAL] = self._pq_parts
+
+    def _k1_planes(self, a, b, r, p_old):
+        """K1 on the local planes [a, b)"""
+        if b <= a:
+            return
+        sl = slice(a, b + 2)                                     # planes a-1 .. b of the ghosted arrays
+        pn = r[sl] + self._beta * p_old[sl]
+        sub = NumpySlabEngine.__new__(NumpySlabEngine)
+        sub.w, sub.nk, sub.NY, sub.NX = self.w, b - a, self.NY, self.NX
+        sub.free, sub.own = self.free[sl], slice(1, b - a + 1)
+        q = sub._apply(pn)
+        own = slice(a + 1, b + 1)
+        assert np.isfinite(q).all(), "part 0 of the split K1 read a ghost plane"
+        if self._alpha_prev != 0.0:
+            self.x.numpy()[own] += self._alpha_prev * p_old[own]
+        self.p[1 - self.pcur].numpy()[own] = pn[1:-1]
+        self.q.numpy()[own] = q
+        self._pq_parts += float((pn[1:-1] * q).sum())
+
+    # transient steps (pdegpu_session_step_rhs / lift_norm / reset_cg)
+    def step_rhs(self):
+        u = self.x.numpy() + self.dt * self.source
+        u[~self.inside] = 0.0
+        w = self.wM
+        v = u
+        acc = (w[0] * v[1:-1, 1:-1, 1:-1] + w[1] * (v[1:-1, 1:-1, :-2] + v[1:-1, 1:-1, 2:]) +
+               w[2] * (v[1:-1, :-2, 1:-1] + v[1:-1, 2:, 1:-1]) + w[3] * (v[:-2, 1:-1, 1:-1] + v[2:, 1:-1, 1:-1]) +
+               w[4] * (v[1:-1, 2:, 2:] + v[1:-1, :-2, :-2]) + w[5] * (v[2:, 1:-1, 2:] + v[:-2, 1:-1, :-2]) +
+               w[6] * (v[2:, 2:, 1:-1] + v[:-2, :-2, 1:-1]) + w[7] * (v[2:, 2:, 2:] + v[:-2, :-2, :-2]))
+        b = np.zeros(self.b.shape)
+        b[1:-1, 1:-1, 1:-1] = acc
+        b[~self.free] = 0.0
+        self.b.copy_(torch.from_numpy(b))
+
+    def lift_norm(self):
+        g = np.where(self.free, 0.0, self.Tb)
+        g[~self.inside] = 0.0
+        r = self.b.numpy()[self.own] - self._apply(g)
+        r[~self.free[self.own]] = 0.0
+        self._reduce_rr(float((r * r).sum()))
+
+    def reset_cg(self):
+        self.scal.zero_()
+        self.pcur = 0
+
+    def x_halo_tensors(self, which):
+        return [self.plane_tensor(0, which)]
+
+    def rr(self):
+        return float(self.scal[SC_RR])
 
     def k2(self):
         pq, rr = float(self.scal[SC_PQ]), float(self.scal[SC_RR])

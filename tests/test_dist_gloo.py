@@ -15,6 +15,7 @@ import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
 N_CELLS, LS, KAPPA, SRC, TB = (7, 6, 11), (1.0, 0.8, 1.5), 1.3, 2.0, 0.5
+T_CELLS, T_LS = (9, 5, 6), (1.5, 0.7, 1.0)          # longest axis first: solve_heat_slabs must cut it (axis permutation)
 ITERS = 120
 
 
@@ -22,6 +23,28 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _worker_transient(rank, world, port, outdir):
+    """solve_heat_slabs (the backward-Euler loop over slabs, axis permutation included) with the numpy engine under gloo"""
+    for p in (ROOT, ROOT / "pde-solver_amd", ROOT / "tests"):
+        if str(p) not in sys.path:
+            sys.path.insert(0, str(p))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pdegpu.dist import solve_heat_slabs
+        from slab_engine_numpy import NumpySlabEngine
+
+        def factory(n, Ls, hk, k0, nk):
+            return NumpySlabEngine(n, Ls, hk["kappa"], hk["source"], hk["T_boundary"], k0, nk, dt=None if hk["steady"] else hk["dt"])
+        out = solve_heat_slabs(T_CELLS, T_LS, KAPPA, TB, T_initial=3.0, dt=0.02, num_steps=3, source=SRC, rtol=1e-12,
+                               engine_factory=factory)
+        if rank == 0:
+            np.savez(Path(outdir) / "transient.npz", values=out["values"], times=out["times"], iters=np.array(out["iterations"]))
+    finally:
+        dist.destroy_process_group()
 
 
 def _worker(rank, world, port, outdir):
@@ -74,6 +97,28 @@ def test_slab_cg_world_1_2_3_agree_and_match_oracle(tmp_path):
         assert np.allclose(rrw[:2], rr1[:2], rtol=1e-11)           # same iterates up to summation order
         assert np.abs(xw - ref).max() < 1e-9 * np.abs(ref).max()
         assert np.abs(xw - x1).max() < 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_transient_heat_over_slabs_matches_oracle(tmp_path, world):
+    """the distributed time loop (x-halo exchange per step, step right-hand side, reference norm, CG, gather to rank 0, axes
+    permuted so that the slabs cut the longest axis) against the oracle's assembled backward-Euler solve"""
+    from oracle import fem_p1 as o
+    mp.spawn(_worker_transient, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "transient.npz")
+    ref = o.solve_heat_3d(*T_LS, *T_CELLS, KAPPA, TB, 3.0, 0.02, 3, source_type="constant", source_value=SRC)
+    assert got["values"].shape == (4, T_CELLS[2] + 1, T_CELLS[1] + 1, T_CELLS[0] + 1)
+    assert np.allclose(got["times"], ref.times)
+    err = np.abs(got["values"].reshape(4, -1) - ref.values).max()
+    assert err < 1e-9 * np.abs(ref.values).max(), err
+
+
+def test_longest_axis_last():
+    from pdegpu.dist import longest_axis_last
+    assert longest_axis_last((1024, 512, 512), (2.0, 1.0, 1.0)) == ([1, 2, 0], (512, 512, 1024), (1.0, 1.0, 2.0))
+    assert longest_axis_last((512, 512, 512), (1.0, 1.0, 1.0))[0] == [0, 1, 2]
+    assert longest_axis_last((256, 64, 64), (1.0, 0.25, 0.25))[1] == (64, 64, 256)
 
 
 def test_slab_engine_matches_c_port():

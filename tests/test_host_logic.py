@@ -273,3 +273,35 @@ def test_weighted_rows_with_composite_core_match_oracle(lib):
     K, M, load = o.assemble_weighted(c, cells, "rcyl", np.where(core, ratio, 1.0))
     assert np.allclose(rK[:, 0], K.diagonal(), rtol=1e-12) and np.allclose(rM[:, 0], M.diagonal(), rtol=1e-12)
     assert np.allclose(rK.sum(axis=1), 0.0, atol=1e-12 * np.abs(rK).max())
+
+
+# ---- output-volume policy (the reference stores every step: fenics_mcp_server.py:694-696, 711-713) --------------------------
+def test_snapshot_policy_keeps_a_request_that_fits(monkeypatch):
+    from pdegpu import _lib as L
+    monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "1")
+    assert L.snapshot_policy(200, 1001, 1, False) == (1, {"snapshot_stride": 1})
+    assert L.snapshot_policy(200, 10 ** 9, 7, True) == (7, {"snapshot_stride": 7})          # steady: one state
+
+
+def test_snapshot_policy_auto_strides_config3_defaults(monkeypatch):
+    """config 3 at the dispatcher's defaults: 201 states x 513^3 nodes = 217 GB -> strided to fit, recorded for meta"""
+    from pdegpu import _lib as L
+    monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "64")
+    monkeypatch.delenv("PDEGPU_OUTPUT_POLICY", raising=False)
+    N = 513 ** 3
+    stride, meta = L.snapshot_policy(200, N, 1, False)
+    assert L.count_snapshots(200, stride) * N * 8 <= 64e9 < L.count_snapshots(200, stride - 1) * N * 8
+    assert meta["snapshot_stride"] == stride and meta["snapshot_stride_requested"] == 1 and "217" in meta["snapshot_policy"]
+    assert L.count_snapshots(200, 1) == 201 and L.count_snapshots(10, 4) == 4            # 0, 4, 8, 10
+
+
+def test_snapshot_policy_error_mode_and_hopeless_requests(monkeypatch):
+    from pdegpu import _lib as L
+    monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "8")
+    monkeypatch.setenv("PDEGPU_OUTPUT_POLICY", "error")
+    with pytest.raises(L.PdeGpuError, match="snapshot_stride"):
+        L.snapshot_policy(200, 513 ** 3, 1, False)
+    monkeypatch.setenv("PDEGPU_OUTPUT_POLICY", "auto")
+    monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "1")
+    with pytest.raises(L.PdeGpuError, match="first and the last"):
+        L.snapshot_policy(200, 513 ** 3, 1, False)
