@@ -149,6 +149,7 @@ int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_hea
  *      in COORDINATE space [origin, origin + L] with one scalar weight w multiplying the mass and the stiffness
  *      form; w enters as the P1 / P2 interpolant of an Expression of degree 1 / 2 and is integrated exactly.
  *      Constant initial condition only (:872-875). */
+#define PDEGPU_WEIGHT_ONE   0      /* w = 1             Constant(1.0): the plain box with a composite core (:537-572, :647) */
 #define PDEGPU_WEIGHT_R     1      /* w = x0            Expression("x[0]", degree=1)               (:802, :1100) */
 #define PDEGPU_WEIGHT_R2    2      /* w = x0^2          Expression("x[0] * x[0]", degree=2)        (:965)        */
 #define PDEGPU_WEIGHT_R2SIN 3      /* w = x0^2 sin(x1)  Expression("x[0] * x[0] * sin(x[1])", 2)   (:1230, :1371) */
@@ -162,6 +163,11 @@ typedef struct pdegpu_weight {
 } pdegpu_weight;
 int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
                                const pdegpu_heat* heat, double* values_out, double* times_out, pdegpu_stats* stats);
+/* the same with a nodal initial field u0 [N] (heat->ic_type == PDEGPU_IC_NODAL): the projected sine / cosine initial conditions
+ * of solve_heat_3D on its cylinder (BoxMesh fallback) and composite-core branches (:672-687) */
+int pdegpu_heat_solve_weighted_ic(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
+                                  const pdegpu_heat* heat, const double* u0, double* values_out, double* times_out,
+                                  pdegpu_stats* stats);
 /* host twin of the per-node weighted assembly (CPU tests): rowsK / rowsM [N][15] (15-offset order
  * {0, -x, +x, -y, +y, -z, +z, -(xy), +(xy), -(xz), +(xz), -(yz), +(yz), -(xyz), +(xyz)}), load [N] */
 int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const pdegpu_weight* weight, double* rowsK, double* rowsM,

@@ -298,18 +298,41 @@ def box_dirichlet(nx, ny, nz, T_boundary=0.0, T_left=None, T_right=None, T_side=
     return mask, vals
 
 
+def core_cells(coords, cells, core_radius):
+    """cells of the composite core (:537-550): SubDomain.mark on cells takes a cell when inside() holds at all of its vertices
+    and at its midpoint; inside = sqrt(y^2 + z^2) < core_radius"""
+    P = coords[cells]
+    rv = np.sqrt(P[:, :, 1] ** 2 + P[:, :, 2] ** 2)
+    mid = P.mean(axis=1)
+    rm = np.sqrt(mid[:, 1] ** 2 + mid[:, 2] ** 2)
+    return (rv < core_radius).all(axis=1) & (rm < core_radius)
+
+
 def solve_heat_3d(Lx, Ly, Lz, nx, ny, nz, diffusivity, T_boundary, T_initial, dt, num_steps, steady=False,
                   source_type="none", source_value=0.0, initial_type="constant",
                   initial_amplitude=1.0, initial_wavenumber=1.0, geometry_type="box",
-                  T_left=None, T_right=None, T_side=None, refactor_each_step=True) -> OracleField:
-    """_solve_heat_3d_raw, box branch, fenics_mcp_server.py:475-762 (box = :533,574,606-628,647,653-716)."""
+                  T_left=None, T_right=None, T_side=None, refactor_each_step=True,
+                  core_radius=None, core_diffusivity=None) -> OracleField:
+    """_solve_heat_3d_raw, box branch, fenics_mcp_server.py:475-762 (box = :533,574,606-628,647,653-716); with
+    core_radius / core_diffusivity the DG0 diffusivity of :537-572 on the plain box (distance from the x-axis, i.e. from the
+    box edge y = z = 0)."""
     if geometry_type != "box":
         raise NotImplementedError("oracle restates the box branch only (SURVEY.md §8a row a3)")
     coords, cells = box_mesh(Lx, Ly, Lz, nx, ny, nz)
     dir_mask, dir_vals = box_dirichlet(nx, ny, nz, T_boundary, T_left, T_right, T_side)
-    vals, times = _heat_core(coords, cells, dir_mask, dir_vals, diffusivity, T_initial, dt, num_steps, steady,
-                             source_type, source_value, initial_type, initial_amplitude, initial_wavenumber,
-                             refactor_each_step)
+    composite = core_radius is not None and core_diffusivity is not None
+    if composite:
+        kcell = np.where(core_cells(coords, cells, core_radius), core_diffusivity / diffusivity, 1.0)
+        u0 = None
+        if not steady:
+            _, M, _ = assemble_scalar(coords, cells)
+            u0 = _initial_condition(coords, cells, M, initial_type, T_initial, initial_amplitude, initial_wavenumber)
+        vals, times = _weighted_heat_core(coords, cells, "one", dir_mask, dir_vals, diffusivity, T_initial, dt, num_steps, steady,
+                                          source_type, source_value, kcell, u0)
+    else:
+        vals, times = _heat_core(coords, cells, dir_mask, dir_vals, diffusivity, T_initial, dt, num_steps, steady,
+                                 source_type, source_value, initial_type, initial_amplitude, initial_wavenumber,
+                                 refactor_each_step)
     meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cartesian",
             "Lx": Lx, "Ly": Ly, "Lz": Lz, "geometry_type": geometry_type, "source_type": source_type,
             "source_value": source_value, "steady": steady}
@@ -319,7 +342,10 @@ def solve_heat_3d(Lx, Ly, Lz, nx, ny, nz, diffusivity, T_boundary, T_initial, dt
                 meta[k] = v
     else:
         meta["T_boundary"] = T_boundary
-    meta["diffusivity"] = diffusivity
+    if composite:                                            # :747-753
+        meta.update({"core_radius": core_radius, "core_diffusivity": core_diffusivity, "base_diffusivity": diffusivity})
+    else:
+        meta["diffusivity"] = diffusivity
     return OracleField(coords, vals, times, 3, meta)
 
 
@@ -452,6 +478,7 @@ WEIGHTS = {
     "r2": (2, lambda X: X[:, 0] ** 2),
     "r2sin": (2, lambda X: X[:, 0] ** 2 * np.sin(X[:, 1])),
     "rcyl": (2, lambda X: np.sqrt(X[:, 1] ** 2 + X[:, 2] ** 2)),   # Expression("sqrt(x[1]*x[1] + x[2]*x[2])", degree=2) (:645)
+    "one": (1, lambda X: np.ones(X.shape[0])),                      # r_expr = Constant(1.0) of the plain box (:647) — with a DG0 core
 }
 
 
@@ -520,12 +547,13 @@ def assemble_weighted(coords, cells, kind, kcell=None):
 
 
 def _weighted_heat_core(coords, cells, kind, dir_mask, dir_vals, kappa, T_initial, dt, num_steps, steady, source_type,
-                        source_value, kcell=None):
+                        source_value, kcell=None, u0=None):
     K, M, load = assemble_weighted(coords, cells, kind, kcell)
     f = float(source_value) if source_type == "constant" else 0.0
     if steady:
         return solve_dirichlet(kappa * K, f * load, dir_mask, dir_vals)[None, :], np.array([0.0])
-    u_n = np.where(dir_mask, dir_vals, float(T_initial))                          # constant IC only (:872-875)
+    # constant IC (:872-875), or the field `project(init_expr, V)` of the 3-D tool (:672-687; u0 given by the caller)
+    u_n = np.where(dir_mask, dir_vals, float(T_initial) if u0 is None else u0)
     snaps, times = [u_n.copy()], [0.0]
     A = (M + dt * kappa * K).tocsr()
     for n in range(num_steps):
@@ -628,7 +656,8 @@ def solve_heat_3d_spherical(r_inner, r_outer, nr, ntheta, nphi, diffusivity, T_b
 
 def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_initial, dt, num_steps, cylinder_radius,
                                     steady=False, source_type="none", source_value=0.0, T_left=None, T_right=None, T_side=None,
-                                    core_radius=None, core_diffusivity=None, Ly=1.0, Lz=1.0):
+                                    core_radius=None, core_diffusivity=None, Ly=1.0, Lz=1.0, initial_type="constant",
+                                    initial_amplitude=1.0, initial_wavenumber=1.0):
     """_solve_heat_3d_raw with geometry_type="cylinder" when mshr is not installed (it is in neither the reference's
     Dockerfile nor its requirements.txt, so this IS what the reference runs): fenics_mcp_server.py:523-529 BoxMesh
     (0,-R,-R)-(Lx,R,R) with int(ny*2R) x int(nz*2R) cells across, :642-645 weight sqrt(y^2+z^2) as a degree-2
@@ -636,7 +665,8 @@ def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_i
     core_radius of the axis — SubDomain.mark), :582-604 directional BCs.  On this box mesh no boundary facet has all
     its vertices at distance exactly R from the axis, so the `T_side` condition (:590-594, topological DirichletBC)
     constrains nothing; without directional values every boundary node gets T_boundary (:626-628).
-    Constant initial condition; the trig ICs of the box branch are not restated for this branch."""
+    Sine / cosine initial conditions (:672-687) are `project(Expression(degree=2), V)` with the plain dx measure (project does not
+    know about the weight), evaluated at the shifted mesh coordinates."""
     R = float(cylinder_radius)
     ny2, nz2 = int(ny * R * 2), int(nz * R * 2)
     if ny2 < 1 or nz2 < 1:
@@ -652,14 +682,16 @@ def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_i
     kcell = None
     composite = core_radius is not None and core_diffusivity is not None
     if composite:
-        P = coords[cells]
-        rv = np.sqrt(P[:, :, 1] ** 2 + P[:, :, 2] ** 2)
-        mid = P.mean(axis=1)
-        rm = np.sqrt(mid[:, 1] ** 2 + mid[:, 2] ** 2)
-        core = (rv < core_radius).all(axis=1) & (rm < core_radius)
-        kcell = np.where(core, core_diffusivity / diffusivity, 1.0)
+        kcell = np.where(core_cells(coords, cells, core_radius), core_diffusivity / diffusivity, 1.0)
+    u0 = None
+    if not steady:
+        if initial_type in ("cosine", "sine"):
+            _, M, _ = assemble_scalar(coords, cells)
+            u0 = _initial_condition(coords, cells, M, initial_type, T_initial, initial_amplitude, initial_wavenumber)
+        elif initial_type == "zero":
+            u0 = np.zeros(n)
     vals, times = _weighted_heat_core(coords, cells, "rcyl", dir_mask, dir_vals, diffusivity, T_initial, dt, num_steps, steady,
-                                      source_type, source_value, kcell)
+                                      source_type, source_value, kcell, u0)
     meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cylindrical", "Lx": Lx, "Ly": R * 2,
             "Lz": R * 2, "geometry_type": "cylinder", "source_type": source_type, "source_value": source_value, "steady": steady,
             "cylinder_radius": R}

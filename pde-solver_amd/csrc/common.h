@@ -16,7 +16,8 @@ struct pdegpu_ctx {
     bool own_stream = false;
     int num_cu = 256;
     // tunables (pdegpu_set_tunable / PDEGPU_* environment at context creation)
-    int fast_ry = 2;            // rows per thread of the z-marching kernels (1, 2, 4, 8); 2 = 4 waves/SIMD, measured best
+    int fast_ry = 0;            // rows per thread of the z-marching kernels (1, 2, 4, 8); 0 = per mode: 4 for the one-vector passes
+                                // (bare apply, residual), 2 for the CG kernels (round-2 sweeps, 512^3: SpMV 0.43 -> 0.38 ms)
     int fast_nt = -1;           // bit 0: non-temporal stores of q / p / x; bit 1: non-temporal loads of x; -1 = auto
                                 // (3 when one slab vector exceeds 64 MiB, i.e. nothing stays cache-resident)
     int fast_ex = 1;            // 1: CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
@@ -30,7 +31,9 @@ struct pdegpu_ctx {
     int fast_minlen = 1;        // shortest z-chunk of the marching kernels on grids too small to fill the device
     int fast_small_mult = 1;    // such grids may launch this many resident rounds of workgroups
     int fast_wg_per_cu_k2 = 0;  // the same for the stencil K2 alone (0 = follow fast_wg_per_cu)
-    int fast_wg_per_cu = 0;     // 0 = occupancy API
+    int fast_wg_per_cu = 0;     // workgroups per CU the z-chunking aims for; 0 = 2 (+ 1/8 slack) when the vectors live in HBM — FEWER,
+                                // longer-lived streams move more bytes per second on this memory system (512^3: K1 1.03 -> 0.92 ms,
+                                // K2 0.62 -> 0.55 ms against the occupancy limit of 5-8) — and the occupancy API on cache-resident grids
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
     int inlaunch_dot = 0;       // opt-in: finish dot products inside the producing launch (dot_finish.h).  Measured slower:
@@ -40,11 +43,15 @@ struct pdegpu_ctx {
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
     int el_fast = 1;            // 3-D elasticity: 1 = z-marching block stencil (k_el_fast); 0 = thread-per-node class-table kernel
     int el_fast_yx = 1;         // k_el_fast: 1 = the 4 waves of a workgroup are y-neighbours and hand their y-halo rows through LDS
+    int el_fast_xface = 1;      // k_el_fast: 1 = the x-face nodes (interior in y, z) are computed by the marching part (edge lanes carry the
+                                // face-class weights); 0 = by the class-table boundary pass (45 uncoalesced loads per node)
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
     int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never
     int tile3d_plain = 1;       // tile sessions: the bare masked apply uses the tile form too
     int plane2d_ry = 4;         // rows per wavefront tile of k_plane2d (2 | 4 | 8)
+    int persist2d = 1;          // 2-D grids up to 1024 cells wide and 8 rows per CU: the whole CG loop in ONE cooperative launch with the state
+                                // in registers (persist2d.hip); 0 = one launch per kernel
     int plane2d = 1;            // 2-D grids: 1 = the two CG kernels load their tile in one round (k_plane2d); 0 = flat view of the marching kernels
     int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary
                                 // nodes; 0 = class-table kernel everywhere
@@ -174,6 +181,7 @@ struct DotIn {
 struct StencilArgs {
     GridDev g;
     const double* tabA;       // device [27][27] class table (general path)
+    unsigned off_mask = 0x7ffffffu;   // general path: bit o set = offset o has a non-zero weight in some class (others are never loaded)
     double w[8];              // interior coefficients: c0, cx, cy, cz, cxy, cxz, cyz, cxyz (fast path)
     const double* in;         // PLAIN/RESIDUAL: input vector;  CG_K1: r
     const double* rhs;        // RESIDUAL: right-hand side vector (nullable -> rhs_const)
@@ -269,6 +277,14 @@ int tridiag_setup(pdegpu_ctx* ctx, const GridDev& g, const double* tabA, const d
                   const double* ellM, long long ell_stride, double* rows /*device [8][NX]*/);
 int tridiag_run(pdegpu_ctx* ctx, int N, const double* rows, double* work /*device [3][N]*/, double* u, double shift, int rhs_given,
                 int nsteps, int step0, int total_steps, int stride, double* snaps);
+
+// persist2d.hip: the CG loop of a 2-D system as one cooperative launch (state in registers, two grid barriers per iteration)
+struct Persist2d;
+bool persist2d_supported(const pdegpu_ctx* ctx, const GridDev& g);
+int persist2d_create(pdegpu_ctx* ctx, const GridDev& g, Persist2d** out);
+int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double* w5, double* x, double* r, const double* p_in, double* p_out,
+                  double* scal, int iters_max, double target, int* iters_done);
+void persist2d_free(Persist2d* p);
 
 int next_poll_chunk(double rr_before, double rr_after, double target, int n_done, int chunk, int cap);   // heat.hip
 GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0, int64_t nk);

@@ -213,6 +213,13 @@ struct ElW36 {
     double c[6];        // centre block: xx yy zz xy xz yz
     double ax[3][6];    // offsets (1,0,0) (0,1,0) (0,0,1)
     double dg[4][3];    // offsets (1,1,0) (1,0,1) (0,1,1) (1,1,1): xy xz yz (zero diagonal)
+    // x-face nodes (interior in y and z) inside the marching kernel.  On the host tables the class of the face x = NX-1 is: offsets
+    // with dx = +1 absent, dx = -1 as in the interior, and for the in-face offsets o (dx = 0)  B_face(o) = B(o) / 2 + A(o)  with
+    // A(-o) = -A(o) antisymmetric and non-zero in its first row / column only, A(o) = [[0, a, b], [-a, 0, 0], [-b, 0, 0]] (the Kuhn
+    // split is not mirror symmetric in x); the face x = 0 has -A.  xf[t] = {a, b} of o = (0,1,0), (0,0,1), (0,1,1); the centre
+    // block is exactly halved.  el_fast_weights checks all of this before xface is set.
+    double xf[3][2];
+    int xface;          // 1: the marching part computes the x-face rows, the boundary pass only the y / z faces
 };
 struct ElFastGeom {
     int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                     const int t = (int)(e % (unsigned)fg.ring);
                     if (t < g.NX) { j = 0; i = t; }
                     else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
-                    else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
+                    else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }      // (ring = 2 NX with xface: never here)
                 }
             }
             const int kg = g.k0 + lk;
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
         }
         const bool ghost_wave = YX && yt >= fg.nty;           // beyond the last row tile: takes part in the barriers only
         if (ghost_wave) yt = fg.nty - 1;                      // (loads stay inside the grid; nothing is stored)
-        const int i = xt * 62 + lane;                         // lanes 0 and 63: x-halo only
+        const int i = xt * 62 + lane;                         // lanes 0 and 63: x-halo only (lane 0 of the first tile: the face x = 0)
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
         const int lk0 = fg.lkb + zc * fg.zlen;
         const int lk1 = min(lk0 + fg.zlen, fg.lke);
@@ -353,7 +360,12 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
             // inside the allocation — rows up to NY (= first row of the next plane), columns up to NX+60 < PX+64, planes
             // -1 .. nkl, covered by the ghost planes and the guard of kGuard + one row on both sides — and a value from
             // outside the grid only ever reaches outputs that are not stored (an interior node has all 15 neighbours inside).
-            const bool out_x = lane >= 1 && lane <= 62 && i <= g.NX - 2;
+            // x-faces: lane 0 of the first tile is the node i = 0 (clamped: its row is 0 when Dirichlet rows are masked), the node
+            // i = NX-1 (traction-free) sits on one of the lanes 1 .. 62 of the last tile
+            const bool face_lo = w.xface && i == 0, face_hi = w.xface && i == g.NX - 1;
+            const bool wave_has_face = w.xface && (xt == 0 || (xt + 1) * 62 >= g.NX - 1);      // wave-uniform
+            const double fsc = (face_lo || face_hi) ? 0.5 : 1.0, fsg = face_hi ? 1.0 : (face_lo ? -1.0 : 0.0);
+            const bool out_x = (lane >= 1 && lane <= 62 && i <= g.NX - (w.xface ? 1 : 2)) || face_lo;
             bool row_out[RH];
 #pragma unroll
             for (int r = 0; r < RH; ++r) row_out[r] = out_x && !ghost_wave && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
@@ -438,8 +450,31 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                     el_off3(w.dg[0], P0[r - 1], Lw);          //        (i-1, j-1, k)
                     el_off3(w.dg[1], Pm[r], Lw);              //        (i-1, j, k-1)
                     el_off3(w.dg[3], Pm[r - 1], Lw);          //        (i-1, j-1, k-1)
+                    if (wave_has_face) {
+                        // x-face lanes: in-face part halved + the antisymmetric remainder, no coupling across the face; the
+                        // clamped face gives 0 when Dirichlet rows are masked
+                        double d1[3], d2[3], d3[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
+                        for (int c = 0; c < 3; ++c) {
+                            d1[c] = P0[r + 1][c] - P0[r - 1][c];
+                            d2[c] = Pp[r][c] - Pm[r][c];
+                            d3[c] = Pp[r + 1][c] - Pm[r - 1][c];
+                        }
+                        const double cx = w.xf[0][0] * d1[1] + w.xf[0][1] * d1[2] + w.xf[1][0] * d2[1] + w.xf[1][1] * d2[2] +
+                                          w.xf[2][0] * d3[1] + w.xf[2][1] * d3[2];
+                        const double cy = -(w.xf[0][0] * d1[0] + w.xf[1][0] * d2[0] + w.xf[2][0] * d3[0]);
+                        const double cz = -(w.xf[0][1] * d1[0] + w.xf[1][1] * d2[0] + w.xf[2][1] * d3[0]);
+                        const double corr[3] = {cx, cy, cz};
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const double up = face_hi ? 0.0 : el_dpp_upper(U[c]), lo = face_lo ? 0.0 : el_dpp_lower(Lw[c]);
+                            y[c] = fsc * y[c] + (up + lo) + fsg * corr[c];     // interior lanes: bitwise the plain y += up + lo
+                            if (face_lo && a.mask_dirichlet) y[c] = 0.0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
+                    }
                     if (row_out[r]) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
@@ -963,6 +998,51 @@ bool el_fast_weights(const double* w15 /*[15][9]*/, ElW36* out) {
     return true;
 }
 
+// x-face structure of the class table (see ElW36::xf): fills xf and returns true when the two x-face classes (interior in y, z)
+// have exactly that form
+bool el_xface_weights(const double* tab /*[27][15][9]*/, ElW36* out) {
+    auto qof = [](int dx, int dy, int dz) {
+        const int o = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+        for (int q = 0; q < PG_NOFF15; ++q)
+            if (pg_off15(q) == o) return q;
+        return -1;
+    };
+    const double* ti = tab + 13 * PG_NOFF15 * 9;
+    double scale = 0.0;
+    for (int t = 0; t < 9; ++t) scale = std::max(scale, std::fabs(ti[qof(0, 0, 0) * 9 + t]));
+    const double tol = 1e-12 * scale;
+    const int inface[3][3] = {{0, 1, 0}, {0, 0, 1}, {0, 1, 1}};
+    for (int face = 0; face < 2; ++face) {                    // 0: x = 0 (class 12, sign -1), 1: x = NX-1 (class 14, sign +1)
+        const double* tf = tab + (face ? 14 : 12) * PG_NOFF15 * 9;
+        const double sg = face ? 1.0 : -1.0;
+        for (int q = 0; q < PG_NOFF15; ++q) {
+            const int o = pg_off15(q), dx = o % 3 - 1;
+            for (int t = 0; t < 9; ++t) {
+                const double bf = tf[q * 9 + t], bi = ti[q * 9 + t];
+                if (dx == (face ? 1 : -1) && std::fabs(bf) > tol) return false;             // outward: absent
+                if (dx == (face ? -1 : 1) && std::fabs(bf - bi) > tol) return false;        // inward: as in the interior
+            }
+        }
+        for (int t = 0; t < 9; ++t)
+            if (std::fabs(tf[qof(0, 0, 0) * 9 + t] - 0.5 * ti[qof(0, 0, 0) * 9 + t]) > tol) return false;
+        for (int k = 0; k < 3; ++k)
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const int q = qof(0, sgn * inface[k][1], sgn * inface[k][2]);
+                double A[9];
+                for (int t = 0; t < 9; ++t) A[t] = tf[q * 9 + t] - 0.5 * ti[q * 9 + t];
+                const double a = sg * sgn * A[1], b = sg * sgn * A[2];
+                if (face == 1 && sgn == 1) { out->xf[k][0] = a; out->xf[k][1] = b; }
+                const double expect[9] = {0, sg * sgn * out->xf[k][0], sg * sgn * out->xf[k][1], -sg * sgn * out->xf[k][0], 0, 0, -sg * sgn * out->xf[k][1], 0, 0};
+                if (!(face == 1 && sgn == 1))
+                    for (int t = 0; t < 9; ++t)
+                        if (std::fabs(A[t] - expect[t]) > tol) return false;
+                if (std::fabs(A[0]) > tol || std::fabs(A[4]) > tol || std::fabs(A[5]) > tol || std::fabs(A[7]) > tol || std::fabs(A[8]) > tol ||
+                    std::fabs(A[1] + A[3]) > tol || std::fabs(A[2] + A[6]) > tol) return false;
+            }
+    }
+    return true;
+}
+
 void el_fast_geometry(ElSession* s) {
     const GridDev& g = s->g;
     ElFastGeom& fg = s->fgeom;
@@ -972,7 +1052,8 @@ void el_fast_geometry(ElSession* s) {
     fg.lkb = fg.full_lo;
     fg.lke = g.nkl - fg.full_hi;
     const int planes = std::max(0, fg.lke - fg.lkb);
-    fg.ntx = (g.NX - 2 + 61) / 62;
+    const bool xface = s->w36.xface != 0;
+    fg.ntx = (g.NX - (xface ? 1 : 2) + 61) / 62;
     fg.nty = (g.NY - 2 + RY - 1) / RY;
     fg.nyg = (fg.nty + 3) / 4;
     const bool yx = s->ctx->el_fast_yx != 0;
@@ -983,7 +1064,7 @@ void el_fast_geometry(ElSession* s) {
     fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
     fg.nb_fast = (int)((cols * fg.nzc + 3) / 4);
     fg.nb_fast = (fg.nb_fast + 7) / 8 * 8;          // multiple of 8 for the XCD-aware tile order (surplus waves find zc >= nzc and idle)
-    fg.ring = 2 * g.NX + 2 * (g.NY - 2);
+    fg.ring = 2 * g.NX + (xface ? 0 : 2 * (g.NY - 2));        // boundary nodes of an interior plane left to the class-table pass
     fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * g.NX * g.NY + (long long)planes * fg.ring;
     fg.nb_bnd = (int)std::min<long long>((fg.nbnd + 255) / 256, 2LL * s->ctx->num_cu);      // grid-stride: the 29 KB table is loaded per workgroup
     fg.mask = s->d_mask;
@@ -1121,6 +1202,13 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     size_t npart = (size_t)s->nblk;
     s->fast_ry = ctx->el_fast_ry == 2 ? 2 : 1;
     s->fast = grid->dim == 3 && s->g.NX >= 3 && s->g.NY >= 3 && s->g.NZ >= 3 && el_fast_weights(s->interior.w, &s->w36);
+    s->w36.xface = 0;
+    if (s->fast && ctx->el_fast_xface) {
+        // x-face rows inside the marching kernel: only when the host table has the structure the kernel relies on
+        std::vector<double> htab((size_t)27 * PG_NOFF15 * 9);
+        for (int e = 0; e < 27 * PG_NOFF15; ++e) fold_elasticity_block(grid->dim, h, s->lam, s->mu, e / PG_NOFF15, e % PG_NOFF15, htab.data() + (size_t)e * 9);
+        s->w36.xface = el_xface_weights(htab.data(), &s->w36) ? 1 : 0;
+    }
     if (s->fast) {
         el_fast_geometry(s);
         if (s->fgeom.nbnd > 0x7fffffffLL) s->fast = false;

@@ -48,6 +48,7 @@ struct pdegpu_session {
     size_t tev_used = 0;
     long long timed_k1 = 0, timed_k2 = 0;
     int k1_parts = 0;              // workgroups (partials) launched by the parts of a split K1 so far
+    Persist2d* p2d = nullptr;      // 2-D sessions: register-resident persistent CG (created on first use)
     // weighted (curvilinear) operators: per-node coefficients + Jacobi-PCG
     bool weighted = false;
     double *ellA = nullptr, *ellM = nullptr, *dinv = nullptr;   // origins (same indexing as the vectors)
@@ -126,6 +127,15 @@ GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t 
 
 namespace {
 
+// offsets that carry a non-zero weight in at least one boundary class of a [27][27] class table (k_general loads only those)
+unsigned table_mask(const double* tab) {
+    unsigned m = 0;
+    for (int c = 0; c < 27; ++c)
+        for (int o = 0; o < 27; ++o)
+            if (tab[c * 27 + o] != 0.0) m |= 1u << o;
+    return m;
+}
+
 void fast_weights(const double* tab, double* w, bool flat2d = false) {
     const double* c = tab + 13 * 27;   // interior class
     w[0] = c[13]; w[1] = c[14]; w[2] = c[16]; w[3] = c[22];
@@ -202,6 +212,7 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     a.mask_dirichlet = mask;
     const double* htab = which == 0 ? s->hA : s->tabs.h_tabM;
     a.tabA = which == 0 ? s->tabs.d_tabA : s->tabs.d_tabM;
+    a.off_mask = table_mask(htab);
     if (s->weighted) {
         a.ell = which == 0 ? s->ellA : s->ellM;
         a.ell_stride = s->ell_stride;
@@ -241,6 +252,7 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     a.dot_which = (s->weighted || !use_inlaunch(s)) ? -1 : 1;   // PCG forms rho = r.z in the follow-up k_k2_pc pass
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
+    a.off_mask = table_mask(s->hA);
     if (s->weighted) {
         a.ell = s->ellA;
         a.ell_stride = s->ell_stride;
@@ -282,6 +294,7 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
     a.dot_which = use_inlaunch(s) ? 0 : -1;
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
+    a.off_mask = table_mask(s->hA);
     const bool part = lk_hi > lk_lo;
     if (part) {
         a.lk_lo = lk_lo;
@@ -409,7 +422,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "persist2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -444,6 +457,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
     if (!strcmp(key, "hybrid_bc")) return &ctx->hybrid_bc;
     if (!strcmp(key, "plane2d")) return &ctx->plane2d;
+    if (!strcmp(key, "persist2d")) return &ctx->persist2d;
     if (!strcmp(key, "tile3d_max_nodes")) return &ctx->tile3d_max_nodes;
     if (!strcmp(key, "plane2d_ry")) return &ctx->plane2d_ry;
     if (!strcmp(key, "fast_minlen")) return &ctx->fast_minlen;
@@ -451,6 +465,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "el_fast")) return &ctx->el_fast;
     if (!strcmp(key, "el_fast_ry")) return &ctx->el_fast_ry;
     if (!strcmp(key, "el_fast_yx")) return &ctx->el_fast_yx;
+    if (!strcmp(key, "el_fast_xface")) return &ctx->el_fast_xface;
     if (!strcmp(key, "el_fast_waves")) return &ctx->el_fast_waves;
     return nullptr;
 }
@@ -496,6 +511,7 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->tev) (void)hipEventDestroy(e);
+    persist2d_free(s->p2d);
     s->cg_graph.reset();
     for (double* b0 : s->ell_base)
         if (b0) (void)hipFree(b0);
@@ -806,10 +822,34 @@ int cg_graph_prepare(pdegpu_session* s) {
 }
 }  // namespace
 
+namespace {
+// 2-D sessions whose CG loop runs as one cooperative launch (persist2d.hip)
+bool use_persist2d(pdegpu_session* s) {
+    return s->plane2d && !s->weighted && s->ctx->persist2d != 0 && s->g.dim == 2 && persist2d_supported(s->ctx, s->g);
+}
+// up to `iters` iterations, stopping early at r.r <= target (target > 0); the scalars and x, r, p of the session are left exactly as
+// the launch-per-kernel loop leaves them (x lags by alpha p, p in p[pcur])
+int persist2d_iterate(pdegpu_session* s, int iters, double target, int* done) {
+    if (!s->p2d) PG_TRY(persist2d_create(s->ctx, s->g, &s->p2d));
+    double w5[8];
+    plane2d_weights(s->hA, w5);
+    return persist2d_run(s->ctx, s->p2d, s->g, w5, s->x.v, s->r.v, s->p[s->pcur].v, s->p[s->pcur].v, s->d_scal, iters, target, done);
+}
+}  // namespace
+
 extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_kernels, pdegpu_stats* stats) {
     if (!s || iters < 0) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;
     PG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!time_kernels && iters > 0 && use_persist2d(s)) {
+        int done = 0;
+        PG_TRY(persist2d_iterate(s, iters, 0.0, &done));
+        if (stats) {
+            stats->cg_iterations += done;
+            stats->path = 1;
+        }
+        return PDEGPU_OK;
+    }
     const size_t need = time_kernels ? (size_t)iters * 4 : 0;
     while (s->events.size() < need) {
         hipEvent_t e;
@@ -1031,7 +1071,18 @@ int cg_solve(pdegpu_session* s, double bnorm2, double rr, double rtol, int max_i
     PG_HIP(ctx, hipEventCreate(&ev.b));
     hipEvent_t e0 = ev.a, e1 = ev.b;
     PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    const bool persistent = use_persist2d(s);
     while (rr > target && it < max_iter && std::isfinite(rr)) {
+        if (persistent) {
+            // one cooperative launch runs until r.r <= target (every workgroup holds the same r.r): no polling, no overshoot;
+            // launches are cut at 8192 iterations only to keep a single launch short
+            int done = 0;
+            PG_TRY(persist2d_iterate(s, std::min(8192, max_iter - it), target, &done));
+            it += done;
+            PG_TRY(pdegpu_session_rr(s, &rr));
+            if (done == 0) break;
+            continue;
+        }
         const int n = std::min(chunk, max_iter - it);
         const double rr_before = rr;
         PG_TRY(pdegpu_session_iterate(s, n, 0, nullptr));
@@ -1128,16 +1179,24 @@ extern "C" int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const
 }
 
 // curvilinear tools (:769-1464): the same backward-Euler / steady loop on the weighted forms
-extern "C" int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
-                                          const pdegpu_heat* heat_in, double* values_out, double* times_out, pdegpu_stats* stats) {
+extern "C" int pdegpu_heat_solve_weighted_ic(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
+                                             const pdegpu_heat* heat_in, const double* u0, double* values_out, double* times_out,
+                                             pdegpu_stats* stats) {
     if (!ctx) return PDEGPU_EINVAL;
     if (!weight) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null weight");
-    if (weight->kind < 1 || weight->kind > 4) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
+    if (weight->kind < PDEGPU_WEIGHT_ONE || weight->kind > PDEGPU_WEIGHT_RCYL) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
     if (grid && weight->kind == 3 && grid->dim < 2) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weight r^2 sin(theta) needs dim >= 2");
     if (grid && weight->kind == 4 && grid->dim < 3) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weight sqrt(y^2+z^2) needs dim == 3");
+    if (grid && weight->kind == PDEGPU_WEIGHT_ONE && grid->dim < 3) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "the unit weight (composite core of the box) needs dim == 3");
     if (weight->core_radius > 0.0 && !(weight->core_ratio > 0.0)) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "core_ratio must be > 0");
     if (grid && grid->element_mode != PDEGPU_ELEM_P1SPLIT) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted forms use the P1 split only");
-    return heat_solve_impl(ctx, grid, heat_in, weight, nullptr, values_out, times_out, stats);
+    return heat_solve_impl(ctx, grid, heat_in, weight, u0, values_out, times_out, stats);
+}
+
+// curvilinear tools (:769-1464): the same backward-Euler / steady loop on the weighted forms
+extern "C" int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
+                                          const pdegpu_heat* heat_in, double* values_out, double* times_out, pdegpu_stats* stats) {
+    return pdegpu_heat_solve_weighted_ic(ctx, grid, weight, heat_in, nullptr, values_out, times_out, stats);
 }
 
 

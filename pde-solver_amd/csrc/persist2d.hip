@@ -1,0 +1,364 @@
+// persist2d.hip — the CG loop of a 2-D heat system as ONE cooperative launch (gfx950).
+//
+// The 2-D tools (fenics_mcp_server.py:345-468: RectangleMesh, one Dirichlet value on the boundary) solve grids whose whole CG state
+// fits in the register files of the chip (config 2: 1025^2 nodes x {x, r, p} = 25 MB against 128 MB of VGPRs), yet the
+// launch-per-kernel loop moves that state through L2 / MALL twice per iteration and pays two kernel boundaries plus the
+// dependent load rounds of each kernel (21.7 us per iteration at config 2, round 1).  Here every workgroup owns a band of RB
+// full-width rows and keeps x, r, p of its nodes in registers for the whole solve; per iteration the only memory traffic is
+//   * the first / last row of r of every band (the neighbours' halo: p on the halo rows is recomputed locally from r and the halo's
+//     previous p, the same trick the slab kernels use for their ghost planes), and
+//   * one 8-byte partial per workgroup and dot product,
+// exchanged through TWO grid barriers per iteration (after p.q and after r.r).  x-neighbours inside a band come from DPP wave
+// shifts and an LDS hand-off between the band's waves.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md §6 Guideline 16, MI355X_MICROARCH.md § visibility, first row of the table of
+// measured hand-offs: one workgroup per CU, hipMalloc memory): every handed-off byte is stored write-through (8-byte sc1 stores =
+// relaxed agent-scope atomic stores), every storing wave drains (s_waitcnt vmcnt(0)) in front of the workgroup barrier, ONE lane
+// then adds to a monotonic agent-scope counter and polls it with relaxed sc1 loads; the other waves wait at the workgroup
+// barrier that lane joins after its poll has matched; every load of handed-off bytes is an sc1 load (no L1 copy can be stale, so
+// no acquire fence is needed).  Spins are bounded: a workgroup that gives up raises a flag every poll loop also watches, so the
+// grid always drains; the host then reports the failure.  Nothing depends on dispatch order or placement; the launch is
+// cooperative, so a grid that cannot be co-resident is refused at launch instead of deadlocking.
+// Sums are formed in a fixed order and every workgroup adds the same partials in the same order: all workgroups hold bitwise
+// identical scalars and take the same branch at the convergence test, which therefore needs no host poll at all.
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ double p2_dpp_lower(double v) {      // lane l <- lane l-1 (lane 0: 0)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double p2_dpp_upper(double v) {      // lane l <- lane l+1 (lane 63: 0)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double p2_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+struct P2dArgs {
+    GridDev g;
+    double w[5];               // w0, wx, wy, wd1 (offsets +-(1,1)), wd2 (offsets +-(1,-1))
+    double* x;
+    double* r;
+    const double* p_in;
+    double* p_out;
+    double* scal;              // SC_* block of the session (read at entry, written at exit)
+    double* part;              // [2][G] per-workgroup partial sums, by phase parity
+    double* pub;               // [2][G][PX]: first / last active row of r of every band
+    unsigned* sync;            // [0] barrier counter, [1] failure flag, [2] iterations done (all zeroed by the host before the launch)
+    int iters_max;
+    double target;             // stop as soon as r.r <= target (0: never)
+    int G;                     // workgroups = bands
+    int spin_limit;
+};
+
+constexpr int kNW = 8;         // waves per workgroup: 8 x 128 = 1024 columns
+
+// arrive + wait: returns false when the grid has failed (this workgroup's spin ran out or another one raised the flag)
+__device__ __forceinline__ bool grid_barrier(const P2dArgs& a, unsigned& epoch, int* sFail) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave: its sc1 stores have left
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        const unsigned want = epoch * (unsigned)a.G;
+        __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int fail = 0;
+        for (int spins = 0;; ++spins) {
+            if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+            if (__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins >= a.spin_limit) {
+                __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fail = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *sFail = fail;
+    }
+    __syncthreads();
+    return *sFail == 0;
+}
+
+// fixed-order sum of the G partials of one phase; identical in every workgroup
+__device__ __forceinline__ double sum_partials(const double* part, int G, double* sRed) {
+    double v = 0.0;
+    for (int e = threadIdx.x; e < G; e += kNW * 64) v += ld_sc1(part + e);
+    v = p2_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNW; ++k) t += sRed[k];
+    return t;
+}
+__device__ __forceinline__ double block_sum(double v, double* sRed) {
+    v = p2_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNW; ++k) t += sRed[k];
+    return t;
+}
+
+template <int RB>
+__global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
+    __shared__ double sRed[kNW];
+    __shared__ double sEdge[RB + 2][kNW][2];
+    __shared__ int sFail;
+    const GridDev& g = a.g;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x;
+    const int i0 = wv * 128 + 2 * lane;
+    const int j0 = 1 + b * RB;                                   // first owned row
+    const bool col_ok = i0 < g.PX;
+    const bool ma = i0 >= 1 && i0 <= g.NX - 2, mb = i0 + 1 <= g.NX - 2;
+    const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wd1 = a.w[3], wd2 = a.w[4];
+    int nact = g.NY - 1 - j0;                                    // active rows of this band: j0 .. min(j0 + RB, NY - 1) - 1
+    if (nact > RB) nact = RB;
+    if (nact < 0) nact = 0;
+
+    // ---- state into registers --------------------------------------------------------------------------------------------
+    double2 X[RB], R[RB], P[RB + 2], RH[2];
+    auto ld2 = [&](const double* v, int j) {
+        const bool ok = col_ok && j >= 0 && j <= g.NY - 1;
+        const double2 t = *reinterpret_cast<const double2*>(v + (ok ? (long long)j * g.PX + i0 : 0));
+        return ok ? t : make_double2(0.0, 0.0);
+    };
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const bool act = q < nact;
+        X[q] = act ? ld2(a.x, j0 + q) : make_double2(0.0, 0.0);
+        R[q] = act ? ld2(a.r, j0 + q) : make_double2(0.0, 0.0);
+        P[q + 1] = act ? ld2(a.p_in, j0 + q) : make_double2(0.0, 0.0);
+    }
+    // halo rows: the row below the band and the row above its last ACTIVE row (rows of a short last band beyond that are zero)
+    P[0] = ld2(a.p_in, j0 - 1);
+    RH[0] = ld2(a.r, j0 - 1);
+    P[RB + 1] = (nact == RB) ? ld2(a.p_in, j0 + RB) : make_double2(0.0, 0.0);
+    RH[1] = (nact == RB) ? ld2(a.r, j0 + RB) : make_double2(0.0, 0.0);
+    double pq = a.scal[SC_PQ], rr = a.scal[SC_RR], rr_prev = a.scal[SC_RR_PREV];
+
+    unsigned epoch = 0;
+    int it = 0;
+    bool ok = true;
+    while (it < a.iters_max && !(a.target > 0.0 && rr <= a.target)) {
+        const double alpha_prev = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
+        const double beta = (rr_prev > 0.0) ? rr / rr_prev : 0.0;
+        // ---- K1: x += alpha_{n-1} p_{n-1};  p_n = r_n + beta p_{n-1} on the band AND its two halo rows ---------------------
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            X[q].x += alpha_prev * P[q + 1].x;
+            X[q].y += alpha_prev * P[q + 1].y;
+            P[q + 1].x = R[q].x + beta * P[q + 1].x;
+            P[q + 1].y = R[q].y + beta * P[q + 1].y;
+        }
+        P[0].x = RH[0].x + beta * P[0].x;
+        P[0].y = RH[0].y + beta * P[0].y;
+        P[RB + 1].x = RH[1].x + beta * P[RB + 1].x;
+        P[RB + 1].y = RH[1].y + beta * P[RB + 1].y;
+        // x-neighbours across the waves of the band: LDS hand-off of every held row's first / last node
+#pragma unroll
+        for (int q = 0; q < RB + 2; ++q) {
+            if (lane == 0) sEdge[q][wv][0] = P[q].x;
+            if (lane == 63) sEdge[q][wv][1] = P[q].y;
+        }
+        __syncthreads();
+        double Lf[RB + 2], Rt[RB + 2];                           // node i0-1 / node i0+2 of every held row
+#pragma unroll
+        for (int q = 0; q < RB + 2; ++q) {
+            double l = p2_dpp_lower(P[q].y), rt = p2_dpp_upper(P[q].x);
+            if (lane == 0) l = wv > 0 ? sEdge[q][wv - 1][1] : 0.0;
+            if (lane == 63) rt = wv < kNW - 1 ? sEdge[q][wv + 1][0] : 0.0;
+            Lf[q] = l;
+            Rt[q] = rt;
+        }
+        // ---- q = A p on the band, p.q ---------------------------------------------------------------------------------------
+        double2 Q[RB];
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int c = q + 1;
+            const double qa = w0 * P[c].x + wx * (Lf[c] + P[c].y) + wy * (P[c - 1].x + P[c + 1].x) + wd1 * (P[c + 1].y + Lf[c - 1]) +
+                              wd2 * (P[c - 1].y + Lf[c + 1]);
+            const double qb = w0 * P[c].y + wx * (P[c].x + Rt[c]) + wy * (P[c - 1].y + P[c + 1].y) + wd1 * (Rt[c + 1] + P[c - 1].x) +
+                              wd2 * (Rt[c - 1] + P[c + 1].x);
+            const bool act = q < nact;
+            Q[q] = make_double2((act && ma) ? qa : 0.0, (act && mb) ? qb : 0.0);
+            acc += P[c].x * Q[q].x + P[c].y * Q[q].y;
+        }
+        const double pq_loc = block_sum(acc, sRed);
+        if (threadIdx.x == 0) st_sc1(a.part + (size_t)(epoch & 1u) * a.G + b, pq_loc);
+        const unsigned ph1 = epoch & 1u;
+        ok = grid_barrier(a, epoch, &sFail);
+        if (!ok) break;
+        pq = sum_partials(a.part + (size_t)ph1 * a.G, a.G, sRed);
+        const double alpha = (pq > 0.0) ? rr / pq : 0.0;
+        // ---- K2: r -= alpha q, r.r; publish the band's first / last active row of r ----------------------------------------
+        acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            R[q].x -= alpha * Q[q].x;
+            R[q].y -= alpha * Q[q].y;
+            acc += R[q].x * R[q].x + R[q].y * R[q].y;
+        }
+        const double rr_loc = block_sum(acc, sRed);
+        if (threadIdx.x == 0) st_sc1(a.part + (size_t)(epoch & 1u) * a.G + b, rr_loc);
+        if (col_ok) {
+            double2 first = R[0], last = R[0];
+#pragma unroll
+            for (int q = 1; q < RB; ++q)
+                if (q < nact) last = R[q];
+            double* pf = a.pub + ((size_t)0 * a.G + b) * g.PX + i0;
+            double* pl = a.pub + ((size_t)1 * a.G + b) * g.PX + i0;
+            st_sc1(pf, first.x);
+            st_sc1(pf + 1, first.y);
+            st_sc1(pl, last.x);
+            st_sc1(pl + 1, last.y);
+        }
+        const unsigned ph2 = epoch & 1u;
+        ok = grid_barrier(a, epoch, &sFail);
+        if (!ok) break;
+        const double rr_new = sum_partials(a.part + (size_t)ph2 * a.G, a.G, sRed);
+        // halo rows of r for the next p: the band below's LAST row, the band above's FIRST row (boundary rows are zero)
+        RH[0] = make_double2(0.0, 0.0);
+        RH[1] = make_double2(0.0, 0.0);
+        if (col_ok && b > 0) {
+            const double* s = a.pub + ((size_t)1 * a.G + (b - 1)) * g.PX + i0;
+            RH[0] = make_double2(ld_sc1(s), ld_sc1(s + 1));
+        }
+        if (col_ok && b + 1 < a.G && nact == RB) {
+            const double* s = a.pub + ((size_t)0 * a.G + (b + 1)) * g.PX + i0;
+            RH[1] = make_double2(ld_sc1(s), ld_sc1(s + 1));
+        }
+        rr_prev = rr;
+        rr = rr_new;
+        ++it;
+    }
+    // ---- state back to memory (x still lags by alpha p: the session's flush / next K1 applies it) -------------------------------
+    if (col_ok) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+            if (q < nact) {
+                const long long off = (long long)(j0 + q) * g.PX + i0;
+                *reinterpret_cast<double2*>(a.x + off) = X[q];
+                *reinterpret_cast<double2*>(a.r + off) = R[q];
+                *reinterpret_cast<double2*>(a.p_out + off) = P[q + 1];
+            }
+    }
+    if (b == 0 && threadIdx.x == 0) {
+        a.scal[SC_PQ] = pq;
+        a.scal[SC_PQ_LOCAL] = pq;
+        a.scal[SC_RR] = rr;
+        a.scal[SC_RR_LOCAL] = rr;
+        a.scal[SC_RR_PREV] = rr_prev;
+        a.sync[2] = (unsigned)it;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Persist2d {
+    double* part = nullptr;
+    double* pub = nullptr;
+    unsigned* sync = nullptr;
+    unsigned* h_sync = nullptr;     // pinned copy of the three sync words
+    int G = 0, rb = 0;
+};
+
+void persist2d_free(Persist2d* p) {
+    if (!p) return;
+    if (p->part) (void)hipFree(p->part);
+    if (p->pub) (void)hipFree(p->pub);
+    if (p->sync) (void)hipFree(p->sync);
+    if (p->h_sync) (void)hipHostFree(p->h_sync);
+    delete p;
+}
+
+// rows per band and band count for this grid, or false when the grid does not fit the register-resident form
+static bool persist2d_shape(const pdegpu_ctx* ctx, const GridDev& g, int* rb, int* G) {
+    if (g.dim != 2 || g.NX < 3 || g.NY < 3) return false;
+    if (g.PX > kNW * 128) return false;                          // one band spans the full width with 8 waves
+    const int rows = g.NY - 2;
+    int need = (rows + ctx->num_cu - 1) / ctx->num_cu;           // one workgroup per CU
+    int r = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 0)));
+    if (r == 0) return false;
+    *rb = r;
+    *G = (rows + r - 1) / r;
+    return *G >= 1 && *G <= ctx->num_cu;
+}
+
+bool persist2d_supported(const pdegpu_ctx* ctx, const GridDev& g) {
+    int rb, G;
+    return persist2d_shape(ctx, g, &rb, &G);
+}
+
+int persist2d_create(pdegpu_ctx* ctx, const GridDev& g, Persist2d** out) {
+    int rb, G;
+    if (!persist2d_shape(ctx, g, &rb, &G)) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "grid does not fit the persistent 2-D CG");
+    Persist2d* p = new Persist2d();
+    p->G = G;
+    p->rb = rb;
+    if (hipMalloc(&p->part, 2 * (size_t)G * sizeof(double)) != hipSuccess || hipMalloc(&p->pub, 2 * (size_t)G * g.PX * sizeof(double)) != hipSuccess ||
+        hipMalloc(&p->sync, 64) != hipSuccess || hipHostMalloc(&p->h_sync, 64) != hipSuccess) {
+        persist2d_free(p);
+        return pdegpu_set_err(ctx, PDEGPU_EHIP, "persistent 2-D CG: allocation failed");
+    }
+    (void)hipMemsetAsync(p->part, 0, 2 * (size_t)G * sizeof(double), ctx->stream);
+    (void)hipMemsetAsync(p->pub, 0, 2 * (size_t)G * g.PX * sizeof(double), ctx->stream);
+    *out = p;
+    return PDEGPU_OK;
+}
+
+// up to iters_max CG iterations (stopping early once r.r <= target, target > 0) in one cooperative launch; synchronises and
+// returns the number of iterations done.  x, r, p_in / p_out: pitched 2-D vectors of the session.
+int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double* w5, double* x, double* r, const double* p_in, double* p_out,
+                  double* scal, int iters_max, double target, int* iters_done) {
+    P2dArgs a{};
+    a.g = g;
+    for (int k = 0; k < 5; ++k) a.w[k] = w5[k];
+    a.x = x;
+    a.r = r;
+    a.p_in = p_in;
+    a.p_out = p_out;
+    a.scal = scal;
+    a.part = p->part;
+    a.pub = p->pub;
+    a.sync = p->sync;
+    a.iters_max = iters_max;
+    a.target = target;
+    a.G = p->G;
+    a.spin_limit = 2000000;                                      // ~ seconds: far beyond any barrier of a healthy grid
+    PG_HIP(ctx, hipMemsetAsync(p->sync, 0, 64, ctx->stream));
+    void* args[] = {&a};
+    const void* fn = nullptr;
+    switch (p->rb) {
+        case 1: fn = reinterpret_cast<const void*>(k_cg2d_persistent<1>); break;
+        case 2: fn = reinterpret_cast<const void*>(k_cg2d_persistent<2>); break;
+        case 4: fn = reinterpret_cast<const void*>(k_cg2d_persistent<4>); break;
+        default: fn = reinterpret_cast<const void*>(k_cg2d_persistent<8>); break;
+    }
+    PG_HIP(ctx, hipLaunchCooperativeKernel(fn, dim3(p->G), dim3(kNW * 64), args, 0, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(p->h_sync, p->sync, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (p->h_sync[1] != 0u) return pdegpu_set_err(ctx, PDEGPU_EHIP, "persistent 2-D CG: a grid barrier timed out (the grid was not co-resident?)");
+    if (iters_done) *iters_done = (int)p->h_sync[2];
+    return PDEGPU_OK;
+}

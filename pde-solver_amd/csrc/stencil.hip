@@ -116,39 +116,50 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
                 if (alpha_prev != 0.0) a.x[idx] += alpha_prev * po;
             }
         }
+        // Neighbour loads are unconditional and separated from their use: every neighbour address of every index of the slab lies
+        // inside the allocation (ghost planes, row pads, guards: all finite) and meets a weight that is exactly 0 when the neighbour
+        // does not exist.  A load inside `if (w != 0)` is waited for inside that branch — 15 to 27 dependent memory round trips
+        // per node; this way they are all in flight together.  a.off_mask = offsets that carry a non-zero weight in ANY class
+        // (kernel-uniform: scalar branches, no waits).
         double s = 0.0;
-        if (ELL && real && !dir) {
-            // per-node coefficients (weighted / curvilinear operators): 15 coupling weights read from HBM
+        if (ELL) {
+            double wq[15], vi[15], vp[15];
 #pragma unroll
             for (int q = 0; q < 15; ++q) {
                 constexpr int kOff[15] = {13, 12, 14, 10, 16, 4, 22, 9, 17, 3, 23, 1, 25, 0, 26};
                 const int o = kOff[q];
                 const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
-                const double wo = a.ell[q * a.ell_stride + idx];
-                if (wo != 0.0) {
-                    const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
-                    double v;
-                    if (MODE == APPLY_CG_K1) v = a.in[nb] + beta * a.p_old[nb];
-                    else v = a.in[nb] + a.in_shift;
-                    s += wo * v;
-                }
+                const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
+                wq[q] = a.ell[q * a.ell_stride + idx];
+                vi[q] = a.in[nb];
+                vp[q] = (MODE == APPLY_CG_K1) ? a.p_old[nb] : 0.0;
             }
-        } else if (real && !dir) {
-            const int cls = pg_axis_class(i, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
-                            9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
+#pragma unroll
+            for (int q = 0; q < 15; ++q) s += wq[q] * ((MODE == APPLY_CG_K1) ? vi[q] + beta * vp[q] : vi[q] + a.in_shift);
+            if (!(real && !dir)) s = 0.0;
+        } else {
+            const int cls = real ? pg_axis_class(i, g.NX) + 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) +
+                                       9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1) : 13;
             const double* w = &sTab[cls * 27];
+            double vi[27], vp[27];
 #pragma unroll
             for (int o = 0; o < 27; ++o) {
-                const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
-                const double wo = w[o];
-                if (wo != 0.0) {
+                vi[o] = 0.0;
+                vp[o] = 0.0;
+                if ((a.off_mask >> o) & 1u) {
+                    const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
                     const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
-                    double v;
-                    if (MODE == APPLY_CG_K1) v = a.in[nb] + beta * a.p_old[nb];
-                    else v = a.in[nb] + a.in_shift;
-                    s += wo * v;
+                    vi[o] = a.in[nb];
+                    if (MODE == APPLY_CG_K1) vp[o] = a.p_old[nb];
                 }
             }
+#pragma unroll
+            for (int o = 0; o < 27; ++o) {
+                // (a weight 0 must give exactly 0 even next to the shifted value of a PLAIN pass)
+                const double v = (MODE == APPLY_CG_K1) ? vi[o] + beta * vp[o] : vi[o] + a.in_shift;
+                s += w[o] * v;
+            }
+            if (!(real && !dir)) s = 0.0;
         }
         if (MODE == APPLY_PLAIN) {
             a.out[idx] = s;
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
-FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0) {
+FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0, int slack8 = 0) {
     FastGeom fg{};
     fg.ntx = (g.NX - 1 + 127) / 128;
     fg.jbase = g.flat2d ? 0 : 1;
@@ -822,6 +833,7 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     const int xy = fg.nxg * fg.nyg;
     // one resident round: (workgroups that fit per CU) x CUs, at least 8 planes per chunk
     int target = wg_per_cu * ctx->num_cu;
+    if (slack8) target += target / 8;
     // chunks of >= 8 planes keep the redundant two-plane prologue below 25 % when there is parallelism to spare; a grid too
     // small to fill the device is latency-bound on the serial march instead (every plane step is a dependent memory round
     // trip), so it gets shorter chunks (down to fast_minlen planes) and up to fast_small_mult resident rounds of workgroups
@@ -862,7 +874,7 @@ struct ModeCfg { int ry, wg, ex, pf; };
 // rows per thread, resident workgroups per CU, LDS edge hand-off and deeper prefetch of one marching-kernel mode
 ModeCfg mode_cfg(const pdegpu_ctx* ctx, int mode) {
     ModeCfg c;
-    c.ry = ctx->fast_ry;
+    c.ry = ctx->fast_ry > 0 ? ctx->fast_ry : ((mode == APPLY_PLAIN || mode == APPLY_RESIDUAL) ? 4 : 2);
     c.wg = (mode == APPLY_CG_K2 && ctx->fast_wg_per_cu_k2 >= 1) ? ctx->fast_wg_per_cu_k2 : ctx->fast_wg_per_cu;
     c.ex = ctx->fast_ex && (mode == APPLY_CG_K1 || mode == APPLY_CG_K2 || ctx->fast_ex_all);
     c.pf = ctx->fast_pf != 0 && mode != APPLY_CG_K1;
@@ -894,8 +906,13 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     }
     int wg_per_cu = occ[mode];
     const ModeCfg mc = mode_cfg(ctx, mode);
+    // HBM-resident vectors (the same threshold as the non-temporal hints): two workgroups per CU, i.e. as few and as long z-chunks
+    // as fill the device; fast_geom adds 1/8 of slack so that e.g. 3 x 192 tiles count as one round
+    const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
+    int slack8 = 0;
     if (mc.wg >= 1 && mc.wg <= 16) wg_per_cu = mc.wg;
-    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, a.lk_lo, a.lk_hi);
+    else if (hbm) { wg_per_cu = 2; slack8 = 1; }
+    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, a.lk_lo, a.lk_hi, slack8);
     const int G = fg.nxg * fg.nyg * fg.nzc;
     if (li) { li->grid = G; li->block = 256; }
     if (G == 0) return PDEGPU_OK;

@@ -245,12 +245,13 @@ __host__ __device__ inline void fold_elasticity_block(int dim, const double* h, 
 // ---------------------------------------------------------------------------------------------
 
 __host__ __device__ inline double pg_weight_eval(int kind, const double* x) {
+    if (kind == PDEGPU_WEIGHT_ONE) return 1.0;
     if (kind == PDEGPU_WEIGHT_R) return x[0];
     if (kind == PDEGPU_WEIGHT_R2) return x[0] * x[0];
     if (kind == PDEGPU_WEIGHT_RCYL) return sqrt(x[1] * x[1] + x[2] * x[2]);
     return x[0] * x[0] * sin(x[1]);
 }
-__host__ __device__ inline int pg_weight_degree(int kind) { return kind == PDEGPU_WEIGHT_R ? 1 : 2; }
+__host__ __device__ inline int pg_weight_degree(int kind) { return (kind == PDEGPU_WEIGHT_R || kind == PDEGPU_WEIGHT_ONE) ? 1 : 2; }
 
 // position q in the 15-offset list of offset id o (or -1)
 __host__ __device__ inline int pg_q_of_o(int o) {

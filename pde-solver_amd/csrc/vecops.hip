@@ -66,17 +66,19 @@ __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const doubl
     dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
 }
 
+// streaming ceilings of the device for 16-B-per-lane accesses: ONE element per thread, as many workgroups as elements / 256 (no
+// grid-stride loop).  tools/membw.hip, measured on this pool: this shape copies at 6.3-6.7 TB/s, a grid-stride loop of 8
+// workgroups per CU over the same vectors at 4.8-5.3 (in a loop every load waits, through the in-order vmcnt counter, for the
+// store in front of it; short-lived workgroups retire with their stores in flight and are replaced in dispatch order)
 __global__ __launch_bounds__(256) void k_membench(int which, double2* __restrict__ r, const double2* __restrict__ q,
                                                    double2* __restrict__ b, long long n2, double c, double* __restrict__ sink) {
-    double acc = 0.0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long long)gridDim.x * 256) {
-        if (which == 0) b[e] = q[e];
-        else if (which == 1) { const double2 v = r[e]; acc += v.x + v.y; }
-        else if (which == 2) b[e] = make_double2(c, c);
-        else if (which == 3) { const double2 rv = r[e], qv = q[e]; b[e] = make_double2(rv.x + c * qv.x, rv.y + c * qv.y); }
-        else { double2 rv = r[e]; const double2 qv = q[e]; rv.x += c * qv.x; rv.y += c * qv.y; r[e] = rv; }
-    }
-    if (which == 1 && acc == 1.2345e300) sink[0] = acc;      // keeps the loads alive
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n2) return;
+    if (which == 0) b[e] = q[e];
+    else if (which == 1) { const double2 v = r[e]; if (v.x + v.y == 1.2345e300) sink[0] = v.x; }      // keeps the load alive
+    else if (which == 2) b[e] = make_double2(c, c);
+    else if (which == 3) { const double2 rv = r[e], qv = q[e]; b[e] = make_double2(rv.x + c * qv.x, rv.y + c * qv.y); }
+    else { double2 rv = r[e]; const double2 qv = q[e]; rv.x += c * qv.x; rv.y += c * qv.y; r[e] = rv; }
 }
 
 __global__ __launch_bounds__(256) void k_norm2(const double2* __restrict__ a, long long n2, double* __restrict__ partials) {
@@ -250,7 +252,9 @@ int vec_unpack(pdegpu_ctx* ctx, const GridDev& g, const double* dense, double* v
 
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink) {
     const long long n2 = (long long)g.nkl * g.PP / 2;
-    hipLaunchKernelGGL(k_membench, dim3(flat_grid(ctx, n2)), dim3(256), 0, ctx->stream, which, reinterpret_cast<double2*>(r),
+    const long long nb = (n2 + 255) / 256;
+    if (nb > 0x7fffffffLL) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "membench: slab too large for a one-shot grid");
+    hipLaunchKernelGGL(k_membench, dim3((unsigned)nb), dim3(256), 0, ctx->stream, which, reinterpret_cast<double2*>(r),
                        reinterpret_cast<const double2*>(q), reinterpret_cast<double2*>(b), n2, 0.0, sink);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;

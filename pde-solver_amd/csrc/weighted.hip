@@ -119,9 +119,9 @@ extern "C" int pdegpu_weighted_rows_host(const pdegpu_grid* grid, const pdegpu_w
     if (!grid || !weight || !rowsK || !rowsM || !load || grid->dim < 1 || grid->dim > 3) return PDEGPU_EINVAL;
     const int kind = weight->kind;
     const double* origin = weight->origin;
-    if (kind < PDEGPU_WEIGHT_R || kind > PDEGPU_WEIGHT_RCYL) return PDEGPU_EINVAL;
+    if (kind < PDEGPU_WEIGHT_ONE || kind > PDEGPU_WEIGHT_RCYL) return PDEGPU_EINVAL;
     if (kind == PDEGPU_WEIGHT_R2SIN && grid->dim < 2) return PDEGPU_EINVAL;
-    if (kind == PDEGPU_WEIGHT_RCYL && grid->dim < 3) return PDEGPU_EINVAL;
+    if ((kind == PDEGPU_WEIGHT_RCYL || kind == PDEGPU_WEIGHT_ONE) && grid->dim < 3) return PDEGPU_EINVAL;
     double h[3] = {1, 1, 1}, lengths[3] = {0, 0, 0};
     int nn[3] = {1, 1, 1};
     for (int r = 0; r < grid->dim; ++r) {

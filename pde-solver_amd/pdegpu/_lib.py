@@ -42,7 +42,7 @@ class Weight(C.Structure):
                 ("core_ratio", C.c_double)]
 
 
-WEIGHT_R, WEIGHT_R2, WEIGHT_R2SIN, WEIGHT_RCYL = 1, 2, 3, 4
+WEIGHT_ONE, WEIGHT_R, WEIGHT_R2, WEIGHT_R2SIN, WEIGHT_RCYL = 0, 1, 2, 3, 4
 
 
 class Elasticity(C.Structure):
@@ -80,6 +80,7 @@ SYMBOLS = {
     "pdegpu_heat_num_snapshots": (C.c_int, [C.POINTER(Heat)]),
     "pdegpu_heat_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_heat_solve_weighted": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.POINTER(Heat), _dp, _dp, C.POINTER(Stats)]),
+    "pdegpu_heat_solve_weighted_ic": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_weighted_rows_host": (C.c_int, [C.POINTER(Grid), C.POINTER(Weight), _dp, _dp, _dp]),
     "pdegpu_mass_solve": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, C.c_double, C.c_int, C.POINTER(Stats)]),
     "pdegpu_heat_apply": (C.c_int, [_vp, C.POINTER(Grid), C.c_double, C.c_double, _dp, _dp, _dp, C.c_int]),

@@ -16,7 +16,7 @@ from .fields import TimeSeriesField
 
 def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady, source_type, source_value, T_initial,
                  bc_mode, bc_value, bc_present, core_radius=0.0, core_ratio=1.0, rtol=None, max_iter=None,
-                 snapshot_stride=None, device=None):
+                 snapshot_stride=None, device=None, u0=None):
     lib = L.load_library()
     ctx = L.context(device)
     grid = L.make_grid(dim, n, lengths, L.ELEM_P1SPLIT)
@@ -44,7 +44,11 @@ def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady,
     n_snap = lib.pdegpu_heat_num_snapshots(h)
     values, times = np.empty((n_snap, N)), np.empty(n_snap)
     st = L.Stats()
-    L.check(ctx, lib.pdegpu_heat_solve_weighted(ctx, grid, w, h, L.dptr(values), L.dptr(times), st))
+    if u0 is not None and not steady:                                 # projected initial field (3-D tool, :672-687)
+        h.ic_type = L.IC_NODAL
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+    L.check(ctx, lib.pdegpu_heat_solve_weighted_ic(ctx, grid, w, h, L.dptr(u0) if (u0 is not None and not steady) else None,
+                                                   L.dptr(values), L.dptr(times), st))
     d = st.as_dict()
     d["snapshot_meta"] = stride_meta
     return values, times, d
@@ -151,14 +155,70 @@ def _solve_heat_3d_spherical_raw(r_inner: float, r_outer: float, nr: int, ntheta
     return TimeSeriesField(coords=coords, values=values, times=times, dim=3, meta=meta)
 
 
+def projected_trig_field(n, lengths, origin, initial_type, amplitude, wavenumber, device=None):
+    """`project(Expression(A cos|sin(k x) cos|sin(k y) cos|sin(k z), degree=2), V)` on the BoxMesh [origin, origin + lengths]
+    (fenics_mcp_server.py:672-687): P2-interpolated load on the host, consistent-mass solve on the GPU.  project() uses the plain dx
+    measure whatever the weight of the heat forms is."""
+    from .project import p2_expression_load, trig_product
+    lib = L.load_library()
+    ctx = L.context(device)
+    grid = L.make_grid(3, n, lengths, L.ELEM_P1SPLIT)
+    rhs = p2_expression_load(3, n, lengths, trig_product(initial_type, amplitude, wavenumber, 3), L.ELEM_P1SPLIT, origin=origin)
+    u0 = np.empty(rhs.shape[0])
+    st = L.Stats()
+    L.check(ctx, lib.pdegpu_mass_solve(ctx, grid, L.dptr(rhs), L.dptr(u0), 1e-13, 20000, st))
+    return u0
+
+
+def solve_heat_3d_box_core(Lx, Ly, Lz, nx, ny, nz, diffusivity, T_boundary, T_initial, dt, num_steps, core_radius, core_diffusivity,
+                           steady=False, source_type="none", source_value=0.0, initial_type="constant", initial_amplitude=1.0,
+                           initial_wavenumber=1.0, T_left=None, T_right=None, T_side=None, **opts) -> TimeSeriesField:
+    """`_solve_heat_3d_raw` on the plain box WITH a composite core (fenics_mcp_server.py:537-572): DG0 diffusivity, a simplex is
+    core when all its vertices and its midpoint lie within core_radius of the x-axis — on BoxMesh((0,0,0),(Lx,Ly,Lz)) that is the
+    quarter cylinder around the edge y = z = 0.  Unit weight (:647), every boundary-condition and initial-condition variant of the
+    box branch."""
+    directional = T_left is not None or T_right is not None or T_side is not None
+    if directional:
+        bc_mode = L.BC_DIRECTIONAL
+        bc_value = tuple(0.0 if v is None else float(v) for v in (T_left, T_right, T_side))
+        bc_present = tuple(0 if v is None else 1 for v in (T_left, T_right, T_side))
+    else:
+        bc_mode, bc_value, bc_present = L.BC_UNIFORM, (T_boundary, 0.0, 0.0), (1, 0, 0)
+    u0 = None
+    if not steady and initial_type in ("cosine", "sine"):
+        u0 = projected_trig_field((nx, ny, nz), (Lx, Ly, Lz), (0.0, 0.0, 0.0), initial_type, initial_amplitude, initial_wavenumber,
+                                  opts.get("device"))
+    values, times, st = run_weighted(3, (nx, ny, nz), (Lx, Ly, Lz), (0.0, 0.0, 0.0), L.WEIGHT_ONE, kappa=diffusivity, dt=dt,
+                                     num_steps=num_steps, steady=steady, source_type=source_type, source_value=source_value,
+                                     T_initial=0.0 if initial_type == "zero" else T_initial, bc_mode=bc_mode, bc_value=bc_value,
+                                     bc_present=bc_present, core_radius=core_radius, core_ratio=core_diffusivity / diffusivity,
+                                     u0=u0, **opts)
+    x, y, z = _axes((nx, ny, nz), (0.0, 0.0, 0.0), (Lx, Ly, Lz))
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cartesian", "Lx": Lx, "Ly": Ly, "Lz": Lz,
+            "geometry_type": "box", "source_type": source_type, "source_value": source_value, "steady": steady}   # :721-733
+    if directional:
+        for k, v in (("T_left", T_left), ("T_right", T_right), ("T_side", T_side)):
+            if v is not None:
+                meta[k] = v
+    else:
+        meta["T_boundary"] = T_boundary
+    meta.update({"core_radius": core_radius, "core_diffusivity": core_diffusivity, "base_diffusivity": diffusivity})   # :747-750
+    meta.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"])})
+    meta.update(st.get("snapshot_meta", {"snapshot_stride": 1}))
+    return TimeSeriesField(coords=coords, values=values, times=times, dim=3, meta=meta)
+
+
 def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_initial, dt, num_steps, cylinder_radius,
                                     steady=False, source_type="none", source_value=0.0, T_left=None, T_right=None, T_side=None,
-                                    core_radius=None, core_diffusivity=None, **opts) -> TimeSeriesField:
+                                    core_radius=None, core_diffusivity=None, initial_type="constant", initial_amplitude=1.0,
+                                    initial_wavenumber=1.0, **opts) -> TimeSeriesField:
     """`_solve_heat_3d_raw(geometry_type="cylinder")` as the reference runs it without mshr (which is in neither its
     Dockerfile nor its requirements): fenics_mcp_server.py:523-529 BoxMesh (0,-R,-R)-(Lx,R,R) with int(ny*2R) x
     int(nz*2R) cells across, :645 weight sqrt(y^2+z^2) (degree 2), :537-572 per-cell core diffusivity, :582-604
     directional conditions (on this mesh the `T_side` predicate matches no boundary facet), else T_boundary on the
-    whole box boundary (:626-628).  Constant initial condition."""
+    whole box boundary (:626-628).  Sine / cosine initial conditions are projected on the shifted mesh (:672-687)."""
     R = float(cylinder_radius)
     ny2, nz2 = int(ny * R * 2), int(nz * R * 2)
     if ny2 < 1 or nz2 < 1:
@@ -171,11 +231,15 @@ def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_i
     else:
         bc_mode, bc_value, bc_present = L.BC_UNIFORM, (T_boundary, 0.0, 0.0), (1, 0, 0)
     composite = core_radius is not None and core_diffusivity is not None
+    u0 = None
+    if not steady and initial_type in ("cosine", "sine"):                          # :672-687 on the shifted BoxMesh
+        u0 = projected_trig_field((nx, ny2, nz2), (Lx, 2 * R, 2 * R), (0.0, -R, -R), initial_type, initial_amplitude,
+                                  initial_wavenumber, opts.get("device"))
     values, times, st = run_weighted(3, (nx, ny2, nz2), (Lx, 2 * R, 2 * R), (0.0, -R, -R), L.WEIGHT_RCYL, kappa=diffusivity, dt=dt,
                                      num_steps=num_steps, steady=steady, source_type=source_type, source_value=source_value,
                                      T_initial=T_initial, bc_mode=bc_mode, bc_value=bc_value, bc_present=bc_present,
                                      core_radius=core_radius if composite else 0.0,
-                                     core_ratio=core_diffusivity / diffusivity if composite else 1.0, **opts)
+                                     core_ratio=core_diffusivity / diffusivity if composite else 1.0, u0=u0, **opts)
     x, y, z = _axes((nx, ny2, nz2), (0.0, -R, -R), (Lx, 2 * R, 2 * R))
     Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
     coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)

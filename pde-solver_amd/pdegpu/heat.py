@@ -134,21 +134,25 @@ def _solve_heat_3d_raw(Lx: float, Ly: float, Lz: float, nx: int, ny: int, nz: in
                        T_right: Optional[float] = None, T_side: Optional[float] = None,
                        core_radius: Optional[float] = None, core_diffusivity: Optional[float] = None,
                        **opts) -> TimeSeriesField:
-    """fenics_mcp_server.py:475-762, box branch (:533, 574, 606-628, 647, 653-716).  The mshr cylinder mesh
-    (:512-530) and the composite core (:537-572) are outside the accelerated path."""
+    """fenics_mcp_server.py:475-762: box branch (:533, 574, 606-628, 647, 653-716), its composite core (:537-572) and the
+    BoxMesh fallback of the cylinder (:523-529) with every initial condition; only a true mshr cylinder mesh (:512-521,
+    unstructured; mshr is in neither the reference's Dockerfile nor its requirements) is outside the path."""
     if geometry_type == "cylinder" and cylinder_radius is not None:
         # :512-530 — the reference meshes a true cylinder with mshr when it is installed; it is in neither its Dockerfile
         # nor its requirements.txt, so what actually runs is the BoxMesh fallback with the sqrt(y^2+z^2) weight
-        if initial_type in ("cosine", "sine"):
-            raise NotImplementedError("projected sine/cosine initial conditions are built for the box branch only")
         from .curvilinear import solve_heat_3d_cylinder_fallback
         return solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, 0.0 if initial_type == "zero" else T_initial,
                                                dt, num_steps, cylinder_radius, steady=steady, source_type=source_type,
                                                source_value=source_value, T_left=T_left, T_right=T_right, T_side=T_side,
-                                               core_radius=core_radius, core_diffusivity=core_diffusivity, **opts)
-    if core_radius is not None and core_diffusivity is not None:
-        raise NotImplementedError("the composite core is built for the cylinder (BoxMesh fallback) branch; on the plain box "
-                                  "the reference marks cells by distance from the x-axis as well, which is not restated")
+                                               core_radius=core_radius, core_diffusivity=core_diffusivity,
+                                               initial_type=initial_type, initial_amplitude=initial_amplitude,
+                                               initial_wavenumber=initial_wavenumber, **opts)
+    if core_radius is not None and core_diffusivity is not None:                        # :537-572 on the plain box
+        from .curvilinear import solve_heat_3d_box_core
+        return solve_heat_3d_box_core(Lx, Ly, Lz, nx, ny, nz, diffusivity, T_boundary, T_initial, dt, num_steps, core_radius,
+                                      core_diffusivity, steady=steady, source_type=source_type, source_value=source_value,
+                                      initial_type=initial_type, initial_amplitude=initial_amplitude,
+                                      initial_wavenumber=initial_wavenumber, T_left=T_left, T_right=T_right, T_side=T_side, **opts)
     directional = T_left is not None or T_right is not None or T_side is not None      # :578
     if directional:                                                                     # :606-623
         bc_mode = L.BC_DIRECTIONAL

@@ -41,13 +41,14 @@ def _simplex_integral(d, *powers):
     return num / math.factorial(sum(powers) + d)
 
 
-def p2_expression_load(dim, n, Ls, fn, element_mode=0) -> np.ndarray:
-    """b[N] (x fastest) with b_i = sum_T int_T I2(f) lambda_i, I2 = P2 interpolant of fn on T."""
+def p2_expression_load(dim, n, Ls, fn, element_mode=0, origin=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """b[N] (x fastest) with b_i = sum_T int_T I2(f) lambda_i, I2 = P2 interpolant of fn on T; the mesh is
+    [origin, origin + Ls] (the BoxMesh fallback of the cylinder starts at (0, -R, -R))."""
     n = [int(n[r]) if r < dim else 0 for r in range(3)]
     h = [float(Ls[r]) / n[r] if r < dim else 0.0 for r in range(3)]
     shape = tuple(n[r] + 1 for r in (2, 1, 0))                                    # [z][y][x]
     b = np.zeros(shape)
-    cell_axes = [np.arange(n[r]) * h[r] if r < dim else np.zeros(1) for r in range(3)]
+    cell_axes = [float(origin[r]) + np.arange(n[r]) * h[r] if r < dim else np.zeros(1) for r in range(3)]
     Z0, Y0, X0 = np.meshgrid(cell_axes[2], cell_axes[1], cell_axes[0], indexing="ij")   # cell origins
     vol = np.prod([h[r] for r in range(dim)]) / math.factorial(dim)
     w_vs = 2 * _simplex_integral(dim, 3) - _simplex_integral(dim, 2)              # vertex basis, same vertex

@@ -98,6 +98,42 @@ def test_3d_cylinder_boxmesh_fallback(lib, gpu_ctx, case):
     _check(got, ref)
 
 
+@pytest.mark.parametrize("kind", ["cosine", "sine"])
+def test_cylinder_fallback_projected_trig_initial_condition(lib, gpu_ctx, kind):
+    """sine / cosine initial conditions on the cylinder branch (:672-687): project(Expression(degree=2), V) on the shifted BoxMesh
+    with the plain dx measure, then the weighted backward-Euler steps; with a composite core on top"""
+    from pdegpu import heat
+    kw = dict(Lx=1.2, nx=6, ny=7, nz=5, diffusivity=0.9, T_boundary=3.0, T_initial=60.0, dt=0.01, num_steps=2, cylinder_radius=0.5,
+              initial_type=kind, initial_amplitude=40.0, initial_wavenumber=2.3, core_radius=0.25, core_diffusivity=12.0)
+    ref = o.solve_heat_3d_cylinder_fallback(**kw)
+    got = heat._solve_heat_3d_raw(Ly=1.0, Lz=1.0, geometry_type="cylinder", rtol=1e-12, **kw)
+    _check(got, ref)
+    interior = ~o.box_dirichlet(6, 7, 5, T_boundary=3.0)[0]
+    assert np.abs(ref.values[0][interior]).max() > 5.0                       # the projected field really is the trigonometric one
+
+
+@pytest.mark.parametrize("case", [
+    dict(),                                                                  # uniform boundary value, constant initial field
+    dict(steady=True, source_type="constant", source_value=30.0),
+    dict(initial_type="cosine", initial_amplitude=25.0, initial_wavenumber=1.7),
+    dict(initial_type="zero", T_left=90.0, T_side=10.0),                     # directional: x = Lx stays natural
+    dict(T_left=50.0, steady=True, source_type="constant", source_value=4.0),
+])
+def test_3d_box_with_composite_core(lib, gpu_ctx, case):
+    """the composite core of solve_heat_3D on the PLAIN box (:537-572, unit weight :647): cells within core_radius of the x-axis
+    — the box edge y = z = 0 — carry core_diffusivity"""
+    from pdegpu import heat
+    kw = dict(Lx=1.0, Ly=0.8, Lz=0.9, nx=7, ny=8, nz=9, diffusivity=1.0, T_boundary=20.0, T_initial=70.0, dt=0.005, num_steps=3,
+              core_radius=0.45, core_diffusivity=35.0)
+    kw.update(case)
+    ref = o.solve_heat_3d(**kw)
+    plain = o.solve_heat_3d(**{k: v for k, v in kw.items() if not k.startswith("core_")})
+    assert rel_err(ref.values[-1], plain.values[-1]) > 1e-4                 # the core matters in this set-up
+    got = heat._solve_heat_3d_raw(rtol=1e-12, **kw)
+    _check(got, ref)
+    assert got.meta["core_radius"] == 0.45 and "diffusivity" not in got.meta and got.meta["geometry_type"] == "box"
+
+
 def test_cylinder_through_the_tool_and_params(lib, gpu_ctx, tmp_path):
     import pickle
     from pdegpu import server

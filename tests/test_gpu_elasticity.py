@@ -141,7 +141,8 @@ def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
 
 
 @pytest.mark.parametrize("nslabs", [1, 2, 3])
-def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs):
+@pytest.mark.parametrize("packed", [False, True])
+def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, packed):
     """the multi-GPU elasticity path on ONE GPU: slab sessions (ghost planes, global boundary classes), halo exchange of
     z and p (3 components each) and the scalar all-reduces done by device copies in the order pdegpu.dist.SlabCG uses;
     then von Mises + project() from the gathered displacement.  Must reproduce the oracle."""
@@ -160,6 +161,17 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs):
         engs = [GpuElasticitySlabEngine(grid, el, *slab_range(n[2] + 1, nslabs, r), 0, stream) for r in range(nslabs)]
 
         def exchange():
+            if packed:
+                # ONE contiguous message per neighbour (the driver's protocol): pack, move the two buffers, unpack
+                for e in engs:
+                    e.halo_pack()
+                for r in range(nslabs - 1):
+                    lo, hi = engs[r], engs[r + 1]
+                    hi.halo_buffer(1, 0).copy_(lo.halo_buffer(0, 1))
+                    lo.halo_buffer(1, 1).copy_(hi.halo_buffer(0, 0))
+                for e in engs:
+                    e.halo_unpack()
+                return
             for r in range(nslabs - 1):
                 lo, hi = engs[r], engs[r + 1]
                 for a, b in zip(hi.halo_tensors(-1), lo.halo_tensors(lo.nk - 1)):

@@ -315,7 +315,8 @@ def test_fast_and_general_sessions_agree(lib, gpu_ctx):
 
 @pytest.mark.parametrize("fast,variant", [(1, 1), (1, 0), (0, 0), (2, 1)])
 @pytest.mark.parametrize("nslabs", [2, 3])
-def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs):
+@pytest.mark.parametrize("split", [False, True])
+def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs, split):
     """slab sessions (k0 > 0, ghost planes, global boundary classes) with the halo exchange / all-reduce done by
     plain device copies on ONE GPU: same order of operations as pdegpu.dist.SlabCG.iterate, no RCCL needed.
     Must reproduce the single-slab CG iterates and the oracle's solution."""
@@ -366,9 +367,18 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs)
             allreduce(1)
             hist = [engs[0].rr()]
             for it in range(iters):
-                exchange()
-                for e in engs:
-                    e.k1()
+                if split:
+                    # the overlapped order of SlabCG.iterate: the bulk of K1 runs BEFORE the ghost planes arrive
+                    assert all(e.can_split_k1() == (fast == 1) for e in engs)
+                    for e in engs:
+                        e.k1_part(0)
+                    exchange()
+                    for e in engs:
+                        e.k1_part(1)
+                else:
+                    exchange()
+                    for e in engs:
+                        e.k1()
                 allreduce(0)
                 for e in engs:
                     e.k2()
@@ -386,7 +396,9 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs)
                 e.close()
         return np.concatenate(xs), np.array(hist)
 
+    split, keep = False, split
     x1, h1 = solve(1)
+    split = keep
     xs, hs = solve(nslabs)
     ref = o.solve_heat_3d(*Ls, *n, 1.1, 0.25, 0.0, 0.1, 1, steady=True, source_type="constant", source_value=3.0,
                           **(dict(T_left=0.25) if hybrid else {})).values[0]
@@ -600,16 +612,20 @@ def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, ca
     assert np.array_equal(alt.values, base.values)
 
 
-@pytest.mark.parametrize("setting", [dict(fast_ry=1), dict(fast_ry=4), dict(fast_ry=8), dict(fast_nt=0), dict(fast_nt=3), dict(fast_ex=0),
-                                     dict(fast_wg_per_cu=2), dict(fast_wg_per_cu_k2=3), dict(grid_mult=2), dict(k2_grid_mult=8),
+@pytest.mark.parametrize("setting", [dict(fast_ry=1), dict(fast_ry=2), dict(fast_ry=4), dict(fast_ry=8), dict(fast_nt=0), dict(fast_nt=3), dict(fast_ex=0),
+                                     dict(fast_wg_per_cu=2), dict(fast_wg_per_cu=6), dict(fast_wg_per_cu_k2=3), dict(grid_mult=2), dict(k2_grid_mult=8),
                                      dict(extrapolate=0), dict(hybrid_bc=0), dict(fast_minlen=4), dict(fast_small_mult=4),
-                                     dict(cg_variant=0), dict(cg_variant=0, fast_ex=0, fast_ry=4)])
+                                     dict(cg_variant=0), dict(cg_variant=0, fast_ex=0, fast_ry=4), dict(fast_ex_all=1), dict(fast_pf=1),
+                                     dict(fast_ex_all=1, fast_pf=1, fast_ry=4), dict(fast_zlen=3), dict(tile3d_max_nodes=0),
+                                     # per-mode configuration words: ry + 16 wg + 256 ex + 512 pf
+                                     dict(fast_cfg_plain=4 + 16 * 2 + 512, fast_cfg_res=2 + 256 + 512, fast_cfg_k1=4 + 16 * 3 + 256, fast_cfg_k2=1 + 16 + 512)])
 def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kernel_form):
     """'results do not depend on the tunables' (include/pdegpu.h): each one, away from its default, on a 3-D steady (7-point,
     64-B variant), a 3-D transient (15-point) and a natural-face problem, against the default run"""
     from pdegpu import heat, _lib
-    defaults = dict(fast_ry=2, fast_nt=-1, fast_ex=1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, extrapolate=1,
-                    hybrid_bc=1, fast_minlen=1, fast_small_mult=1, cg_variant=1)
+    defaults = dict(fast_ry=0, fast_nt=-1, fast_ex=1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, extrapolate=1,
+                    hybrid_bc=1, fast_minlen=1, fast_small_mult=1, cg_variant=1, fast_ex_all=0, fast_pf=0, fast_zlen=0, tile3d_max_nodes=3000000,
+                    fast_cfg_plain=-1, fast_cfg_res=-1, fast_cfg_k1=-1, fast_cfg_k2=-1)
     def runs():
         a = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 140, 13, 11, 0.9, 1.5, 20.0, 0.003, 1, steady=True, source_type="constant", source_value=2.0, rtol=1e-12)
         b = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 30, 17, 12, 0.9, 1.5, 20.0, 0.003, 3, rtol=1e-12)
@@ -625,3 +641,62 @@ def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kerne
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), defaults[k]))
     for x, y in zip(alt, base):
         assert rel_err(x.values, y.values) < TOL
+
+
+@pytest.mark.parametrize("n,Ls", [((2, 2), (1.0, 1.0)), ((5, 3), (1.0, 0.4)), ((130, 37), (1.0, 0.6)), ((300, 513), (0.7, 1.3)),
+                                  ((1023, 260), (2.0, 0.5)), ((640, 2049), (1.0, 3.0))])
+def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib, gpu_ctx, n, Ls):
+    """the register-resident cooperative CG of the 2-D tools (persist2d.hip: bands of 1 / 2 / 4 / 8 rows, short last bands, fewer
+    bands than CUs, 1- and 8-wave-wide grids, a one-node grid) against the launch-per-kernel loop (persist2d = 0) — same
+    iteration counts to +-2, fields to 1e-10 — and, where the sparse LU is affordable, against the oracle"""
+    from pdegpu import heat, _lib
+    kw = dict(Lx=Ls[0], Ly=Ls[1], nx=n[0], ny=n[1], diffusivity=0.9, T_boundary=1.5, T_initial=20.0, dt=0.002, num_steps=2)
+
+    def run(persist, **extra):
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", persist))
+        try:
+            return heat._solve_heat_2d_raw(**{**kw, **extra}, rtol=1e-12)
+        finally:
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", 1))
+
+    for extra in (dict(), dict(steady=True, source_type="constant", source_value=3.0)):
+        a, b = run(1, **extra), run(0, **extra)
+        assert a.meta["solver_path"] == "fast"
+        assert abs(a.meta["cg_iterations"] - b.meta["cg_iterations"]) <= 2 * (1 if extra else kw["num_steps"]) + 2
+        assert rel_err(a.values, b.values) < 1e-10
+        if (n[0] + 1) * (n[1] + 1) <= 200000:
+            assert rel_err(a.values, o.solve_heat_2d(**{**kw, **extra}).values) < TOL
+
+
+def test_persistent_2d_cg_session_iterate_leaves_the_state_of_the_stepwise_loop(lib, gpu_ctx):
+    """pdegpu_session_iterate on a 2-D session: N iterations in ONE cooperative launch leave r.r, x (after flush) and the scalars
+    where N launches of K1 / K2 leave them (summation orders differ: 1e-12)"""
+    import ctypes as C
+    from pdegpu import _lib
+    grid = _lib.make_grid(2, (257, 91), (1.0, 0.4))
+    h = _lib.Heat()
+    h.kappa, h.dt, h.steady, h.source = 1.0, 0.0, 1, 2.0
+    h.bc_mode, h.fast_path = _lib.BC_UNIFORM, 1
+    h.bc_present[0], h.bc_value[0] = 1, 0.5
+    out = []
+    for persist in (1, 0):
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", persist))
+        s = C.c_void_p()
+        _lib.check(gpu_ctx, lib.pdegpu_session_create(gpu_ctx, grid, h, 0, 1, C.byref(s)))
+        try:
+            _lib.check(gpu_ctx, lib.pdegpu_session_begin(s, 0.0))
+            _lib.check(gpu_ctx, lib.pdegpu_session_residual(s))
+            hist = []
+            for chunk in (1, 2, 7, 30):
+                _lib.check(gpu_ctx, lib.pdegpu_session_iterate(s, chunk, 0, None))
+                rr = C.c_double()
+                _lib.check(gpu_ctx, lib.pdegpu_session_rr(s, C.byref(rr)))
+                hist.append(rr.value)
+            _lib.check(gpu_ctx, lib.pdegpu_session_flush(s))
+            x = np.empty(258 * 92)
+            _lib.check(gpu_ctx, lib.pdegpu_session_get_x(s, _lib.dptr(x)))
+            out.append((np.array(hist), x))
+        finally:
+            lib.pdegpu_session_destroy(s)
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", 1))
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-10) and rel_err(out[0][1], out[1][1]) < 1e-12

@@ -104,3 +104,55 @@ def test_cylinder_fallback_restatement():
     # u == T_b fixed point
     k = o.solve_heat_3d_cylinder_fallback(2.0, 3, 4, 4, 1.0, 7.0, 7.0, 0.01, 2, cylinder_radius=0.5)
     assert np.abs(k.values - 7.0).max() < 1e-12
+
+
+def test_unit_weight_is_the_plain_assembly_and_the_core_factor_scales_whole_cells():
+    """the "one" weight kind (composite core on the plain box): K, M, load equal the unweighted assembly; with a per-cell
+    factor the stiffness is the cell-wise weighted sum; the host twin of the GPU's per-node rows reproduces both"""
+    import ctypes as C
+    from pdegpu import _lib as L
+    n, Ls = (4, 3, 5), (1.0, 0.6, 0.9)
+    coords, cells = o.box_mesh(*Ls, *n)
+    K0, M0, l0 = o.assemble_scalar(coords, cells)
+    K1, M1, l1 = o.assemble_weighted(coords, cells, "one")
+    assert abs(K1 - K0).max() < 1e-14 and abs(M1 - M0).max() < 1e-15 and np.abs(l1 - l0).max() < 1e-15
+    core = o.core_cells(coords, cells, 0.5)
+    assert 0 < core.sum() < cells.shape[0]
+    Kc, _, _ = o.assemble_weighted(coords, cells, "one", np.where(core, 9.0, 1.0))
+    Kin, _, _ = o.assemble_weighted(coords, cells[core], "one")
+    assert abs((Kc - K0) - 8.0 * Kin).max() < 1e-12
+    # host twin of k_weighted_assemble (kind 0 + core) against the oracle's assembled rows
+    lib = L.load_library()
+    grid = L.make_grid(3, n, Ls)
+    w = L.Weight()
+    w.kind, w.core_radius, w.core_ratio = L.WEIGHT_ONE, 0.5, 9.0
+    N = coords.shape[0]
+    rK, rM, ld = np.zeros((N, 15)), np.zeros((N, 15)), np.zeros(N)
+    assert lib.pdegpu_weighted_rows_host(grid, w, L.dptr(rK.reshape(-1)), L.dptr(rM.reshape(-1)), L.dptr(ld)) == 0
+    offs = [13, 12, 14, 10, 16, 4, 22, 9, 17, 3, 23, 1, 25, 0, 26]
+    NX, NY = n[0] + 1, n[1] + 1
+    Kd, Md = Kc.toarray(), M0.toarray()
+    for q, oid in enumerate(offs):
+        dx, dy, dz = oid % 3 - 1, (oid // 3) % 3 - 1, oid // 9 - 1
+        for i in range(N):
+            ix, iy, iz = i % NX, (i // NX) % NY, i // (NX * NY)
+            jx, jy, jz = ix + dx, iy + dy, iz + dz
+            inside = 0 <= jx < NX and 0 <= jy < NY and 0 <= jz <= n[2]
+            j = (jz * NY + jy) * NX + jx
+            assert abs(rK[i, q] - (Kd[i, j] if inside else 0.0)) < 1e-12 and abs(rM[i, q] - (Md[i, j] if inside else 0.0)) < 1e-14
+    assert np.abs(ld - l0).max() < 1e-15
+
+
+def test_box_core_and_cylinder_trig_restatements():
+    """oracle-side sanity of the two (f) leftovers: the core changes the box solution and leaves the metadata of :747-753; the
+    cylinder branch with a cosine initial field starts from the projected field (not the constant)"""
+    a = o.solve_heat_3d(1.0, 0.8, 0.9, 5, 6, 7, 1.0, 20.0, 70.0, 0.01, 2, core_radius=0.45, core_diffusivity=30.0)
+    b = o.solve_heat_3d(1.0, 0.8, 0.9, 5, 6, 7, 1.0, 20.0, 70.0, 0.01, 2)
+    assert np.abs(a.values[-1] - b.values[-1]).max() > 1e-2 and np.array_equal(a.values[0], b.values[0])
+    assert a.meta["base_diffusivity"] == 1.0 and a.meta["core_diffusivity"] == 30.0 and "diffusivity" not in a.meta
+    c = o.solve_heat_3d_cylinder_fallback(1.0, 5, 6, 6, 1.0, 0.0, 50.0, 0.01, 1, cylinder_radius=0.5, initial_type="cosine",
+                                          initial_amplitude=10.0, initial_wavenumber=1.0)
+    ctr = np.argmin(np.linalg.norm(c.coords - np.array([0.0, 0.0, 0.0]), axis=1))
+    x0 = np.argmin(np.linalg.norm(c.coords - np.array([0.4, 0.0, 0.0]), axis=1))
+    assert c.values[0, ctr] == 0.0                                              # boundary node: bc.apply after the projection
+    assert abs(c.values[0, x0] - 10.0 * np.cos(0.4)) < 0.5                      # interior: ~ A cos(kx) cos(0) cos(0)

@@ -9,7 +9,7 @@ sys.path[:0] = [str(ROOT), str(ROOT / "pde-solver_amd")]
 import numpy as np
 import torch, torch.distributed as dist
 from pdegpu import _lib as L
-from pdegpu.dist import GpuSlabEngine, SlabCG, slab_range
+from pdegpu.dist import GpuSlabEngine, SlabCG, gather_slabs, slab_range, solve_heat_slabs
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 120
@@ -32,13 +32,12 @@ with torch.cuda.stream(stream):
         cg.iterate(10)
         hist.append(eng.rr())
     cg.finish()
-    x = np.empty(nk * (n + 1) * (n + 1))
-    L.check(eng.ctx, lib.pdegpu_session_get_x(eng.s, L.dptr(x)))
+    assert eng.can_split_k1() and cg.overlap          # the overlapped order: K1's bulk runs before the ghost planes arrive
+    x = eng.owned_x()
     eng.close()
-parts = [None] * world
-dist.all_gather_object(parts, x)
+xs = gather_slabs(x, nzg + 1, rank, world)             # fp64 tensors to rank 0 (no pickling)
 if rank == 0:
-    xs = np.concatenate(parts)
+    xs = xs.ravel()
     with torch.cuda.stream(stream):
         one = GpuSlabEngine(grid, heat, 0, nzg + 1, 0, stream)
         c1 = SlabCG(one, 0, 1)
@@ -55,5 +54,15 @@ if rank == 0:
     hrel = max(abs(a - b) / b for a, b in zip(hist, h1))
     print(f"rehearsal world={world} cells={n}x{n}x{nzg}: max rel diff of x vs single slab {rel:.2e}, residual history rel diff {hrel:.2e}, rr {hist[-1]:.6e}", flush=True)
     assert rel < 1e-11 and hrel < 1e-9
+# the tool-level distributed solve: three backward-Euler steps of a box whose longest axis is x (the slabs must cut it), against
+# the single-GPU tool
+m = (3 * n // 2, n // 2, n // 2 + 1)
+out = solve_heat_slabs(m, (1.5, 0.5, 0.6), 1.3, 0.5, T_initial=20.0, dt=0.01, num_steps=3, source=2.0, rtol=1e-12)
+if rank == 0:
+    from pdegpu import heat as H
+    one = H._solve_heat_3d_raw(1.5, 0.5, 0.6, *m, 1.3, 0.5, 20.0, 0.01, 3, source_type="constant", source_value=2.0, rtol=1e-12)
+    rel = np.abs(out["values"].reshape(4, -1) - one.values).max() / np.abs(one.values).max()
+    print(f"solve_heat_slabs world={world} cells={m}: 4 states vs the single-GPU tool, max rel diff {rel:.2e}, iterations {out['iterations']}", flush=True)
+    assert rel < 1e-9 and np.allclose(out["times"], one.times)
     print("REHEARSAL OK", flush=True)
 dist.destroy_process_group()
