@@ -73,12 +73,21 @@ def cpu_baseline(n_cells: int, budget_s: float = 12.0):
     """same-algorithm CPU baseline: oracle/cg_port.c (classic matrix-free CG, OpenMP) on this host's cores.
     Bounded sample: the same n^3 grid, as many iterations as fit in ~budget_s (at least 3)."""
     from oracle import cg_port
-    threads = max(1, min(cg_port.max_threads(), effective_cpus()))
     nodes = n_cells + 1
     h = 1.0 / n_cells
     w = cg_port.p1_weights((h, h, h), 0.0, 1.0)
     unknowns = (nodes - 2) ** 3
-    secs, _, _ = cg_port.run((nodes,) * 3, w, h ** 3, 0.0, 2, threads)          # calibration (2 iterations)
+    # thread count: the cgroup quota says what the box may use on average, but the kernel still schedules every thread of the
+    # affinity mask; calibrate (2 iterations each) over the quota and a few wider teams and keep the fastest
+    aff = len(os.sched_getaffinity(0))
+    cands = sorted({max(1, min(cg_port.max_threads(), c)) for c in (effective_cpus(), 8, 16, 32) if c <= aff} | {max(1, min(cg_port.max_threads(), effective_cpus()))})
+    best = None
+    for c in cands:
+        secs, _, _ = cg_port.run((nodes,) * 3, w, h ** 3, 0.0, 2, c)
+        log(f"cpu baseline calibration: {c} threads -> {secs / 2 * 1e3:.0f} ms per iteration")
+        if best is None or secs < best[1]:
+            best = (c, secs)
+    threads, secs = best
     per_iter = max(secs / 2, 1e-6)
     iters = int(max(3, min(200, budget_s / per_iter)))
     secs, rr, _ = cg_port.run((nodes,) * 3, w, h ** 3, 0.0, iters, threads)
@@ -86,7 +95,8 @@ def cpu_baseline(n_cells: int, budget_s: float = 12.0):
     # + p update (read r, p; write p) = 14 vector passes of 8 B = 112 B per unknown and iteration
     return {"value": unknowns * iters / secs, "unit": "DoF/s", "cores": threads, "kind": "port",
             "sample": f"{iters} CG iterations of the same {n_cells}^3 steady heat system (oracle/cg_port.c, "
-                      f"classic unfused CG, OpenMP static, {threads} threads); the reference's own algorithm "
+                      f"classic unfused CG, OpenMP static, {threads} threads = the fastest of {cands} on this host: affinity {aff}, "
+                      f"cgroup quota {effective_cpus()}); the reference's own algorithm "
                       f"(sparse LU per step, FEniCS 2019.1.0) is not installable offline: see reference_algorithm",
             "ms_per_step": secs / iters * 1e3, "achieved_GBps": 112.0 * nodes ** 3 * iters / secs / 1e9,
             "bytes_per_dof_model": 112}

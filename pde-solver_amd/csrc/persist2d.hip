@@ -61,7 +61,7 @@ struct P2dArgs {
     double* scal;              // SC_* block of the session (read at entry, written at exit)
     double* part;              // [2][G] per-workgroup partial sums, by phase parity
     double* pub;               // [2][G][PX]: first / last active row of r of every band
-    unsigned* sync;            // [0] barrier counter, [1] failure flag, [2] iterations done (all zeroed by the host before the launch)
+    unsigned* sync;            // SY_* words: barrier counters, failure flag, iterations done (all zeroed by the host before the launch)
     int iters_max;
     double target;             // stop as soon as r.r <= target (0: never)
     int G;                     // workgroups = bands
@@ -70,25 +70,84 @@ struct P2dArgs {
 
 constexpr int kNW = 8;         // waves per workgroup: 8 x 128 = 1024 columns
 
-// arrive + wait: returns false when the grid has failed (this workgroup's spin ran out or another one raised the flag)
-__device__ __forceinline__ bool grid_barrier(const P2dArgs& a, unsigned& epoch, int* sFail) {
+// words of the sync block (zeroed by the host before every launch); counters that many workgroups hit sit on lines of their own
+enum { SY_FLAT = 0, SY_FAIL = 1, SY_ITERS = 2, SY_POP = 16 /* [8] */, SY_CNT = 32 /* [8] x 16 words */, SY_TOP = 160, SY_GEN = 176 /* [8] x 16 words */,
+       SY_WORDS = 320 };
+
+struct BarrierState {
+    unsigned epoch = 0;        // hierarchical barriers passed
+    int xcc = 0;               // group key of this workgroup: the XCD it runs on (speed only — any partition of the grid is correct)
+    unsigned npop = 0;         // workgroups of this group
+    unsigned ngroups = 0;      // non-empty groups
+    bool leader = false;       // first workgroup of its group to arrive at the census
+};
+
+__device__ __forceinline__ bool poll_ge(const P2dArgs& a, const unsigned* word, unsigned want, bool nap) {
+    for (int spins = 0;; ++spins) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        if (__hip_atomic_load(a.sync + SY_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins >= a.spin_limit) {
+            __hip_atomic_store(a.sync + SY_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        if (nap) __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// census + one flat barrier at kernel start: every workgroup registers with the group of its XCD; afterwards each knows the size
+// of its group, whether it leads it, and how many groups exist.  false = the grid failed.
+__device__ __forceinline__ bool barrier_init(const P2dArgs& a, BarrierState& bs, int* sShared /* >= 4 ints */) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // HW_REG_XCC_ID (id 20), bits [3:0]: which of the 8 XCDs this workgroup was placed on
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+        const unsigned ticket = __hip_atomic_fetch_add(a.sync + SY_POP + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.sync + SY_FLAT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool okb = poll_ge(a, a.sync + SY_FLAT, (unsigned)a.G, true);
+        unsigned npop = 0, ngroups = 0;
+        if (okb) {
+            for (int x = 0; x < 8; ++x) {
+                const unsigned c = __hip_atomic_load(a.sync + SY_POP + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ngroups += c > 0u ? 1u : 0u;
+                if (x == xcc) npop = c;
+            }
+        }
+        sShared[0] = okb ? 1 : 0;
+        sShared[1] = xcc;
+        sShared[2] = (int)npop;
+        sShared[3] = (int)(ngroups | (ticket == 0u ? 0x100u : 0u));
+    }
+    __syncthreads();
+    bs.xcc = sShared[1];
+    bs.npop = (unsigned)sShared[2];
+    bs.ngroups = (unsigned)sShared[3] & 0xffu;
+    bs.leader = (sShared[3] & 0x100) != 0;
+    const bool okb = sShared[0] != 0;
+    __syncthreads();
+    return okb;
+}
+
+// XCD-hierarchical grid barrier (MI355X_MICROARCH.md price list, row barrier-xcd: 4.1 us at 256 workgroups against 7.4 for one flat
+// counter — 256 arrivals on ONE word serialise at ~12 ns each): every workgroup arrives on its group's counter; the group leader
+// waits for its group, arrives on the top counter, waits for all leaders and publishes the group's generation word, which the
+// other workgroups of the group poll.  Payload: sc1 stores drained before the arrival, sc1 loads after the release (see header).
+__device__ __forceinline__ bool grid_barrier(const P2dArgs& a, BarrierState& bs, int* sFail) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave: its sc1 stores have left
     __syncthreads();
-    ++epoch;
+    ++bs.epoch;
     if (threadIdx.x == 0) {
-        const unsigned want = epoch * (unsigned)a.G;
-        __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int fail = 0;
-        for (int spins = 0;; ++spins) {
-            if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-            if (__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins >= a.spin_limit) {
-                __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fail = 1;
-                break;
+        bool okb = true;
+        __hip_atomic_fetch_add(a.sync + SY_CNT + 16 * bs.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bs.leader) {
+            okb = poll_ge(a, a.sync + SY_CNT + 16 * bs.xcc, bs.npop * bs.epoch, false);
+            if (okb) {
+                __hip_atomic_fetch_add(a.sync + SY_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                okb = poll_ge(a, a.sync + SY_TOP, bs.ngroups * bs.epoch, false);
             }
-            __builtin_amdgcn_s_sleep(2);
+            if (okb) __hip_atomic_store(a.sync + SY_GEN + 16 * bs.xcc, bs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            okb = poll_ge(a, a.sync + SY_GEN + 16 * bs.xcc, bs.epoch, true);
         }
-        *sFail = fail;
+        *sFail = okb ? 0 : 1;
     }
     __syncthreads();
     return *sFail == 0;
@@ -123,6 +182,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
     __shared__ double sRed[kNW];
     __shared__ double sEdge[RB + 2][kNW][2];
     __shared__ int sFail;
+    __shared__ int sCensus[4];
     const GridDev& g = a.g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x;
     const int i0 = wv * 128 + 2 * lane;
@@ -155,10 +215,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
     RH[1] = (nact == RB) ? ld2(a.r, j0 + RB) : make_double2(0.0, 0.0);
     double pq = a.scal[SC_PQ], rr = a.scal[SC_RR], rr_prev = a.scal[SC_RR_PREV];
 
-    unsigned epoch = 0;
+    BarrierState bs;
     int it = 0;
-    bool ok = true;
-    while (it < a.iters_max && !(a.target > 0.0 && rr <= a.target)) {
+    bool ok = barrier_init(a, bs, sCensus);
+    unsigned phase = 0;                                          // dot-product phases completed (parity selects the partial buffer)
+    while (ok && it < a.iters_max && !(a.target > 0.0 && rr <= a.target)) {
         const double alpha_prev = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
         const double beta = (rr_prev > 0.0) ? rr / rr_prev : 0.0;
         // ---- K1: x += alpha_{n-1} p_{n-1};  p_n = r_n + beta p_{n-1} on the band AND its two halo rows ---------------------
@@ -204,9 +265,10 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
             acc += P[c].x * Q[q].x + P[c].y * Q[q].y;
         }
         const double pq_loc = block_sum(acc, sRed);
-        if (threadIdx.x == 0) st_sc1(a.part + (size_t)(epoch & 1u) * a.G + b, pq_loc);
-        const unsigned ph1 = epoch & 1u;
-        ok = grid_barrier(a, epoch, &sFail);
+        const unsigned ph1 = phase & 1u;
+        if (threadIdx.x == 0) st_sc1(a.part + (size_t)ph1 * a.G + b, pq_loc);
+        ++phase;
+        ok = grid_barrier(a, bs, &sFail);
         if (!ok) break;
         pq = sum_partials(a.part + (size_t)ph1 * a.G, a.G, sRed);
         const double alpha = (pq > 0.0) ? rr / pq : 0.0;
@@ -219,7 +281,9 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
             acc += R[q].x * R[q].x + R[q].y * R[q].y;
         }
         const double rr_loc = block_sum(acc, sRed);
-        if (threadIdx.x == 0) st_sc1(a.part + (size_t)(epoch & 1u) * a.G + b, rr_loc);
+        const unsigned ph2 = phase & 1u;
+        if (threadIdx.x == 0) st_sc1(a.part + (size_t)ph2 * a.G + b, rr_loc);
+        ++phase;
         if (col_ok) {
             double2 first = R[0], last = R[0];
 #pragma unroll
@@ -232,8 +296,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
             st_sc1(pl, last.x);
             st_sc1(pl + 1, last.y);
         }
-        const unsigned ph2 = epoch & 1u;
-        ok = grid_barrier(a, epoch, &sFail);
+        ok = grid_barrier(a, bs, &sFail);
         if (!ok) break;
         const double rr_new = sum_partials(a.part + (size_t)ph2 * a.G, a.G, sRed);
         // halo rows of r for the next p: the band below's LAST row, the band above's FIRST row (boundary rows are zero)
@@ -268,7 +331,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
         a.scal[SC_RR] = rr;
         a.scal[SC_RR_LOCAL] = rr;
         a.scal[SC_RR_PREV] = rr_prev;
-        a.sync[2] = (unsigned)it;
+        a.sync[SY_ITERS] = (unsigned)it;
     }
 }
 
@@ -295,7 +358,8 @@ void persist2d_free(Persist2d* p) {
 // rows per band and band count for this grid, or false when the grid does not fit the register-resident form
 static bool persist2d_shape(const pdegpu_ctx* ctx, const GridDev& g, int* rb, int* G) {
     if (g.dim != 2 || g.NX < 3 || g.NY < 3) return false;
-    if (g.PX > kNW * 128) return false;                          // one band spans the full width with 8 waves
+    if (g.NX - 1 > kNW * 128) return false;                      // one band spans the columns 0 .. NX-2 with 8 waves (the last column is a
+                                                                 // Dirichlet column: CG vectors vanish there and x never changes)
     const int rows = g.NY - 2;
     int need = (rows + ctx->num_cu - 1) / ctx->num_cu;           // one workgroup per CU
     int r = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 0)));
@@ -317,7 +381,7 @@ int persist2d_create(pdegpu_ctx* ctx, const GridDev& g, Persist2d** out) {
     p->G = G;
     p->rb = rb;
     if (hipMalloc(&p->part, 2 * (size_t)G * sizeof(double)) != hipSuccess || hipMalloc(&p->pub, 2 * (size_t)G * g.PX * sizeof(double)) != hipSuccess ||
-        hipMalloc(&p->sync, 64) != hipSuccess || hipHostMalloc(&p->h_sync, 64) != hipSuccess) {
+        hipMalloc(&p->sync, SY_WORDS * sizeof(unsigned)) != hipSuccess || hipHostMalloc(&p->h_sync, 64) != hipSuccess) {
         persist2d_free(p);
         return pdegpu_set_err(ctx, PDEGPU_EHIP, "persistent 2-D CG: allocation failed");
     }
@@ -346,7 +410,7 @@ int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double*
     a.target = target;
     a.G = p->G;
     a.spin_limit = 2000000;                                      // ~ seconds: far beyond any barrier of a healthy grid
-    PG_HIP(ctx, hipMemsetAsync(p->sync, 0, 64, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(p->sync, 0, SY_WORDS * sizeof(unsigned), ctx->stream));
     void* args[] = {&a};
     const void* fn = nullptr;
     switch (p->rb) {

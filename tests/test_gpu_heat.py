@@ -262,8 +262,28 @@ def test_trivial_and_edge_cases(lib, gpu_ctx):
         heat._solve_heat_3d_raw(1, 1, 1, 0, 4, 4, 1.0, 0.0, 20.0, 0.01, 1)
     with pytest.raises(_lib.PdeGpuError):
         heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, -1.0, 0.0, 20.0, 0.01, 1)
-    with pytest.raises(NotImplementedError):                       # composite core on the plain box branch is not restated
-        heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 1, core_radius=0.2, core_diffusivity=5.0)
+    with pytest.raises(_lib.PdeGpuError):                          # composite core: the ratio core / base diffusivity must be positive
+        heat._solve_heat_3d_raw(1, 1, 1, 4, 4, 4, 1.0, 0.0, 20.0, 0.01, 1, core_radius=0.2, core_diffusivity=-5.0)
+    # the stride taken from the environment is the one meta reports
+    import os
+    os.environ["PDEGPU_SNAPSHOT_STRIDE"] = "3"
+    try:
+        env = heat._solve_heat_3d_raw(1, 1, 1, 6, 6, 6, 1.0, 0.0, 20.0, 0.01, 5, rtol=1e-12)
+    finally:
+        del os.environ["PDEGPU_SNAPSHOT_STRIDE"]
+    assert env.meta["snapshot_stride"] == 3 and np.allclose(env.times, [0.0, 0.03, 0.05]) and full.meta["snapshot_stride"] == 1
+    # the output budget: 6 states of 343 nodes do not fit 10 kB -> strided automatically, recorded in meta; or refused
+    os.environ["PDEGPU_MAX_OUTPUT_GB"] = "1e-5"
+    try:
+        auto = heat._solve_heat_3d_raw(1, 1, 1, 6, 6, 6, 1.0, 0.0, 20.0, 0.01, 5, rtol=1e-12)
+        assert auto.meta["snapshot_stride"] > 1 and auto.meta["snapshot_stride_requested"] == 1 and "auto-strided" in auto.meta["snapshot_policy"]
+        assert auto.values.shape[0] * 343 * 8 <= 1e4 and np.array_equal(auto.values[-1], full.values[-1]) and np.array_equal(auto.values[0], full.values[0])
+        os.environ["PDEGPU_OUTPUT_POLICY"] = "error"
+        with pytest.raises(_lib.PdeGpuError, match="snapshot_stride"):
+            heat._solve_heat_3d_raw(1, 1, 1, 6, 6, 6, 1.0, 0.0, 20.0, 0.01, 5, rtol=1e-12)
+    finally:
+        del os.environ["PDEGPU_MAX_OUTPUT_GB"]
+        os.environ.pop("PDEGPU_OUTPUT_POLICY", None)
 
 
 def test_q1_mode_differs_by_h2(lib, gpu_ctx):
@@ -662,7 +682,9 @@ def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib,
     for extra in (dict(), dict(steady=True, source_type="constant", source_value=3.0)):
         a, b = run(1, **extra), run(0, **extra)
         assert a.meta["solver_path"] == "fast"
-        assert abs(a.meta["cg_iterations"] - b.meta["cg_iterations"]) <= 2 * (1 if extra else kw["num_steps"]) + 2
+        # the cooperative launch stops at the first iteration with r.r <= target; the polled loop may run up to a chunk longer
+        solves = 1 if extra else kw["num_steps"]
+        assert b.meta["cg_iterations"] - 64 * solves <= a.meta["cg_iterations"] <= b.meta["cg_iterations"] + 2 * solves
         assert rel_err(a.values, b.values) < 1e-10
         if (n[0] + 1) * (n[1] + 1) <= 200000:
             assert rel_err(a.values, o.solve_heat_2d(**{**kw, **extra}).values) < TOL

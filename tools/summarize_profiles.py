@@ -59,11 +59,16 @@ for k in sorted(set(fetch) | set(write)):
                              "hbm_bytes": 2 * fm * 1024 + wm * 1024}
 (out / f"{rnd}{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1))
 import re
+import subprocess
+try:
+    commit = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+except OSError:
+    commit = "unknown"
 k1 = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 2[,>]", k)]
 if k1:
-    (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "source": f"{rnd}{tag}_pmc_summary.json"}))
+    (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "source": f"{rnd}{tag}_pmc_summary.json", "commit": commit}))
 k2 = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 3[,>]", k)]
 if k1 and k2:
     (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "k2_hbm_bytes_per_launch": k2[0]["hbm_bytes"],
-                                                      "source": f"{rnd}{tag}_pmc_summary.json"}))
+                                                      "source": f"{rnd}{tag}_pmc_summary.json", "commit": commit}))
 print(json.dumps(summary, indent=1)[:3000])
