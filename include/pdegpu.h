@@ -122,7 +122,8 @@ const char* pdegpu_version(void);
  * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_ex" (1 = LDS hand-off of tile-edge values in the CG kernels), "fast_ex_all" (1 = also in the bare apply / residual pass), "fast_pf" (1 = the one-vector marching modes request plane k+2 before computing plane k), "fast_wg_per_cu" (0 = occupancy API),
  * "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
  * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration; 0 = K1 stores q, 72 B/DoF), "use_graph"
- * (1 = replay the CG inner loop from a captured hipGraph), "inlaunch_dot" (1 = finish dot products inside the producing
+ * (1 = replay the CG inner loop from a captured hipGraph; opt-in, no measured gain, and NOT profilable: rocprofv3 7.2 aborted on
+ * graph launches in round 1), "inlaunch_dot" (1 = finish dot products inside the producing
  * launch instead of a separate one-workgroup reduce launch; measured slower), "lazy_dot" (1 = the next
  * kernel's prologue sums the previous launch's partials, no reduce launches inside a single-slab CG chunk; same bits),
  * "direct_1d" (1 = 1-D grids use the Thomas recurrence inside one launch, 0 = CG), "el_fast" (1 = 3-D elasticity
@@ -130,8 +131,10 @@ const char* pdegpu_version(void);
  * "el_fast_yx" (1 = y-halo rows handed between the workgroup's waves through LDS), "hybrid_bc" (1 = 3-D grids with natural faces: marching kernel on the interior + class-table
  * kernel on the boundary nodes), "extrapolate" (1 = transient solves start CG from 2 u^n - u^{n-1}), "fast_minlen" /
  * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2",
- * "plane2d" / "plane2d_ry" (2-D grids: CG kernels as one-round tiles), "tile3d_max_nodes" (3-D grids up to this many nodes:
- * CG kernels as one-round tiles; 0 = always march).
+ * "plane2d" / "plane2d_ry" (2-D grids: CG kernels as one-round tiles), "persist2d" (1 = 2-D grids up to 1024 cells wide and 8 rows per
+ * CU run their whole CG loop in ONE cooperative launch with the state in registers), "tile3d_max_nodes" (3-D grids up to this many
+ * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "fast_cfg_plain|res|k1|k2" (per-mode
+ * word ry + 16 wg + 256 ex + 512 pf, -1 = global tunables), "el_fast_xface" (1 = x-face rows inside the elasticity marching kernel).
  * Results do not depend on them beyond the solver tolerance. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 

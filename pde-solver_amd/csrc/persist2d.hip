@@ -66,6 +66,7 @@ struct P2dArgs {
     double target;             // stop as soon as r.r <= target (0: never)
     int G;                     // workgroups = bands
     int spin_limit;
+    int barrier_kind;          // 1: sharded counters polled by every workgroup; 2: XCD-hierarchical (leaders + generation words)
 };
 
 constexpr int kNW = 8;         // waves per workgroup: 8 x 128 = 1024 columns
@@ -130,7 +131,41 @@ __device__ __forceinline__ bool barrier_init(const P2dArgs& a, BarrierState& bs,
 // counter — 256 arrivals on ONE word serialise at ~12 ns each): every workgroup arrives on its group's counter; the group leader
 // waits for its group, arrives on the top counter, waits for all leaders and publishes the group's generation word, which the
 // other workgroups of the group poll.  Payload: sc1 stores drained before the arrival, sc1 loads after the release (see header).
+// Sharded form (a.barrier_kind == 1, the default): every workgroup adds to the counter of its group and then polls ALL eight
+// group counters itself — eight lanes, one load instruction, one memory round trip per poll — until they sum to G x epoch.  No
+// leader hop, no generation word: arrive + one or two polls (measured against the leader form in tools/c2_persist.py).
+__device__ __forceinline__ bool grid_barrier_sharded(const P2dArgs& a, BarrierState& bs, int* sFail) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave: its sc1 stores have left
+    __syncthreads();
+    ++bs.epoch;
+    if (threadIdx.x < 64) {                                             // wave 0 polls; the other waves wait at the barrier below
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_fetch_add(a.sync + SY_CNT + 16 * bs.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)a.G * bs.epoch;
+        int fail = 0;
+        for (int spins = 0;; ++spins) {
+            unsigned v = 0;
+            if (lane < 8) v = __hip_atomic_load(a.sync + SY_CNT + 16 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 8) v = __hip_atomic_load(a.sync + SY_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 0x40000000u : 0u;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v >= 0x40000000u || spins >= a.spin_limit) {
+                if (lane == 0) __hip_atomic_store(a.sync + SY_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fail = 1;
+                break;
+            }
+            if (v >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) *sFail = fail;
+    }
+    __syncthreads();
+    return *sFail == 0;
+}
+
 __device__ __forceinline__ bool grid_barrier(const P2dArgs& a, BarrierState& bs, int* sFail) {
+    if (a.barrier_kind == 1) return grid_barrier_sharded(a, bs, sFail);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave: its sc1 stores have left
     __syncthreads();
     ++bs.epoch;
@@ -410,6 +445,7 @@ int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double*
     a.target = target;
     a.G = p->G;
     a.spin_limit = 2000000;                                      // ~ seconds: far beyond any barrier of a healthy grid
+    a.barrier_kind = ctx->persist2d == 2 ? 2 : 1;
     PG_HIP(ctx, hipMemsetAsync(p->sync, 0, SY_WORDS * sizeof(unsigned), ctx->stream));
     void* args[] = {&a};
     const void* fn = nullptr;

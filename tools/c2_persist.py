@@ -12,7 +12,7 @@ for n in (1024, 512, 256, 2048):
         st = 10
     else:
         st = steps
-    for persist in (1, 0, 1, 0):
+    for persist in (1, 2, 0, 1, 2, 0):          # 1: sharded-poll barrier, 2: XCD-hierarchical barrier, 0: one launch per kernel
         L.check(ctx, lib.pdegpu_set_tunable(ctx, b"persist2d", persist))
         t0 = time.perf_counter()
         f = heat._solve_heat_2d_raw(1.0, 1.0, n, n, 1.0, 0.0, 20.0, 0.0025, st)
