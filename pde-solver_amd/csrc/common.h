@@ -53,6 +53,7 @@ struct pdegpu_ctx {
     int persist2d = 1;          // 2-D grids up to 1024 cells wide and 8 rows per CU: the whole CG loop in ONE cooperative launch with the state
                                 // in registers (persist2d.hip); 0 = one launch per kernel
     int plane2d = 1;            // 2-D grids: 1 = the two CG kernels load their tile in one round (k_plane2d); 0 = flat view of the marching kernels
+    int hybrid_fx = 1;          // hybrid sessions: 1 = the marching kernel computes the x-face rows too (the class-table pass keeps the y / z faces)
     int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary
                                 // nodes; 0 = class-table kernel everywhere
     int extrapolate = 1;        // transient solves start CG from 2 u^n - u^{n-1} instead of u^n (fewer iterations, same tolerance)
@@ -205,7 +206,11 @@ struct StencilArgs {
     int bnd_lkb = 0;          // first local plane that is interior in z
     int bnd_ring = 0;         // boundary nodes of such a plane: 2 NX + 2 (NY - 2)
     int bnd_xcover = 0;       // columns [0, bnd_xcover) of interior rows get p / x from the marching kernel (128-node tiles)
-    int free_x = 0;           // marching kernel: the x-faces carry unknowns (their CG vectors are not zero: load them)
+    int fx_hi = 0;            // free_x == 2: the tiles reach the node NX-1 (no extra tile is spent on it: a fifth, one-node tile column
+                              // per 513-node row was measured 27 % SLOWER than leaving that column to the class-table pass)
+    int bnd_xcols = 2;        // boundary pass: x-face columns of the interior rows it still owns (2 both, 1 only x = NX-1, 0 none)
+    int free_x = 0;           // marching kernel: 1 = the x-faces carry unknowns (their CG vectors are not zero: load them); 2 = and the
+                              // x-face nodes of interior rows are computed by the marching kernel itself (edge lanes, halved in-face terms)
     int lk_lo = 0, lk_hi = 0; // marching kernel: restrict the launch to the local planes [lk_lo, lk_hi) (lk_hi > lk_lo; 0, 0 = all).  The
                               // multi-GPU loop launches K1 on the planes away from the ghosts first (halo exchange in flight)
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position

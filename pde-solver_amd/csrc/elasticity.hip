@@ -369,7 +369,10 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
             bool row_out[RH];
 #pragma unroll
             for (int r = 0; r < RH; ++r) row_out[r] = out_x && !ghost_wave && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
-            const long long col = (long long)(j0 - 1) * g.PX + i;
+            // lanes beyond the padded row (the last 62-node tile overshoots: 558 columns for a 513-node row) read the row's last pad
+            // entry instead of the next row's data: same cache line as real data, no traffic of their own (9 % of the loads at
+            // NX = 513); what they hold never reaches a stored output
+            const long long col = (long long)(j0 - 1) * g.PX + (i < g.PX ? i : g.PX - 1);
             double Pm[RH][3], P0[RH][3], Pp[RH][3];
             auto load_plane = [&](int lk, double (*P)[3]) {
                 const long long base = (long long)lk * g.PP + col;

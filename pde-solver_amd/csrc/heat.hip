@@ -184,7 +184,11 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     a.bnd_full_hi = g.k0 + g.nkl == g.NZ ? 1 : 0;
     a.bnd_lkb = a.bnd_full_lo;
     const int planes = std::max(0, g.nkl - a.bnd_full_lo - a.bnd_full_hi);
-    a.bnd_ring = 2 * g.NX + 2 * (g.NY - 2);
+    // free_x == 2: the marching kernel has done the x-face nodes of the interior rows — x = 0 always, x = NX-1 when its tiles reach
+    // it (a.fx_hi); otherwise that one column stays here
+    const bool fx = a.free_x == 2;
+    a.bnd_xcols = fx ? (a.fx_hi ? 0 : 1) : 2;
+    a.bnd_ring = 2 * g.NX + a.bnd_xcols * (g.NY - 2);
     a.bnd_xcover = std::min(g.PX, ((g.NX - 1 + 127) / 128) * 128);
     a.bnd_n = (long long)(a.bnd_full_lo + a.bnd_full_hi) * g.NX * g.NY + (long long)planes * a.bnd_ring;
     if (a.bnd_n <= 0) return PDEGPU_OK;
@@ -227,7 +231,8 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
         a.g = s->gk;
         fast_weights(htab, a.w, s->gk.flat2d != 0);
         a.npt = s->grid.element_mode == PDEGPU_ELEM_Q1 ? 27 : (is_seven_point(a.w) ? 7 : 15);
-        a.free_x = s->hybrid ? 1 : 0;
+        a.free_x = s->hybrid ? (s->ctx->hybrid_fx ? 2 : 1) : 0;
+        a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
         LaunchInfo lf;
         PG_TRY(stencil_fast(s->ctx, a, APPLY_PLAIN, &lf));
         return s->hybrid ? hybrid_boundary(s, a, APPLY_PLAIN, &lf) : PDEGPU_OK;
@@ -261,7 +266,8 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
-        a.free_x = s->hybrid ? 1 : 0;
+        a.free_x = s->hybrid ? (s->ctx->hybrid_fx ? 2 : 1) : 0;
+        a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
         if (s->hybrid) a.dot_which = -1;
         PG_TRY(stencil_fast(s->ctx, a, APPLY_RESIDUAL, li));
         return s->hybrid ? hybrid_boundary(s, a, APPLY_RESIDUAL, li) : PDEGPU_OK;
@@ -317,7 +323,8 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
-        a.free_x = s->hybrid ? 1 : 0;
+        a.free_x = s->hybrid ? (s->ctx->hybrid_fx ? 2 : 1) : 0;
+        a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
         if (s->hybrid) a.dot_which = -1;
         rc = stencil_fast(s->ctx, a, APPLY_CG_K1, li);
         if (rc == PDEGPU_OK && s->hybrid) rc = hybrid_boundary(s, a, APPLY_CG_K1, li);
@@ -422,7 +429,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "plane2d", "persist2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "plane2d", "persist2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -456,6 +463,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "lazy_dot")) return &ctx->lazy_dot;
     if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
     if (!strcmp(key, "hybrid_bc")) return &ctx->hybrid_bc;
+    if (!strcmp(key, "hybrid_fx")) return &ctx->hybrid_fx;
     if (!strcmp(key, "plane2d")) return &ctx->plane2d;
     if (!strcmp(key, "persist2d")) return &ctx->persist2d;
     if (!strcmp(key, "tile3d_max_nodes")) return &ctx->tile3d_max_nodes;

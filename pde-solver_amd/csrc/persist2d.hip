@@ -66,7 +66,8 @@ struct P2dArgs {
     double target;             // stop as soon as r.r <= target (0: never)
     int G;                     // workgroups = bands
     int spin_limit;
-    int barrier_kind;          // 1: sharded counters polled by every workgroup; 2: XCD-hierarchical (leaders + generation words)
+    int barrier_kind;          // 1: XCD-hierarchical (group leaders + generation words; default); 2: sharded counters polled by every
+                               // workgroup; 3: hierarchical arrival, every workgroup polls the top counter
 };
 
 constexpr int kNW = 8;         // waves per workgroup: 8 x 128 = 1024 columns
@@ -131,9 +132,10 @@ __device__ __forceinline__ bool barrier_init(const P2dArgs& a, BarrierState& bs,
 // counter — 256 arrivals on ONE word serialise at ~12 ns each): every workgroup arrives on its group's counter; the group leader
 // waits for its group, arrives on the top counter, waits for all leaders and publishes the group's generation word, which the
 // other workgroups of the group poll.  Payload: sc1 stores drained before the arrival, sc1 loads after the release (see header).
-// Sharded form (a.barrier_kind == 1, the default): every workgroup adds to the counter of its group and then polls ALL eight
+// Sharded form (a.barrier_kind == 2): every workgroup adds to the counter of its group and then polls ALL eight
 // group counters itself — eight lanes, one load instruction, one memory round trip per poll — until they sum to G x epoch.  No
-// leader hop, no generation word: arrive + one or two polls (measured against the leader form in tools/c2_persist.py).
+// leader hop, no generation word; measured SLOWER than the leader form (config 2: 13.9-14.1 against 12.8-13.6 us per iteration,
+// tools/c2_persist.py): 256 pollers on the eight counter lines slow the arrivals down.
 __device__ __forceinline__ bool grid_barrier_sharded(const P2dArgs& a, BarrierState& bs, int* sFail) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave: its sc1 stores have left
     __syncthreads();
@@ -165,7 +167,7 @@ __device__ __forceinline__ bool grid_barrier_sharded(const P2dArgs& a, BarrierSt
 }
 
 __device__ __forceinline__ bool grid_barrier(const P2dArgs& a, BarrierState& bs, int* sFail) {
-    if (a.barrier_kind == 1) return grid_barrier_sharded(a, bs, sFail);
+    if (a.barrier_kind == 2) return grid_barrier_sharded(a, bs, sFail);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave: its sc1 stores have left
     __syncthreads();
     ++bs.epoch;
@@ -178,7 +180,9 @@ __device__ __forceinline__ bool grid_barrier(const P2dArgs& a, BarrierState& bs,
                 __hip_atomic_fetch_add(a.sync + SY_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 okb = poll_ge(a, a.sync + SY_TOP, bs.ngroups * bs.epoch, false);
             }
-            if (okb) __hip_atomic_store(a.sync + SY_GEN + 16 * bs.xcc, bs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (okb && a.barrier_kind != 3) __hip_atomic_store(a.sync + SY_GEN + 16 * bs.xcc, bs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (a.barrier_kind == 3) {
+            okb = poll_ge(a, a.sync + SY_TOP, bs.ngroups * bs.epoch, true);      // every workgroup watches the top counter: one hop less
         } else {
             okb = poll_ge(a, a.sync + SY_GEN + 16 * bs.xcc, bs.epoch, true);
         }
@@ -445,7 +449,7 @@ int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double*
     a.target = target;
     a.G = p->G;
     a.spin_limit = 2000000;                                      // ~ seconds: far beyond any barrier of a healthy grid
-    a.barrier_kind = ctx->persist2d == 2 ? 2 : 1;
+    a.barrier_kind = (ctx->persist2d == 2 || ctx->persist2d == 3) ? ctx->persist2d : 1;
     PG_HIP(ctx, hipMemsetAsync(p->sync, 0, SY_WORDS * sizeof(unsigned), ctx->stream));
     void* args[] = {&a};
     const void* fn = nullptr;

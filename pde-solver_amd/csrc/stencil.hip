@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
                     const int t = (int)(e % (unsigned)a.bnd_ring);
                     if (t < g.NX) { j = 0; i = t; }
                     else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
+                    else if (a.bnd_xcols == 1) { j = 1 + (t - 2 * g.NX); i = g.NX - 1; }      // only the column x = NX-1 is left to this pass
                     else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
                 }
             }
@@ -273,8 +274,19 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         const double shift = a.in_shift;
 
         const bool lane_ok = active && i0 < g.PX;             // pair inside the padded row
-        const bool ma = active && (i0 >= 1) && (i0 <= g.NX - 2);   // node a = i0 is an interior (free) node
-        const bool mb = active && (i0 + 1 <= g.NX - 2);       // node b = i0+1
+        // free_x == 2 (natural-face sessions): the x-face nodes of interior rows are computed HERE.  On the host tables the class of
+        // an x-face is the interior stencil with the in-face (dx = 0) terms halved, the inward dx = -+1 terms unchanged and the
+        // outward ones absent (K and M, P1 and Q1, any h): q_face = D / 2 + (inward shifted part).  Per-lane factors, all 1 away
+        // from the faces; a Dirichlet face keeps its factors at 1 and is masked as before.
+        const bool fx = a.free_x == 2;
+        const bool lo_free = fx && g.bc_mode == PDEGPU_BC_DIRECTIONAL && !g.bc_present[0];
+        const bool hi_free = fx && a.fx_hi && g.bc_mode == PDEGPU_BC_DIRECTIONAL && !g.bc_present[1];
+        const int xlo = lo_free ? 0 : 1, xhi = hi_free ? g.NX - 1 : g.NX - 2;
+        const bool ma = active && (i0 >= xlo) && (i0 <= xhi);      // node a = i0 is a free node computed by this kernel
+        const bool mb = active && (i0 + 1 <= xhi);                 // node b = i0+1
+        const bool fa_lo = lo_free && i0 == 0, fa_hi = hi_free && i0 == g.NX - 1, fb_hi = hi_free && i0 + 1 == g.NX - 1;
+        const double sa = (fa_lo || fa_hi) ? 0.5 : 1.0, la = fa_lo ? 0.0 : 1.0, ra = fa_hi ? 0.0 : 1.0;
+        const double sb = fb_hi ? 0.5 : 1.0, rb = fb_hi ? 0.0 : 1.0;
         const bool edge_lane = (lane == 0) || (lane == 63);
         const long long edge_off = (lane == 0) ? -1 : 2;      // lane 0: node i0-1, lane 63: node i0+2
 
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     const int j = j0 + r;
-                    RHS[r] = make_double2(a.rhs_const, a.rhs_const);
+                    RHS[r] = make_double2(sa * a.rhs_const, sb * a.rhs_const);      // (a constant load is halved on an x-face)
                     if (a.rhs) {                                   // kernel-uniform; the load itself is unconditional (see value_row)
                         const bool ok = j <= fg.jmax && lane_ok;
                         RHS[r] = load_pair(a.rhs, ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0);
@@ -474,6 +486,10 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                     rC = (lane == 63) ? EC[c] : rC;
                     double qa = w0 * C[c].x + wx * (lC + C[c].y) + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x);
                     double qb = w0 * C[c].y + wx * (C[c].x + rC) + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y);
+                    if (fx && !W15) {                                 // 7-point with x-face rows (kernel-uniform branch)
+                        qa = sa * (w0 * C[c].x + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x)) + wx * (la * lC + ra * C[c].y);
+                        qb = sb * (w0 * C[c].y + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y)) + wx * (C[c].x + rb * rC);
+                    }
                     if (W27) {
                         // Q1: q = w0 C + wy Sy + wz Sz + wyz Syz + l(T) + r(T),  T = wx C + wxy Sy + wxz Sz + wxyz Syz with the row
                         // sums Sy = C[j-1] + C[j+1], Sz = P + N, Syz = P[j-1] + P[j+1] + N[j-1] + N[j+1]: two x-shifts per node
@@ -490,6 +506,10 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                         rT = (lane == 63) ? Te : rT;
                         qa = w0 * C[c].x + wy * Sy.x + wz * Sz.x + wyz * Syz.x + lT + T.y;
                         qb = w0 * C[c].y + wy * Sy.y + wz * Sz.y + wyz * Syz.y + T.x + rT;
+                        if (fx) {
+                            qa = sa * (w0 * C[c].x + wy * Sy.x + wz * Sz.x + wyz * Syz.x) + la * lT + ra * T.y;
+                            qb = sb * (w0 * C[c].y + wy * Sy.y + wz * Sz.y + wyz * Syz.y) + T.x + rb * rT;
+                        }
                     } else if (W15) {
                         // same-sign diagonals of the Kuhn split: +-(1,1,0), +-(1,0,1), +-(0,1,1), +-(1,1,1).  Everything whose
                         // source sits at x+1 is accumulated in U, at x-1 in L, and the x-shift is applied to the two sums:
@@ -505,6 +525,12 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                         rU = (lane == 63) ? Ue : rU;
                         qa = w0 * C[c].x + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x) + wyz * (N[c + 1].x + P[c - 1].x) + U.y + lL;
                         qb = w0 * C[c].y + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y) + wyz * (N[c + 1].y + P[c - 1].y) + rU + Lw.x;
+                        if (fx) {
+                            qa = sa * (w0 * C[c].x + wy * (C[c - 1].x + C[c + 1].x) + wz * (P[c].x + N[c].x) + wyz * (N[c + 1].x + P[c - 1].x)) +
+                                 ra * U.y + la * lL;
+                            qb = sb * (w0 * C[c].y + wy * (C[c - 1].y + C[c + 1].y) + wz * (P[c].y + N[c].y) + wyz * (N[c + 1].y + P[c - 1].y)) +
+                                 rb * rU + Lw.x;
+                        }
                     }
                     double2 o;
                     if (RES) {
@@ -812,8 +838,9 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
-FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0, int slack8 = 0) {
+FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0, int slack8 = 0, int cover_hi = 0) {
     FastGeom fg{};
+    (void)cover_hi;
     fg.ntx = (g.NX - 1 + 127) / 128;
     fg.jbase = g.flat2d ? 0 : 1;
     fg.jmax = g.flat2d ? 0 : g.NY - 2;

@@ -184,7 +184,8 @@ def test_heat_3d_wide_grid_fast_path(lib, gpu_ctx, cg_kernel_form):
 
 
 @pytest.mark.parametrize("bcs", [dict(T_left=10.0, T_right=1.0, T_side=None), dict(T_left=10.0, T_right=None, T_side=3.0),
-                                 dict(T_left=None, T_right=4.0, T_side=None), dict(T_left=5.0, T_right=6.0, T_side=7.0)])
+                                 dict(T_left=None, T_right=4.0, T_side=None), dict(T_left=5.0, T_right=6.0, T_side=7.0),
+                                 dict(T_left=None, T_right=None, T_side=2.5)])      # both x-faces natural: both computed by the marching kernel
 def test_heat_3d_directional_bc_natural_faces(lib, gpu_ctx, bcs):
     """faces left natural use the truncated class stencils (fenics_mcp_server.py:606-623)"""
     from pdegpu import heat
@@ -215,6 +216,31 @@ def test_hybrid_path_tile_edges_and_modes(lib, gpu_ctx, nx, steady):
     assert rel_err(a.values, b.values) < TOL
     if nx <= 130:
         assert rel_err(a.values, o.solve_heat_3d(**kw).values) < TOL
+
+
+@pytest.mark.parametrize("nx", [127, 128, 200])
+@pytest.mark.parametrize("steady", [False, True])
+def test_hybrid_x_faces_in_the_marching_kernel_q1_and_p1(lib, gpu_ctx, nx, steady):
+    """the x-face rows computed by the edge lanes of the marching kernel (halved in-face terms + inward coupling; 7-, 15- and
+    27-point forms) vs the class-table kernel everywhere (hybrid_fx = 0 and fast_path = 0), both element modes, faces free on
+    one or both sides; hybrid_fx = 1 and 0 must agree to round-off"""
+    from pdegpu import heat, _lib
+    for em in (_lib.ELEM_P1SPLIT, _lib.ELEM_Q1):
+        for bcs in (dict(T_left=3.0, T_right=None, T_side=None), dict(T_left=None, T_right=None, T_side=1.0)):
+            kw = dict(Lx=1.5, Ly=0.5, Lz=0.45, nx=nx, ny=6, nz=5, diffusivity=0.8, T_boundary=0.0, T_initial=2.0, dt=0.02, num_steps=2,
+                      source_type="constant", source_value=1.2, steady=steady, element_mode=em, **bcs)
+            a = heat._solve_heat_3d_raw(**kw, rtol=1e-12)
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"hybrid_fx", 0))
+            try:
+                b = heat._solve_heat_3d_raw(**kw, rtol=1e-12)
+            finally:
+                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"hybrid_fx", 1))
+            g = heat._solve_heat_3d_raw(**kw, rtol=1e-12, fast_path=False)
+            assert a.meta["solver_path"] == "fast+boundary" and g.meta["solver_path"] == "general"
+            assert rel_err(a.values, g.values) < TOL and rel_err(a.values, b.values) < 1e-10
+            if em == _lib.ELEM_P1SPLIT and nx <= 128:
+                ref = o.solve_heat_3d(**{k: v for k, v in kw.items() if k != "element_mode"})
+                assert rel_err(a.values, ref.values) < TOL
 
 
 @pytest.mark.parametrize("dim", [1, 2, 3])
@@ -634,7 +660,7 @@ def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, ca
 
 @pytest.mark.parametrize("setting", [dict(fast_ry=1), dict(fast_ry=2), dict(fast_ry=4), dict(fast_ry=8), dict(fast_nt=0), dict(fast_nt=3), dict(fast_ex=0),
                                      dict(fast_wg_per_cu=2), dict(fast_wg_per_cu=6), dict(fast_wg_per_cu_k2=3), dict(grid_mult=2), dict(k2_grid_mult=8),
-                                     dict(extrapolate=0), dict(hybrid_bc=0), dict(fast_minlen=4), dict(fast_small_mult=4),
+                                     dict(extrapolate=0), dict(hybrid_bc=0), dict(hybrid_fx=0), dict(fast_minlen=4), dict(fast_small_mult=4),
                                      dict(cg_variant=0), dict(cg_variant=0, fast_ex=0, fast_ry=4), dict(fast_ex_all=1), dict(fast_pf=1),
                                      dict(fast_ex_all=1, fast_pf=1, fast_ry=4), dict(fast_zlen=3), dict(tile3d_max_nodes=0),
                                      # per-mode configuration words: ry + 16 wg + 256 ex + 512 pf
@@ -644,7 +670,7 @@ def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kerne
     64-B variant), a 3-D transient (15-point) and a natural-face problem, against the default run"""
     from pdegpu import heat, _lib
     defaults = dict(fast_ry=0, fast_nt=-1, fast_ex=1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, extrapolate=1,
-                    hybrid_bc=1, fast_minlen=1, fast_small_mult=1, cg_variant=1, fast_ex_all=0, fast_pf=0, fast_zlen=0, tile3d_max_nodes=3000000,
+                    hybrid_bc=1, hybrid_fx=1, fast_minlen=1, fast_small_mult=1, cg_variant=1, fast_ex_all=0, fast_pf=0, fast_zlen=0, tile3d_max_nodes=3000000,
                     fast_cfg_plain=-1, fast_cfg_res=-1, fast_cfg_k1=-1, fast_cfg_k2=-1)
     def runs():
         a = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 140, 13, 11, 0.9, 1.5, 20.0, 0.003, 1, steady=True, source_type="constant", source_value=2.0, rtol=1e-12)
