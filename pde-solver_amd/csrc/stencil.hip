@@ -860,7 +860,11 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     const int xy = fg.nxg * fg.nyg;
     // one resident round: (workgroups that fit per CU) x CUs, at least 8 planes per chunk
     int target = wg_per_cu * ctx->num_cu;
-    if (slack8) target += target / 8;
+    // slack8 (HBM-resident grids, launch_fast): the chunk count is set directly — as few z-chunks as give every CU its
+    // wg_per_cu workgroups — instead of by the rounds x planes model below, which prefers many short chunks as soon as they
+    // pack the rounds a little better (512^3: 9 chunks = 2304 workgroups, measured slower in K2 / SpMV and +8 % HBM traffic
+    // against 2 chunks = 512 workgroups: profiles/r02_pmc_by_geometry.txt)
+    int direct_nzc = 0;
     // chunks of >= 8 planes keep the redundant two-plane prologue below 25 % when there is parallelism to spare; a grid too
     // small to fill the device is latency-bound on the serial march instead (every plane step is a dependent memory round
     // trip), so it gets shorter chunks (down to fast_minlen planes) and up to fast_small_mult resident rounds of workgroups
@@ -879,7 +883,12 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     // chunks that fill whole rounds beat one partly filled round.
     int nzc = 1;
     long long best = -1;
-    for (int c = 1; c <= maxc; ++c) {
+    if (slack8 && xy > 0) {
+        direct_nzc = (int)((target + xy - 1) / xy);
+        if (direct_nzc > maxc) direct_nzc = maxc;
+        if (direct_nzc < 1) direct_nzc = 1;
+    }
+    for (int c = 1; c <= maxc && direct_nzc == 0; ++c) {
         const long long rounds = ((long long)xy * c + target - 1) / (target > 0 ? target : 1);
         const long long cost = rounds * ((planes + c - 1) / c + 2);
         if (best < 0 || cost < best) {
@@ -887,6 +896,7 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
             nzc = c;
         }
     }
+    if (direct_nzc > 0) nzc = direct_nzc;
     if (ctx->fast_zlen > 0 && planes > 0) nzc = (planes + ctx->fast_zlen - 1) / ctx->fast_zlen;      // forced chunk length (tuning)
     {   // one partial per workgroup: the grid must fit the session's partial buffer
         const long long cap = stencil_max_partials(const_cast<pdegpu_ctx*>(ctx));
