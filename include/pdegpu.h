@@ -132,7 +132,8 @@ const char* pdegpu_version(void);
  * kernel on the boundary nodes), "extrapolate" (1 = transient solves start CG from 2 u^n - u^{n-1}), "fast_minlen" /
  * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2",
  * "plane2d" / "plane2d_ry" (2-D grids: CG kernels as one-round tiles), "persist2d" (1 = 2-D grids up to 1024 cells wide and 8 rows per
- * CU run their whole CG loop in ONE cooperative launch with the state in registers), "tile3d_max_nodes" (3-D grids up to this many
+ * CU run their whole CG loop in ONE cooperative launch with the state in registers; 2 / 3 = other grid-barrier forms), "persist2d_sr" (1 = that
+ * launch uses the single-reduction CG recurrences: one grid barrier + one neighbour hand-off per iteration), "tile3d_max_nodes" (3-D grids up to this many
  * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "fast_cfg_plain|res|k1|k2" (per-mode
  * word ry + 16 wg + 256 ex + 512 pf, -1 = global tunables), "el_fast_xface" (1 = x-face rows inside the elasticity marching kernel).
  * Results do not depend on them beyond the solver tolerance. */

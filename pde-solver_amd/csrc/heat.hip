@@ -429,7 +429,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "plane2d", "persist2d", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -466,6 +466,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "hybrid_fx")) return &ctx->hybrid_fx;
     if (!strcmp(key, "plane2d")) return &ctx->plane2d;
     if (!strcmp(key, "persist2d")) return &ctx->persist2d;
+    if (!strcmp(key, "persist2d_sr")) return &ctx->persist2d_sr;
     if (!strcmp(key, "tile3d_max_nodes")) return &ctx->tile3d_max_nodes;
     if (!strcmp(key, "plane2d_ry")) return &ctx->plane2d_ry;
     if (!strcmp(key, "fast_minlen")) return &ctx->fast_minlen;
@@ -837,11 +838,11 @@ bool use_persist2d(pdegpu_session* s) {
 }
 // up to `iters` iterations, stopping early at r.r <= target (target > 0); the scalars and x, r, p of the session are left exactly as
 // the launch-per-kernel loop leaves them (x lags by alpha p, p in p[pcur])
-int persist2d_iterate(pdegpu_session* s, int iters, double target, int* done) {
+int persist2d_iterate(pdegpu_session* s, int iters, double target, int* done, int fresh = 0) {
     if (!s->p2d) PG_TRY(persist2d_create(s->ctx, s->g, &s->p2d));
     double w5[8];
     plane2d_weights(s->hA, w5);
-    return persist2d_run(s->ctx, s->p2d, s->g, w5, s->x.v, s->r.v, s->p[s->pcur].v, s->p[s->pcur].v, s->d_scal, iters, target, done);
+    return persist2d_run(s->ctx, s->p2d, s->g, w5, s->x.v, s->r.v, s->p[s->pcur].v, s->p[s->pcur].v, s->d_scal, iters, target, done, fresh);
 }
 }  // namespace
 
@@ -1085,7 +1086,7 @@ int cg_solve(pdegpu_session* s, double bnorm2, double rr, double rtol, int max_i
             // one cooperative launch runs until r.r <= target (every workgroup holds the same r.r): no polling, no overshoot;
             // launches are cut at 8192 iterations only to keep a single launch short
             int done = 0;
-            PG_TRY(persist2d_iterate(s, std::min(8192, max_iter - it), target, &done));
+            PG_TRY(persist2d_iterate(s, std::min(8192, max_iter - it), target, &done, /*fresh=*/it == 0 ? 1 : 0));
             it += done;
             PG_TRY(pdegpu_session_rr(s, &rr));
             if (done == 0) break;

@@ -66,6 +66,8 @@ struct P2dArgs {
     double target;             // stop as soon as r.r <= target (0: never)
     int G;                     // workgroups = bands
     int spin_limit;
+    unsigned* flags;           // [G] x 16 words: epoch of the rows of r each band has published (single-reduction form)
+    int single_reduction;      // 1: Chronopoulos-Gear CG — one grid barrier + one neighbour hand-off per iteration (fresh solves only)
     int barrier_kind;          // 1: XCD-hierarchical (group leaders + generation words; default); 2: sharded counters polled by every
                                // workgroup; 3: hierarchical arrival, every workgroup polls the top counter
 };
@@ -374,6 +376,189 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Single-reduction form (Chronopoulos & Gear 1989): the same Krylov iterates in exact arithmetic, but both dot products of an
+// iteration, gamma = r.r and delta = (A r).r, are formed at the same point, so an iteration needs ONE grid barrier; the operator is
+// applied to r, whose band-edge rows travel to the two neighbouring bands through a flag hand-off (two workgroups, not the grid):
+//   p = r + beta p;  s = w + beta s  (s = A p by recurrence);  x += alpha p;  r -= alpha s;
+//   [publish first / last row of r, wait for the neighbours' rows]   w = A r;  gamma' = r.r, delta' = w.r   [grid barrier]
+//   beta' = gamma' / gamma;  alpha' = gamma' / (delta' - beta' gamma' / alpha)
+// Used for fresh solves only (it starts from p = s = 0); leaves x fully updated (no pending alpha p) and SC_PQ = 0.
+template <int RB>
+__global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_sr(P2dArgs a) {
+    __shared__ double sRed[kNW];
+    __shared__ double sEdge[RB + 2][kNW][2];
+    __shared__ int sFail;
+    __shared__ int sCensus[4];
+    const GridDev& g = a.g;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x;
+    const int i0 = wv * 128 + 2 * lane;
+    const int j0 = 1 + b * RB;
+    const bool col_ok = i0 < g.PX;
+    const bool ma = i0 >= 1 && i0 <= g.NX - 2, mb = i0 + 1 <= g.NX - 2;
+    const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wd1 = a.w[3], wd2 = a.w[4];
+    int nact = g.NY - 1 - j0;
+    if (nact > RB) nact = RB;
+    if (nact < 0) nact = 0;
+    double2 X[RB], P[RB], S[RB], W[RB], R[RB + 2];               // R[0], R[RB+1]: halo rows of r
+    auto ld2 = [&](const double* v, int j) {
+        const bool ok = col_ok && j >= 0 && j <= g.NY - 1;
+        const double2 t = *reinterpret_cast<const double2*>(v + (ok ? (long long)j * g.PX + i0 : 0));
+        return ok ? t : make_double2(0.0, 0.0);
+    };
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const bool act = q < nact;
+        X[q] = act ? ld2(a.x, j0 + q) : make_double2(0.0, 0.0);
+        R[q + 1] = act ? ld2(a.r, j0 + q) : make_double2(0.0, 0.0);
+        P[q] = S[q] = W[q] = make_double2(0.0, 0.0);
+    }
+    R[0] = ld2(a.r, j0 - 1);
+    R[RB + 1] = (nact == RB) ? ld2(a.r, j0 + RB) : make_double2(0.0, 0.0);
+
+    // w = A r on the band, returns the two local sums (r.r, w.r)
+    auto apply_r = [&](double* rr_out, double* wr_out) {
+#pragma unroll
+        for (int q = 0; q < RB + 2; ++q) {
+            if (lane == 0) sEdge[q][wv][0] = R[q].x;
+            if (lane == 63) sEdge[q][wv][1] = R[q].y;
+        }
+        __syncthreads();
+        double Lf[RB + 2], Rt[RB + 2];
+#pragma unroll
+        for (int q = 0; q < RB + 2; ++q) {
+            double l = p2_dpp_lower(R[q].y), rt = p2_dpp_upper(R[q].x);
+            if (lane == 0) l = wv > 0 ? sEdge[q][wv - 1][1] : 0.0;
+            if (lane == 63) rt = wv < kNW - 1 ? sEdge[q][wv + 1][0] : 0.0;
+            Lf[q] = l;
+            Rt[q] = rt;
+        }
+        double arr = 0.0, awr = 0.0;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int c = q + 1;
+            const double qa = w0 * R[c].x + wx * (Lf[c] + R[c].y) + wy * (R[c - 1].x + R[c + 1].x) + wd1 * (R[c + 1].y + Lf[c - 1]) +
+                              wd2 * (R[c - 1].y + Lf[c + 1]);
+            const double qb = w0 * R[c].y + wx * (R[c].x + Rt[c]) + wy * (R[c - 1].y + R[c + 1].y) + wd1 * (Rt[c + 1] + R[c - 1].x) +
+                              wd2 * (Rt[c - 1] + R[c + 1].x);
+            const bool act = q < nact;
+            W[q] = make_double2((act && ma) ? qa : 0.0, (act && mb) ? qb : 0.0);
+            arr += R[c].x * R[c].x + R[c].y * R[c].y;
+            awr += W[q].x * R[c].x + W[q].y * R[c].y;
+        }
+        *rr_out = block_sum(arr, sRed);
+        *wr_out = block_sum(awr, sRed);
+    };
+
+    BarrierState bs;
+    bool ok = barrier_init(a, bs, sCensus);
+    unsigned phase = 0;
+    int it = 0;
+    // gamma_0 = r.r, delta_0 = (A r).r  (one reduction)
+    double gamma = 0.0, delta = 0.0, alpha = 0.0, beta = 0.0;
+    if (ok) {
+        double lr, lw;
+        apply_r(&lr, &lw);
+        if (threadIdx.x == 0) {
+            st_sc1(a.part + (size_t)(phase & 1u) * 2 * a.G + b, lr);
+            st_sc1(a.part + (size_t)(phase & 1u) * 2 * a.G + a.G + b, lw);
+        }
+        const unsigned ph = phase & 1u;
+        ++phase;
+        ok = grid_barrier(a, bs, &sFail);
+        if (ok) {
+            gamma = sum_partials(a.part + (size_t)ph * 2 * a.G, a.G, sRed);
+            delta = sum_partials(a.part + (size_t)ph * 2 * a.G + a.G, a.G, sRed);
+            alpha = delta > 0.0 ? gamma / delta : 0.0;
+        }
+    }
+    unsigned hepoch = 0;                                          // neighbour hand-offs completed
+    while (ok && it < a.iters_max && !(a.target > 0.0 && gamma <= a.target) && alpha != 0.0) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            P[q].x = R[q + 1].x + beta * P[q].x;
+            P[q].y = R[q + 1].y + beta * P[q].y;
+            S[q].x = W[q].x + beta * S[q].x;
+            S[q].y = W[q].y + beta * S[q].y;
+            X[q].x += alpha * P[q].x;
+            X[q].y += alpha * P[q].y;
+            R[q + 1].x -= alpha * S[q].x;
+            R[q + 1].y -= alpha * S[q].y;
+        }
+        // ---- band-edge rows of the new r to the two neighbouring bands: sc1 rows, drain, ONE lane raises this band's flag ------
+        ++hepoch;
+        if (col_ok) {
+            double2 first = R[1], last = R[1];
+#pragma unroll
+            for (int q = 1; q < RB; ++q)
+                if (q < nact) last = R[q + 1];
+            double* pf = a.pub + ((size_t)0 * a.G + b) * g.PX + i0;
+            double* pl = a.pub + ((size_t)1 * a.G + b) * g.PX + i0;
+            st_sc1(pf, first.x);
+            st_sc1(pf + 1, first.y);
+            st_sc1(pl, last.x);
+            st_sc1(pl + 1, last.y);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.flags + 16 * b, hepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool okn = true;
+            if (b > 0) okn = poll_ge(a, a.flags + 16 * (b - 1), hepoch, false);
+            if (okn && b + 1 < a.G) okn = poll_ge(a, a.flags + 16 * (b + 1), hepoch, false);
+            sFail = okn ? 0 : 1;
+        }
+        __syncthreads();
+        if (sFail != 0) { ok = false; break; }
+        R[0] = make_double2(0.0, 0.0);
+        R[RB + 1] = make_double2(0.0, 0.0);
+        if (col_ok && b > 0) {
+            const double* sp = a.pub + ((size_t)1 * a.G + (b - 1)) * g.PX + i0;
+            R[0] = make_double2(ld_sc1(sp), ld_sc1(sp + 1));
+        }
+        if (col_ok && b + 1 < a.G && nact == RB) {
+            const double* sp = a.pub + ((size_t)0 * a.G + (b + 1)) * g.PX + i0;
+            R[RB + 1] = make_double2(ld_sc1(sp), ld_sc1(sp + 1));
+        }
+        // ---- w = A r, both dot products, ONE grid barrier ------------------------------------------------------------------------
+        double lr, lw;
+        apply_r(&lr, &lw);
+        const unsigned ph = phase & 1u;
+        if (threadIdx.x == 0) {
+            st_sc1(a.part + (size_t)ph * 2 * a.G + b, lr);
+            st_sc1(a.part + (size_t)ph * 2 * a.G + a.G + b, lw);
+        }
+        ++phase;
+        ok = grid_barrier(a, bs, &sFail);
+        if (!ok) break;
+        const double gamma_new = sum_partials(a.part + (size_t)ph * 2 * a.G, a.G, sRed);
+        const double delta_new = sum_partials(a.part + (size_t)ph * 2 * a.G + a.G, a.G, sRed);
+        beta = gamma > 0.0 ? gamma_new / gamma : 0.0;
+        const double den = delta_new - beta * gamma_new / alpha;
+        alpha = den > 0.0 ? gamma_new / den : 0.0;
+        gamma = gamma_new;
+        ++it;
+    }
+    if (col_ok) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+            if (q < nact) {
+                const long long off = (long long)(j0 + q) * g.PX + i0;
+                *reinterpret_cast<double2*>(a.x + off) = X[q];
+                *reinterpret_cast<double2*>(a.r + off) = R[q + 1];
+                *reinterpret_cast<double2*>(a.p_out + off) = P[q];
+            }
+    }
+    if (b == 0 && threadIdx.x == 0) {
+        a.scal[SC_PQ] = 0.0;                                     // x is fully updated: nothing pending for flush / the next K1
+        a.scal[SC_PQ_LOCAL] = 0.0;
+        a.scal[SC_RR] = gamma;
+        a.scal[SC_RR_LOCAL] = gamma;
+        a.scal[SC_RR_PREV] = 0.0;                                // a follow-up launch-per-kernel iteration restarts (beta = 0)
+        a.sync[SY_ITERS] = (unsigned)it;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -381,6 +566,7 @@ struct Persist2d {
     double* part = nullptr;
     double* pub = nullptr;
     unsigned* sync = nullptr;
+    unsigned* flags = nullptr;
     unsigned* h_sync = nullptr;     // pinned copy of the three sync words
     int G = 0, rb = 0;
 };
@@ -390,6 +576,7 @@ void persist2d_free(Persist2d* p) {
     if (p->part) (void)hipFree(p->part);
     if (p->pub) (void)hipFree(p->pub);
     if (p->sync) (void)hipFree(p->sync);
+    if (p->flags) (void)hipFree(p->flags);
     if (p->h_sync) (void)hipHostFree(p->h_sync);
     delete p;
 }
@@ -419,12 +606,12 @@ int persist2d_create(pdegpu_ctx* ctx, const GridDev& g, Persist2d** out) {
     Persist2d* p = new Persist2d();
     p->G = G;
     p->rb = rb;
-    if (hipMalloc(&p->part, 2 * (size_t)G * sizeof(double)) != hipSuccess || hipMalloc(&p->pub, 2 * (size_t)G * g.PX * sizeof(double)) != hipSuccess ||
+    if (hipMalloc(&p->part, 4 * (size_t)G * sizeof(double)) != hipSuccess || hipMalloc(&p->flags, 16 * (size_t)G * sizeof(unsigned)) != hipSuccess || hipMalloc(&p->pub, 2 * (size_t)G * g.PX * sizeof(double)) != hipSuccess ||
         hipMalloc(&p->sync, SY_WORDS * sizeof(unsigned)) != hipSuccess || hipHostMalloc(&p->h_sync, 64) != hipSuccess) {
         persist2d_free(p);
         return pdegpu_set_err(ctx, PDEGPU_EHIP, "persistent 2-D CG: allocation failed");
     }
-    (void)hipMemsetAsync(p->part, 0, 2 * (size_t)G * sizeof(double), ctx->stream);
+    (void)hipMemsetAsync(p->part, 0, 4 * (size_t)G * sizeof(double), ctx->stream);
     (void)hipMemsetAsync(p->pub, 0, 2 * (size_t)G * g.PX * sizeof(double), ctx->stream);
     *out = p;
     return PDEGPU_OK;
@@ -433,7 +620,7 @@ int persist2d_create(pdegpu_ctx* ctx, const GridDev& g, Persist2d** out) {
 // up to iters_max CG iterations (stopping early once r.r <= target, target > 0) in one cooperative launch; synchronises and
 // returns the number of iterations done.  x, r, p_in / p_out: pitched 2-D vectors of the session.
 int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double* w5, double* x, double* r, const double* p_in, double* p_out,
-                  double* scal, int iters_max, double target, int* iters_done) {
+                  double* scal, int iters_max, double target, int* iters_done, int fresh) {
     P2dArgs a{};
     a.g = g;
     for (int k = 0; k < 5; ++k) a.w[k] = w5[k];
@@ -450,14 +637,26 @@ int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double*
     a.G = p->G;
     a.spin_limit = 2000000;                                      // ~ seconds: far beyond any barrier of a healthy grid
     a.barrier_kind = (ctx->persist2d == 2 || ctx->persist2d == 3) ? ctx->persist2d : 1;
+    a.flags = p->flags;
+    a.single_reduction = (fresh && ctx->persist2d_sr) ? 1 : 0;
     PG_HIP(ctx, hipMemsetAsync(p->sync, 0, SY_WORDS * sizeof(unsigned), ctx->stream));
+    if (a.single_reduction) PG_HIP(ctx, hipMemsetAsync(p->flags, 0, 16 * (size_t)p->G * sizeof(unsigned), ctx->stream));
     void* args[] = {&a};
     const void* fn = nullptr;
-    switch (p->rb) {
-        case 1: fn = reinterpret_cast<const void*>(k_cg2d_persistent<1>); break;
-        case 2: fn = reinterpret_cast<const void*>(k_cg2d_persistent<2>); break;
-        case 4: fn = reinterpret_cast<const void*>(k_cg2d_persistent<4>); break;
-        default: fn = reinterpret_cast<const void*>(k_cg2d_persistent<8>); break;
+    if (a.single_reduction) {
+        switch (p->rb) {
+            case 1: fn = reinterpret_cast<const void*>(k_cg2d_persistent_sr<1>); break;
+            case 2: fn = reinterpret_cast<const void*>(k_cg2d_persistent_sr<2>); break;
+            case 4: fn = reinterpret_cast<const void*>(k_cg2d_persistent_sr<4>); break;
+            default: fn = reinterpret_cast<const void*>(k_cg2d_persistent_sr<8>); break;
+        }
+    } else {
+        switch (p->rb) {
+            case 1: fn = reinterpret_cast<const void*>(k_cg2d_persistent<1>); break;
+            case 2: fn = reinterpret_cast<const void*>(k_cg2d_persistent<2>); break;
+            case 4: fn = reinterpret_cast<const void*>(k_cg2d_persistent<4>); break;
+            default: fn = reinterpret_cast<const void*>(k_cg2d_persistent<8>); break;
+        }
     }
     PG_HIP(ctx, hipLaunchCooperativeKernel(fn, dim3(p->G), dim3(kNW * 64), args, 0, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(p->h_sync, p->sync, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../pde-solver_amd"
 rm -rf build_asan && mkdir -p build_asan
-for f in tridiag tables stencil vecops heat elasticity weighted; do
+for f in tridiag tables stencil vecops heat elasticity weighted persist2d; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address -fno-omit-frame-pointer -c csrc/$f.hip -o build_asan/$f.o
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address build_asan/*.o -o build_asan/libpdegpu_asan.so
@@ -23,8 +23,8 @@ for dim, n, Ls in ((1, (5,), (1.0,)), (2, (4, 3), (1.0, 2.0)), (3, (3, 4, 2), (1
     a, b, c = np.zeros(729), np.zeros(729), np.zeros(27)
     assert lib.pdegpu_heat_tables_host(g, L.dptr(a), L.dptr(b), L.dptr(c)) == 0
     N = int(lib.pdegpu_grid_num_nodes(g))
-    for kind in (1, 2) + ((3,) if dim >= 2 else ()) + ((4,) if dim == 3 else ()):
-        w = L.Weight(); w.kind = kind; w.core_radius, w.core_ratio = (0.3, 5.0) if kind == 4 else (0.0, 1.0)
+    for kind in (1, 2) + ((3,) if dim >= 2 else ()) + ((4, 0) if dim == 3 else ()):
+        w = L.Weight(); w.kind = kind; w.core_radius, w.core_ratio = (0.3, 5.0) if kind in (0, 4) else (0.0, 1.0)
         rk, rm, ld = np.zeros((N, 15)), np.zeros((N, 15)), np.zeros(N)
         assert lib.pdegpu_weighted_rows_host(g, w, L.dptr(rk), L.dptr(rm), L.dptr(ld)) == 0
     if dim >= 2:

@@ -12,8 +12,9 @@ for n in (1024, 512, 256):
         st = 10
     else:
         st = steps
-    for persist in (1, 3, 2, 0, 1, 3, 2, 0):    # 1: XCD-hierarchical barrier (default), 3: the same, all poll the top counter, 2: sharded-poll barrier, 0: one launch per kernel
-        L.check(ctx, lib.pdegpu_set_tunable(ctx, b"persist2d", persist))
+    for persist in (1, 11, 0, 1, 11, 0):        # 1: classic CG, two XCD-hierarchical barriers; 11: single-reduction CG (one barrier + neighbour hand-off); 0: one launch per kernel
+        L.check(ctx, lib.pdegpu_set_tunable(ctx, b"persist2d", persist % 10))
+        L.check(ctx, lib.pdegpu_set_tunable(ctx, b"persist2d_sr", persist // 10))
         t0 = time.perf_counter()
         f = heat._solve_heat_2d_raw(1.0, 1.0, n, n, 1.0, 0.0, 20.0, 0.0025, st)
         dt = time.perf_counter() - t0
@@ -21,3 +22,4 @@ for n in (1024, 512, 256):
         print(f"{n}^2 persist2d={persist}: {st} steps {dt:.3f} s wall, {it} CG iterations ({it/st:.0f}/step), {dt/it*1e6:.2f} us per iteration incl. everything, "
               f"u_center(t_end) = {f.values[-1][(n//2)*(n+1)+n//2]:.9f}", flush=True)
 L.check(ctx, lib.pdegpu_set_tunable(ctx, b"persist2d", 1))
+L.check(ctx, lib.pdegpu_set_tunable(ctx, b"persist2d_sr", 1))
