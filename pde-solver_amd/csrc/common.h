@@ -45,6 +45,10 @@ struct pdegpu_ctx {
     int el_fast_yx = 1;         // k_el_fast: 1 = the 4 waves of a workgroup are y-neighbours and hand their y-halo rows through LDS
     int el_fast_xface = 1;      // k_el_fast: 1 = the x-face nodes (interior in y, z) are computed by the marching part (edge lanes carry the
                                 // face-class weights); 0 = by the class-table boundary pass (45 uncoalesced loads per node)
+    int el_fast_yzface = 3;     // k_el_fast also computes: bit 0 the y-face nodes, bit 1 (with bit 0) the nodes of the planes 0 / NZ-1
+    int el_fast_nt = 0;         // k_el_fast: bit 0 = non-temporal stores, bit 1 = non-temporal loads of the own rows
+    int el_bnd_last = 0;        // k_el_fast: 1 = the boundary workgroups take the last block indices instead of the first
+    int el_debug_part = 0;      // timing aid for tools/: 1 = k_el_fast launches its marching part only, 2 = its boundary workgroups only (wrong results)
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
     int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never

@@ -213,67 +213,186 @@ struct ElW36 {
     double c[6];        // centre block: xx yy zz xy xz yz
     double ax[3][6];    // offsets (1,0,0) (0,1,0) (0,0,1)
     double dg[4][3];    // offsets (1,1,0) (1,0,1) (0,1,1) (1,1,1): xy xz yz (zero diagonal)
-    // x-face nodes (interior in y and z) inside the marching kernel.  On the host tables the class of the face x = NX-1 is: offsets
-    // with dx = +1 absent, dx = -1 as in the interior, and for the in-face offsets o (dx = 0)  B_face(o) = B(o) / 2 + A(o)  with
-    // A(-o) = -A(o) antisymmetric and non-zero in its first row / column only, A(o) = [[0, a, b], [-a, 0, 0], [-b, 0, 0]] (the Kuhn
-    // split is not mirror symmetric in x); the face x = 0 has -A.  xf[t] = {a, b} of o = (0,1,0), (0,0,1), (0,1,1); the centre
-    // block is exactly halved.  el_fast_weights checks all of this before xface is set.
-    double xf[3][2];
-    int xface;          // 1: the marching part computes the x-face rows, the boundary pass only the y / z faces
+    // Face nodes inside the marching kernel.  On the host tables the class of a face with normal axis N and sign s (+1: high) is: offsets
+    // pointing out of the grid absent, inward ones as in the interior, and for the in-face offsets o  B_face(+-o) = B(o) / 2 +- s A(g(o))
+    // with an antisymmetric remainder that couples the normal component with the tangential ones, (A(g) v)_N = g . v, (A(g) v)_t = -g_t v_N
+    // (the Kuhn split is not mirror symmetric); the centre block is exactly halved.  The 27 numbers g (3 axes x 3 in-face offsets e_p, e_q,
+    // e_p + e_q) travel in ElFastGeom::gf (device memory -> LDS).  el_face_weights checks all of this before a bit is set.
+    int faces;          // the marching part computes the nodes of: bit 0 the x-faces, bit 1 the y-faces, bit 2 the z-faces (each interior in the
+                        // other two directions; a bit implies the lower ones) — with all three the class-table pass keeps the edges and corners
 };
+// The 36 interior weights are 18 numbers: on the uniform Kuhn split every off-diagonal entry of the 15 blocks is one of a = B(1,0,0)_xy,
+// b = B(1,0,0)_xz, c = B(1,1,0)_yz times a signed power of two (xy: centre -2a, (1,0,0) a, (0,1,0) a, (0,0,1) -a/2, (1,1,0) -a, (1,0,1) a/2,
+// (0,1,1) a/2, (1,1,1) -a/2; xz and yz alike), and the axis blocks have two distinct diagonal entries (normal, tangential).  The kernel takes
+// these 18 (36 SGPRs instead of 72 — with 72 the compiler kept every other scalar of the marching loop in VGPR lanes, 40 v_readlane per plane)
+// and rebuilds the 36 with signs as source modifiers; el_pack_weights checks the relations on the host table before the path is enabled.
+struct ElW18 {
+    double dc[3];             // centre block diagonal: xx yy zz
+    double dp[2], dq[2], dr[2];      // (1,0,0), (0,1,0), (0,0,1): {normal-normal entry, the two tangential ones}
+    double a[3], b[3], c[3];  // {a/2, a, 2a}, {b/2, b, 2b}, {c, 2c, 4c}
+    int faces;                // see ElW36::faces
+};
+__device__ __forceinline__ ElW36 el_expand_weights(const ElW18& k) {
+    ElW36 w;
+    const double c6[6] = {k.dc[0], k.dc[1], k.dc[2], -k.a[2], -k.b[2], -k.c[2]};
+    const double x6[6] = {k.dp[0], k.dp[1], k.dp[1], k.a[1], k.b[1], -k.c[0]};
+    const double y6[6] = {k.dq[1], k.dq[0], k.dq[1], k.a[1], -k.b[0], k.c[1]};
+    const double z6[6] = {k.dr[1], k.dr[1], k.dr[0], -k.a[0], k.b[1], k.c[1]};
+    const double d3[4][3] = {{-k.a[1], k.b[0], k.c[0]}, {k.a[0], -k.b[1], k.c[0]}, {k.a[0], k.b[0], -k.c[1]}, {-k.a[0], -k.b[0], -k.c[0]}};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        w.c[t] = c6[t];
+        w.ax[0][t] = x6[t];
+        w.ax[1][t] = y6[t];
+        w.ax[2][t] = z6[t];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w.dg[r][t] = d3[r][t];
+    w.faces = k.faces;
+    return w;
+}
 struct ElFastGeom {
     int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
     int nyg;                   // groups of 4 y-tiles (one workgroup each) of the y-hand-off variant
     int lkb, lke;              // local interior plane range [lkb, lke)
     int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
-    int nb_bnd;                // boundary workgroups (launched first so that their short tail overlaps the marching part)
+    int nb_bnd;                // boundary workgroups
+    int bnd_last;              // 1: they take the LAST block indices
+    int nt;                    // bit 0: non-temporal stores of the marching part, bit 1: non-temporal loads of its own rows
     int full_lo, full_hi;      // 1: this slab owns the global plane 0 / NZ-1 (all of its nodes are boundary nodes)
     int ring;                  // boundary nodes of an interior plane: 2 NX + 2 (NY - 2)
     long long nbnd;            // boundary nodes of the slab
     const unsigned* mask;      // [27] nonzero-block masks of the class table
+    const double* gf;          // [3][3][3] face remainder vectors g (see ElW36::faces)
 };
 
 __device__ __forceinline__ double el_dpp_lower(double v) {     // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1)
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);      // bound_ctrl: lane 0 receives 0, no `old` operand to set up
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double el_dpp_upper(double v) {     // lane l <- lane l+1 (v_mov_b32_dpp wave_shl:1)
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// block products as explicit FMA chains (y += b0 v0 + b3 v1 + b4 v2 written as a sum is contracted to mul + 2 fma + add: a third more
+// issue slots in a kernel whose marching loop is VALU-co-bound)
 __device__ __forceinline__ void el_sym6(const double* b, const double* v, double* y) {
-    y[0] += b[0] * v[0] + b[3] * v[1] + b[4] * v[2];
-    y[1] += b[3] * v[0] + b[1] * v[1] + b[5] * v[2];
-    y[2] += b[4] * v[0] + b[5] * v[1] + b[2] * v[2];
+    y[0] = fma(b[4], v[2], fma(b[3], v[1], fma(b[0], v[0], y[0])));
+    y[1] = fma(b[5], v[2], fma(b[1], v[1], fma(b[3], v[0], y[1])));
+    y[2] = fma(b[2], v[2], fma(b[5], v[1], fma(b[4], v[0], y[2])));
 }
 __device__ __forceinline__ void el_off3(const double* b, const double* v, double* y) {
-    y[0] += b[0] * v[1] + b[1] * v[2];
-    y[1] += b[0] * v[0] + b[2] * v[2];
-    y[2] += b[1] * v[0] + b[2] * v[1];
+    y[0] = fma(b[1], v[2], fma(b[0], v[1], y[0]));
+    y[1] = fma(b[2], v[2], fma(b[0], v[0], y[1]));
+    y[2] = fma(b[2], v[1], fma(b[1], v[0], y[2]));
 }
 
-template <int RY, bool YX>
-__global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom fg) {
+// y += sg A(g) v with the face remainder A(g) v = e_N (g . v) - g v_N  (N = face normal, g_N = 0, sg = +-1)
+template <int N>
+__device__ __forceinline__ void el_rem(const double* g, double sg, const double* v, double* y) {
+    constexpr int T1 = (N + 1) % 3, T2 = (N + 2) % 3;
+    const double g1 = sg * g[T1], g2 = sg * g[T2];
+    y[N] = fma(g2, v[T2], fma(g1, v[T1], y[N]));
+    y[T1] = fma(-g1, v[N], y[T1]);
+    y[T2] = fma(-g2, v[N], y[T2]);
+}
+
+// One node of a y- or z-face (interior in the two other directions), in the marching kernel's terms.  On the host tables the class of a
+// face with normal axis N and sign s (+1: high face) is: centre block halved; for the in-face offsets +-o  B(o) / 2 +- s A(g(o)) with
+// the antisymmetric remainder above (the Kuhn split is not mirror symmetric); inward offsets as in the interior, outward ones absent
+// (el_face_weights checks exactly this before the path is enabled).  c = the node, (e1p, e1m) = its neighbours along the second
+// in-face axis (+, -) — they are also the sources of the in-face x-diagonal —, n0 / n1 = the inward neighbour and the inward
+// (0,1,1) diagonal neighbour.  G[k] = g of the in-face offsets e_x, e_second, e_x + e_second.  y: unshifted part, U / Lw: the parts the
+// lanes i-1 / i+1 pick up through the x-shifts, exactly as for interior rows.
+template <int N, bool HIGH>
+__device__ __forceinline__ void el_face_node(const ElW36& w, const double (*G)[3], const double* c, const double* e1p, const double* e1m,
+                                             const double* n0, const double* n1, double* y, double* U, double* Lw) {
+    constexpr double s = HIGH ? 1.0 : -1.0;
+    const double* Bin = N == 1 ? w.ax[2] : w.ax[1];       // second in-face axis: z for a y-face, y for a z-face
+    const double* Din = N == 1 ? w.dg[1] : w.dg[0];       // in-face x-diagonal: (1,0,1) | (1,1,0)
+    const double* Bnor = N == 1 ? w.ax[1] : w.ax[2];      // normal axis
+    const double* Dnor = N == 1 ? w.dg[0] : w.dg[1];      // x-diagonal with a normal component: (1,1,0) | (1,0,1)
+    // (every temporary lives only as long as its one use: the four plane buffers leave about 60 VGPRs at three waves per SIMD)
+    double t[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        t[e] = 0.5 * c[e];
+        y[e] = 0.0;
+        U[e] = 0.0;
+    }
+    el_sym6(w.c, t, y);
+    el_sym6(w.ax[0], t, U);
+    Lw[0] = U[0]; Lw[1] = U[1]; Lw[2] = U[2];
+    el_rem<N>(G[0], s, c, U);
+    el_rem<N>(G[0], -s, c, Lw);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) t[e] = 0.5 * (e1p[e] + e1m[e]);
+    el_sym6(Bin, t, y);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) t[e] = e1p[e] - e1m[e];
+    el_rem<N>(G[1], s, t, y);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) t[e] = 0.5 * e1p[e];
+    el_off3(Din, t, U);
+    el_rem<N>(G[2], s, e1p, U);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) t[e] = 0.5 * e1m[e];
+    el_off3(Din, t, Lw);
+    el_rem<N>(G[2], -s, e1m, Lw);
+    el_sym6(Bnor, n0, y);
+    el_off3(w.dg[2], n1, y);
+    el_off3(Dnor, n0, HIGH ? Lw : U);
+    el_off3(w.dg[3], n1, HIGH ? Lw : U);
+}
+
+// (min. 3 workgroups per CU for RY <= 2: the code fits 168 VGPRs without a spill, but left alone the scheduler trades the third wave per SIMD away)
+template <int RY, bool YX, bool ZF>
+__global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, ElW18 wk, ElFastGeom fg) {
+    const ElW36 w = el_expand_weights(wk);
     __shared__ double sTab[27 * PG_NOFF15 * 9];
     __shared__ unsigned sMask[27];
     __shared__ double sRed[8];
     constexpr int RH = RY + 2;
     const GridDev& g = a.g;
     double acc = 0.0;
-    if ((int)blockIdx.x < fg.nb_bnd) {
+    // workgroup roles: bnd_last = 0: boundary workgroups take the first nb_bnd block indices; 1: the last ones (they then start as the
+    // marching workgroups retire, filling the tail of the launch)
+    const int bidx = fg.bnd_last ? ((int)blockIdx.x >= fg.nb_fast ? (int)blockIdx.x - fg.nb_fast : -1) : ((int)blockIdx.x < fg.nb_bnd ? (int)blockIdx.x : -1);
+    if (bidx >= 0) {
         // ---- boundary nodes: one thread per node, truncated class stencils from LDS -----------------------------
         for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
         if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
         __syncthreads();
-        for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * 256) {
+        for (long long e0 = (long long)bidx * 256 + threadIdx.x; e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * 256) {
             unsigned e = (unsigned)e0;                        // 32-bit divisions (nbnd < 2^31 is checked on the host)
             int i, j, lk;
             const unsigned plane_nodes = (unsigned)g.NX * (unsigned)g.NY;
-            if (fg.full_lo && e < plane_nodes) {
+            if (w.faces & 2) {
+                // y-faces folded: the planes 0 / NZ-1 this slab owns (their perimeter only when the z-faces are folded as well), then the
+                // four corners of every other plane
+                const unsigned ringp = 2u * (unsigned)g.NX + 2u * (unsigned)(g.NY - 2);
+                const unsigned per = (w.faces & 4) ? ringp : plane_nodes;
+                const unsigned nlo = fg.full_lo ? per : 0u, nhi = fg.full_hi ? per : 0u;
+                if (e < nlo + nhi) {
+                    lk = e < nlo ? -g.k0 : g.NZ - 1 - g.k0;
+                    const int t = (int)(e < nlo ? e : e - nlo);
+                    if (!(w.faces & 4)) { j = t / g.NX; i = t % g.NX; }
+                    else if (t < g.NX) { j = 0; i = t; }
+                    else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
+                    else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
+                } else {
+                    e -= nlo + nhi;
+                    lk = fg.lkb + (int)(e >> 2);
+                    j = (e & 2u) ? g.NY - 1 : 0;
+                    i = (e & 1u) ? g.NX - 1 : 0;
+                }
+            } else if (fg.full_lo && e < plane_nodes) {
                 lk = -g.k0;                                   // global plane 0
                 j = (int)(e / (unsigned)g.NX);
                 i = (int)(e % (unsigned)g.NX);
@@ -333,21 +452,25 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
         const int lane = threadIdx.x & 63;
         // XCD-aware order: workgroups b and b+8 share an XCD (round-robin dispatch), so XCD x is given the contiguous range
         // [x*G/8, (x+1)*G/8) of tiles: y-neighbouring columns, whose halo rows overlap, then meet in one L2 (speed only)
-        int bm = (int)blockIdx.x - fg.nb_bnd;
+        int bm = fg.bnd_last ? (int)blockIdx.x : (int)blockIdx.x - fg.nb_bnd;
         if ((fg.nb_fast & 7) == 0) bm = (bm & 7) * (fg.nb_fast >> 3) + (bm >> 3);
-        const int wv = threadIdx.x >> 6;
-        int xt, yt, zc;
+        if (w.faces) {                                        // every wave of the workgroup passes here
+            if (threadIdx.x < 27) sTab[3200 + threadIdx.x] = fg.gf[threadIdx.x];
+            __syncthreads();
+        }
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and known to the compiler as such:
+        int xt, yt, zc;                                                       // the row / halo conditions below stay scalar branches
         if (YX) {
             // the four waves of a workgroup are y-neighbours (same x-tile, same z-chunk): they hand their y-halo rows to
             // each other through LDS, so a workgroup loads 4 RY + 2 rows per plane instead of 4 (RY + 2)
             xt = bm % fg.ntx;
             yt = ((bm / fg.ntx) % fg.nyg) * 4 + wv;
-            zc = bm / (fg.ntx * fg.nyg);
+            zc = fg.nzc - 1 - bm / (fg.ntx * fg.nyg);        // the chunk with the extra plane NZ-1 first; surplus workgroups get zc < 0
         } else {
             const int wid = bm * 4 + wv;
             xt = wid % fg.ntx;
             yt = (wid / fg.ntx) % fg.nty;
-            zc = wid / (fg.ntx * fg.nty);
+            zc = fg.nzc - 1 - wid / (fg.ntx * fg.nty);
         }
         const bool ghost_wave = YX && yt >= fg.nty;           // beyond the last row tile: takes part in the barriers only
         if (ghost_wave) yt = fg.nty - 1;                      // (loads stay inside the grid; nothing is stored)
@@ -355,51 +478,65 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
         const int lk0 = fg.lkb + zc * fg.zlen;
         const int lk1 = min(lk0 + fg.zlen, fg.lke);
-        if (zc < fg.nzc && lk0 < lk1) {
+        if (zc >= 0 && lk0 < lk1) {
             // Loads are unconditional (branch-free, all of a plane in flight at once): every address a wave can form lies
             // inside the allocation — rows up to NY (= first row of the next plane), columns up to NX+60 < PX+64, planes
             // -1 .. nkl, covered by the ghost planes and the guard of kGuard + one row on both sides — and a value from
             // outside the grid only ever reaches outputs that are not stored (an interior node has all 15 neighbours inside).
             // x-faces: lane 0 of the first tile is the node i = 0 (clamped: its row is 0 when Dirichlet rows are masked), the node
             // i = NX-1 (traction-free) sits on one of the lanes 1 .. 62 of the last tile
-            const bool face_lo = w.xface && i == 0, face_hi = w.xface && i == g.NX - 1;
-            const bool wave_has_face = w.xface && (xt == 0 || (xt + 1) * 62 >= g.NX - 1);      // wave-uniform
-            const double fsc = (face_lo || face_hi) ? 0.5 : 1.0, fsg = face_hi ? 1.0 : (face_lo ? -1.0 : 0.0);
-            const bool out_x = (lane >= 1 && lane <= 62 && i <= g.NX - (w.xface ? 1 : 2)) || face_lo;
-            bool row_out[RH];
-#pragma unroll
-            for (int r = 0; r < RH; ++r) row_out[r] = out_x && !ghost_wave && r >= 1 && r <= RY && (j0 - 1 + r) <= g.NY - 2;
+            const bool face_lo = (w.faces & 1) && i == 0, face_hi = (w.faces & 1) && i == g.NX - 1;
+            const bool wave_has_face = (w.faces & 1) && (xt == 0 || (xt + 1) * 62 >= g.NX - 1);      // wave-uniform
+            const double kup = face_hi ? 0.0 : 1.0, klo = face_lo ? 0.0 : 1.0;      // no coupling across the face (the lanes beyond hold finite pad values)
+            const bool out_x = (lane >= 1 && lane <= 62 && i <= g.NX - ((w.faces & 1) ? 1 : 2)) || face_lo;
+            const int rows_out = ghost_wave ? 0 : min(RY, g.NY - 1 - j0);      // owned rows inside the grid (wave-uniform)
             // lanes beyond the padded row (the last 62-node tile overshoots: 558 columns for a 513-node row) read the row's last pad
             // entry instead of the next row's data: same cache line as real data, no traffic of their own (9 % of the loads at
             // NX = 513); what they hold never reaches a stored output
             const long long col = (long long)(j0 - 1) * g.PX + (i < g.PX ? i : g.PX - 1);
-            double Pm[RH][3], P0[RH][3], Pp[RH][3];
-            auto load_plane = [&](int lk, double (*P)[3]) {
+            // four plane buffers whose roles (k-1, k, k+1, the plane in flight) rotate by NAME: the z-loop is unrolled four times, so no
+            // register is ever copied (the copying form spent 96 of its ~450 VALU instructions per plane on the rotation)
+            double PA[RH][3], PB[RH][3], PC[RH][3], PD[RH][3];
+            auto load_plane = [&](int lk, double (*P)[3]) __attribute__((always_inline)) {
                 const long long base = (long long)lk * g.PP + col;
 #pragma unroll
                 for (int r = 0; r < RH; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) P[r][c] = a.in[c * a.stride + base + (long long)r * g.PX];
             };
-            // one more plane in flight: plane lk+2 is requested before plane lk is computed
-            double Pn[RH][3];
             // YX: a marching plane is loaded without the halo rows its y-neighbours in the workgroup own (the lowest wave
             // still loads row j0-1, the highest real wave row j0+RY); they arrive through LDS one step later, when the
-            // plane has become Pp and its loads have landed.  The LDS block is the class table's (boundary workgroups only).
+            // plane has become the k+1 plane and its loads have landed.  The LDS block is the class table's (boundary workgroups only).
             const bool lo_global = !YX || wv == 0;
             const bool hi_global = !YX || wv == 3 || (yt + 1 >= fg.nty);
-            auto load_own = [&](int lk, double (*P)[3]) {
+            auto load_own = [&](int lk, double (*P)[3]) __attribute__((always_inline)) {
                 const long long base = (long long)lk * g.PP + col;
 #pragma unroll
-                for (int r = 0; r < RH; ++r) {
-                    const bool need = (r >= 1 && r <= RY) || (r == 0 ? lo_global : hi_global);      // wave-uniform
+                for (int r = 1; r <= RY; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) P[r][c] = need ? a.in[c * a.stride + base + (long long)r * g.PX] : 0.0;
+                    for (int c = 0; c < 3; ++c) {
+                        const double* src = a.in + c * a.stride + base + (long long)r * g.PX;
+                        // rows 2 .. RY-1 of the inner waves are read by nobody else (rows 1 / RY of the edge waves: by the y-neighbour workgroup)
+                        P[r][c] = (fg.nt & 2) ? __builtin_nontemporal_load(src) : *src;
+                    }
+                if (lo_global) {                              // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[0][c] = a.in[c * a.stride + base];
+                }
+                if (hi_global) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[RH - 1][c] = a.in[c * a.stride + base + (long long)(RH - 1) * g.PX];
                 }
             };
             double* sY = sTab;                                // [2][4 waves][first | last own row][3][64]
-            int ybuf = 0;
-            auto y_exchange = [&](double (*P)[3]) {
+            // face remainder vectors of axis ax, beyond the hand-off block.  The offset passes through an empty asm so that the reads stay where
+            // they are used: hoisted out of the z-loop the 27 numbers cost 54 VGPRs and a third of the occupancy
+            auto face_g = [&](int ax) __attribute__((always_inline)) {
+                int off = 3200 + 9 * ax;
+                asm volatile("" : "+v"(off));
+                return reinterpret_cast<const double (*)[3]>(sTab + off);
+            };
+            auto y_exchange = [&](int ybuf, double (*P)[3]) __attribute__((always_inline)) {
                 double* mine = sY + ((ybuf * 4 + wv) * 2) * 192;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -417,16 +554,50 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
 #pragma unroll
                     for (int c = 0; c < 3; ++c) P[RH - 1][c] = above[c * 64 + lane];
                 }
-                ybuf ^= 1;
             };
-            load_plane(lk0 - 1, Pm);
-            load_plane(lk0, P0);
-            load_plane(lk0 + 1, Pp);                          // the address is inside the allocation even when lk0 + 1 == lk1 == nkl
-            for (int lk = lk0; lk < lk1; ++lk) {
-                // lk + 2 can reach nkl + 1 (one plane past the upper ghost plane) only when it is not needed: clamp it
+            // y- and z-face nodes (faces bit 1): which of them this wave computes
+            const bool yz = (w.faces & 2) != 0, zf = ZF && (w.faces & 4) != 0;
+            const bool ylo_wave = yz && !ghost_wave && yt == 0;                       // row 0 = the halo row below the first row tile
+            const int r_hi = (yz && !ghost_wave && yt == fg.nty - 1) ? g.NY - j0 : 0;       // held-row index of the row NY-1 (2 .. RY+1)
+            const bool zlo_chunk = zf && fg.full_lo && zc == 0, zhi_chunk = zf && fg.full_hi && lk1 == fg.lke;
+            const bool out_f = lane >= 1 && lane <= 62 && i >= 1 && i <= g.NX - 2;      // face nodes proper (the x-ends are edges of the box)
+            auto face_finish = [&](long long o, const double* c0, double* y, const double* U, const double* Lw) __attribute__((always_inline)) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
+                if (out_f) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        a.out[c * a.stride + o] = y[c];
+                        acc += c0[c] * y[c];
+                    }
+                }
+            };
+            // the plane 0 / NZ-1 of the grid (owned rows of this tile; the perimeter of the plane stays with the class-table pass): Pin = the
+            // inward neighbour plane
+            auto zface_lo = [&](int lk, double (*P0)[3], double (*Pin)[3]) __attribute__((always_inline)) {
+                const long long obase = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) {
+                    double y[3], U[3], Lw[3];
+                    el_face_node<2, false>(w, face_g(2), P0[r], P0[r + 1], P0[r - 1], Pin[r], Pin[r + 1], y, U, Lw);
+                    if (r <= rows_out) face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw);
+                }
+            };
+            auto zface_hi = [&](int lk, double (*P0)[3], double (*Pin)[3]) __attribute__((always_inline)) {
+                const long long obase = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) {
+                    double y[3], U[3], Lw[3];
+                    el_face_node<2, true>(w, face_g(2), P0[r], P0[r + 1], P0[r - 1], Pin[r], Pin[r - 1], y, U, Lw);
+                    if (r <= rows_out) face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw);
+                }
+            };
+            auto step = [&](int lk, double (*Pm)[3], double (*P0)[3], double (*Pp)[3], double (*Pn)[3]) __attribute__((always_inline)) {
+                // one more plane in flight: plane lk+2 is requested before plane lk is computed; lk + 2 can reach nkl + 1 (one plane
+                // past the upper ghost plane) only when it is not needed: clamp it
                 if (YX) {
                     load_own(min(lk + 2, lk1), Pn);
-                    if (lk > lk0) y_exchange(Pp);             // Pp was requested one step ago; every wave of the workgroup passes here
+                    if (lk > lk0) y_exchange((lk - lk0) & 1, Pp);      // Pp was requested one step ago; every wave of the workgroup passes here
                 } else {
                     load_plane(min(lk + 2, lk1), Pn);
                 }
@@ -434,7 +605,7 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
 #pragma unroll
                 for (int r = 1; r <= RY; ++r) {
                     // y = [unshifted terms] + up(U) + lo(L): the x-shifts act on two accumulated 3-vectors, not on 24 inputs
-                    double y[3] = {0.0, 0.0, 0.0}, U[3] = {0.0, 0.0, 0.0}, Lw[3] = {0.0, 0.0, 0.0}, v[3];
+                    double y[3] = {0.0, 0.0, 0.0}, U[3] = {0.0, 0.0, 0.0}, Lw[3], v[3];
                     el_sym6(w.c, P0[r], y);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) v[c] = P0[r + 1][c] + P0[r - 1][c];
@@ -455,45 +626,86 @@ __global__ __launch_bounds__(256) void k_el_fast(ElArgs a, ElW36 w, ElFastGeom f
                     el_off3(w.dg[3], Pm[r - 1], Lw);          //        (i-1, j-1, k-1)
                     if (wave_has_face) {
                         // x-face lanes: in-face part halved + the antisymmetric remainder, no coupling across the face; the
-                        // clamped face gives 0 when Dirichlet rows are masked
-                        double d1[3], d2[3], d3[3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            d1[c] = P0[r + 1][c] - P0[r - 1][c];
-                            d2[c] = Pp[r][c] - Pm[r][c];
-                            d3[c] = Pp[r + 1][c] - Pm[r - 1][c];
+                        // clamped face gives 0 when Dirichlet rows are masked.  The six remainder weights come from LDS (uniform
+                        // address: a broadcast read) — as kernel arguments they pushed the interior weights out of the SGPR file
+                        // (one difference vector at a time: this branch is where the kernel's register pressure peaks)
+                        const double (*G0)[3] = face_g(0);
+                        double corr[3] = {0.0, 0.0, 0.0};
+                        {
+                            const double dv[3] = {P0[r + 1][0] - P0[r - 1][0], P0[r + 1][1] - P0[r - 1][1], P0[r + 1][2] - P0[r - 1][2]};
+                            el_rem<0>(G0[0], 1.0, dv, corr);
                         }
-                        const double cx = w.xf[0][0] * d1[1] + w.xf[0][1] * d1[2] + w.xf[1][0] * d2[1] + w.xf[1][1] * d2[2] +
-                                          w.xf[2][0] * d3[1] + w.xf[2][1] * d3[2];
-                        const double cy = -(w.xf[0][0] * d1[0] + w.xf[1][0] * d2[0] + w.xf[2][0] * d3[0]);
-                        const double cz = -(w.xf[0][1] * d1[0] + w.xf[1][1] * d2[0] + w.xf[2][1] * d3[0]);
-                        const double corr[3] = {cx, cy, cz};
+                        {
+                            const double dv[3] = {Pp[r][0] - Pm[r][0], Pp[r][1] - Pm[r][1], Pp[r][2] - Pm[r][2]};
+                            el_rem<0>(G0[1], 1.0, dv, corr);
+                        }
+                        {
+                            const double dv[3] = {Pp[r + 1][0] - Pm[r - 1][0], Pp[r + 1][1] - Pm[r - 1][1], Pp[r + 1][2] - Pm[r - 1][2]};
+                            el_rem<0>(G0[2], 1.0, dv, corr);
+                        }
+                        const double fsc = 0.5 * (kup + klo), fsg = klo - kup;      // face lanes: 1/2, +-1 (high / low face); interior lanes: 1, 0
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const double up = face_hi ? 0.0 : el_dpp_upper(U[c]), lo = face_lo ? 0.0 : el_dpp_lower(Lw[c]);
-                            y[c] = fsc * y[c] + (up + lo) + fsg * corr[c];     // interior lanes: bitwise the plain y += up + lo
+                            // the shifts run with every lane active and their results are masked by factors: written as
+                            // `face_hi ? 0.0 : shift(U)` the compiler moved the DPP under exec = !face_hi, and the lane next to the face
+                            // then read a disabled lane (= 0) instead of the face node's contribution
+                            const double up = el_dpp_upper(U[c]), lo = el_dpp_lower(Lw[c]);
+                            y[c] = fsc * y[c] + (kup * up + klo * lo) + fsg * corr[c];     // interior lanes: bitwise the plain y += up + lo
                             if (face_lo && a.mask_dirichlet) y[c] = 0.0;
                         }
                     } else {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
                     }
-                    if (row_out[r]) {
+                    if (r <= rows_out && out_x) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            a.out[c * a.stride + obase + (long long)r * g.PX] = y[c];
+                            double* dst = a.out + c * a.stride + obase + (long long)r * g.PX;
+                            if (fg.nt & 1) __builtin_nontemporal_store(y[c], dst);      // the output is not read again by this launch
+                            else *dst = y[c];
                             acc += P0[r][c] * y[c];
                         }
                     }
                 }
+                // y-face rows of this plane (wave-uniform branches): row 0 by the first row tile, row NY-1 by the last one
+                if (ylo_wave) {
+                    double y[3], U[3], Lw[3];
+                    el_face_node<1, false>(w, face_g(1), P0[0], Pp[0], Pm[0], P0[1], Pp[1], y, U, Lw);
+                    face_finish(obase, P0[0], y, U, Lw);
+                }
+                if (r_hi > 0) {
 #pragma unroll
-                for (int r = 0; r < RH; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        Pm[r][c] = P0[r][c];
-                        P0[r][c] = Pp[r][c];
-                        Pp[r][c] = Pn[r][c];
-                    }
+                    for (int r = 2; r < RH; ++r)
+                        if (r == r_hi) {
+                            double y[3], U[3], Lw[3];
+                            el_face_node<1, true>(w, face_g(1), P0[r], Pp[r], Pm[r], P0[r - 1], Pm[r - 1], y, U, Lw);
+                            face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw);
+                        }
+                }
+            };
+            load_plane(lk0 - 1, PA);
+            load_plane(lk0, PB);
+            load_plane(lk0 + 1, PC);                          // the address is inside the allocation even when lk0 + 1 == lk1 == nkl
+            if constexpr (ZF)
+                if (zlo_chunk) zface_lo(lk0 - 1, PA, PB);
+            for (int lk = lk0; lk < lk1; lk += 4) {
+                step(lk, PA, PB, PC, PD);
+                if (lk + 1 >= lk1) break;
+                step(lk + 1, PB, PC, PD, PA);
+                if (lk + 2 >= lk1) break;
+                step(lk + 2, PC, PD, PA, PB);
+                if (lk + 3 >= lk1) break;
+                step(lk + 3, PD, PA, PB, PC);
+            }
+            if constexpr (ZF) if (zhi_chunk) {
+                // the plane NZ-1 and its inward neighbour are read once more (cache hits) rather than taken from the rotating buffers: which
+                // two they are depends on the chunk length, and four exit blocks with four buffer pairs made the compiler carry copies of
+                // two planes through the loop (+70 VGPRs, a third of the occupancy).  This chunk is dispatched first (see zc above).
+                int lkf = lk1;
+                asm volatile("" : "+s"(lkf));                 // (keeps these loads below the loop)
+                load_plane(lkf, PA);
+                load_plane(lkf - 1, PB);
+                zface_hi(lkf, PA, PB);
             }
         }
     }
@@ -909,6 +1121,7 @@ struct ElSession {
     bool fast = false;
     int fast_ry = 1;
     ElW36 w36{};
+    ElW18 w18{};               // what k_el_fast is launched with (w36 in 18 numbers + the faces bits)
     ElFastGeom fgeom{};
     unsigned* d_mask = nullptr;
     int last_apply_blocks = 1;      // workgroups (= partials) of the most recent apply launch
@@ -1001,46 +1214,86 @@ bool el_fast_weights(const double* w15 /*[15][9]*/, ElW36* out) {
     return true;
 }
 
-// x-face structure of the class table (see ElW36::xf): fills xf and returns true when the two x-face classes (interior in y, z)
-// have exactly that form
-bool el_xface_weights(const double* tab /*[27][15][9]*/, ElW36* out) {
-    auto qof = [](int dx, int dy, int dz) {
-        const int o = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+// the 18-number form of the interior weights (see ElW18); false if the 36 do not have that structure
+bool el_pack_weights(const ElW36& w, ElW18* k) {
+    double scale = 0.0;
+    for (int t = 0; t < 6; ++t) scale = std::max(scale, std::fabs(w.c[t]));
+    const double tol = 1e-12 * scale;
+    auto eq = [&](double x, double y) { return std::fabs(x - y) <= tol; };
+    const double a = w.ax[0][3], b = w.ax[0][4], c = w.dg[0][2];
+    bool ok = eq(w.ax[0][1], w.ax[0][2]) && eq(w.ax[1][0], w.ax[1][2]) && eq(w.ax[2][0], w.ax[2][1]);
+    ok = ok && eq(w.c[3], -2 * a) && eq(w.c[4], -2 * b) && eq(w.c[5], -4 * c);
+    ok = ok && eq(w.ax[0][5], -c) && eq(w.ax[1][3], a) && eq(w.ax[1][4], -0.5 * b) && eq(w.ax[1][5], 2 * c);
+    ok = ok && eq(w.ax[2][3], -0.5 * a) && eq(w.ax[2][4], b) && eq(w.ax[2][5], 2 * c);
+    ok = ok && eq(w.dg[0][0], -a) && eq(w.dg[0][1], 0.5 * b);
+    ok = ok && eq(w.dg[1][0], 0.5 * a) && eq(w.dg[1][1], -b) && eq(w.dg[1][2], c);
+    ok = ok && eq(w.dg[2][0], 0.5 * a) && eq(w.dg[2][1], 0.5 * b) && eq(w.dg[2][2], -2 * c);
+    ok = ok && eq(w.dg[3][0], -0.5 * a) && eq(w.dg[3][1], -0.5 * b) && eq(w.dg[3][2], -c);
+    if (!ok) return false;
+    for (int t = 0; t < 3; ++t) k->dc[t] = w.c[t];
+    k->dp[0] = w.ax[0][0]; k->dp[1] = w.ax[0][1];
+    k->dq[0] = w.ax[1][1]; k->dq[1] = w.ax[1][0];
+    k->dr[0] = w.ax[2][2]; k->dr[1] = w.ax[2][0];
+    k->a[0] = 0.5 * a; k->a[1] = a; k->a[2] = 2 * a;
+    k->b[0] = 0.5 * b; k->b[1] = b; k->b[2] = 2 * b;
+    k->c[0] = c; k->c[1] = 2 * c; k->c[2] = 4 * c;
+    k->faces = w.faces;
+    return true;
+}
+
+// Face structure of the class table (see ElW36::faces): fills G[k] = g of the in-face offsets e_p, e_q, e_p + e_q (p < q the two in-face
+// axes) and returns true when the two face classes of `axis` (interior in the other two directions) have exactly that form
+bool el_face_weights(const double* tab /*[27][15][9]*/, int axis, double (*G)[3]) {
+    auto qof = [](const int* d) {
+        const int o = (d[0] + 1) + 3 * (d[1] + 1) + 9 * (d[2] + 1);
         for (int q = 0; q < PG_NOFF15; ++q)
             if (pg_off15(q) == o) return q;
         return -1;
     };
+    const int pw[3] = {1, 3, 9};
+    const int P = (axis + 1) % 3 < (axis + 2) % 3 ? (axis + 1) % 3 : (axis + 2) % 3, Q = 3 - axis - P;
     const double* ti = tab + 13 * PG_NOFF15 * 9;
+    const int zero[3] = {0, 0, 0};
+    const int qc = qof(zero);
     double scale = 0.0;
-    for (int t = 0; t < 9; ++t) scale = std::max(scale, std::fabs(ti[qof(0, 0, 0) * 9 + t]));
+    for (int t = 0; t < 9; ++t) scale = std::max(scale, std::fabs(ti[qc * 9 + t]));
     const double tol = 1e-12 * scale;
-    const int inface[3][3] = {{0, 1, 0}, {0, 0, 1}, {0, 1, 1}};
-    for (int face = 0; face < 2; ++face) {                    // 0: x = 0 (class 12, sign -1), 1: x = NX-1 (class 14, sign +1)
-        const double* tf = tab + (face ? 14 : 12) * PG_NOFF15 * 9;
+    for (int k = 0; k < 3; ++k)
+        for (int t = 0; t < 3; ++t) G[k][t] = 0.0;
+    for (int fi = 0; fi < 2; ++fi) {                          // the high face first (g is read from its +o blocks), then the low face
+        const int face = 1 - fi;                              // 0: low face (sign -1), 1: high face (sign +1)
+        const double* tf = tab + (13 + (face ? pw[axis] : -pw[axis])) * PG_NOFF15 * 9;
         const double sg = face ? 1.0 : -1.0;
         for (int q = 0; q < PG_NOFF15; ++q) {
-            const int o = pg_off15(q), dx = o % 3 - 1;
+            const int o = pg_off15(q);
+            const int d[3] = {o % 3 - 1, (o / 3) % 3 - 1, o / 9 - 1};
             for (int t = 0; t < 9; ++t) {
                 const double bf = tf[q * 9 + t], bi = ti[q * 9 + t];
-                if (dx == (face ? 1 : -1) && std::fabs(bf) > tol) return false;             // outward: absent
-                if (dx == (face ? -1 : 1) && std::fabs(bf - bi) > tol) return false;        // inward: as in the interior
+                if (d[axis] == (face ? 1 : -1) && std::fabs(bf) > tol) return false;             // outward: absent
+                if (d[axis] == (face ? -1 : 1) && std::fabs(bf - bi) > tol) return false;        // inward: as in the interior
             }
         }
         for (int t = 0; t < 9; ++t)
-            if (std::fabs(tf[qof(0, 0, 0) * 9 + t] - 0.5 * ti[qof(0, 0, 0) * 9 + t]) > tol) return false;
+            if (std::fabs(tf[qc * 9 + t] - 0.5 * ti[qc * 9 + t]) > tol) return false;
         for (int k = 0; k < 3; ++k)
-            for (int sgn = -1; sgn <= 1; sgn += 2) {
-                const int q = qof(0, sgn * inface[k][1], sgn * inface[k][2]);
+            for (int sgn = 1; sgn >= -1; sgn -= 2) {
+                int d[3] = {0, 0, 0};
+                if (k != 1) d[P] = sgn;
+                if (k != 0) d[Q] = sgn;
+                const int q = qof(d);
+                if (q < 0) return false;
                 double A[9];
                 for (int t = 0; t < 9; ++t) A[t] = tf[q * 9 + t] - 0.5 * ti[q * 9 + t];
-                const double a = sg * sgn * A[1], b = sg * sgn * A[2];
-                if (face == 1 && sgn == 1) { out->xf[k][0] = a; out->xf[k][1] = b; }
-                const double expect[9] = {0, sg * sgn * out->xf[k][0], sg * sgn * out->xf[k][1], -sg * sgn * out->xf[k][0], 0, 0, -sg * sgn * out->xf[k][1], 0, 0};
-                if (!(face == 1 && sgn == 1))
-                    for (int t = 0; t < 9; ++t)
-                        if (std::fabs(A[t] - expect[t]) > tol) return false;
-                if (std::fabs(A[0]) > tol || std::fabs(A[4]) > tol || std::fabs(A[5]) > tol || std::fabs(A[7]) > tol || std::fabs(A[8]) > tol ||
-                    std::fabs(A[1] + A[3]) > tol || std::fabs(A[2] + A[6]) > tol) return false;
+                // expected: sg * sgn * Ahigh(g),  Ahigh[axis][t] = g_t, Ahigh[t][axis] = -g_t
+                if (face == 1 && sgn == 1)
+                    for (int t = 0; t < 3; ++t) G[k][t] = t == axis ? 0.0 : A[axis * 3 + t];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) {
+                        double expect = 0.0;
+                        if (r == axis && c != axis) expect = sg * sgn * G[k][c];
+                        if (c == axis && r != axis) expect = -sg * sgn * G[k][r];
+                        if (std::fabs(A[r * 3 + c] - expect) > tol) return false;
+                    }
             }
     }
     return true;
@@ -1055,7 +1308,7 @@ void el_fast_geometry(ElSession* s) {
     fg.lkb = fg.full_lo;
     fg.lke = g.nkl - fg.full_hi;
     const int planes = std::max(0, fg.lke - fg.lkb);
-    const bool xface = s->w36.xface != 0;
+    const bool xface = s->w36.faces != 0;
     fg.ntx = (g.NX - (xface ? 1 : 2) + 61) / 62;
     fg.nty = (g.NY - 2 + RY - 1) / RY;
     fg.nyg = (fg.nty + 3) / 4;
@@ -1069,8 +1322,19 @@ void el_fast_geometry(ElSession* s) {
     fg.nb_fast = (fg.nb_fast + 7) / 8 * 8;          // multiple of 8 for the XCD-aware tile order (surplus waves find zc >= nzc and idle)
     fg.ring = 2 * g.NX + (xface ? 0 : 2 * (g.NY - 2));        // boundary nodes of an interior plane left to the class-table pass
     fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * g.NX * g.NY + (long long)planes * fg.ring;
+    if (s->w36.faces & 2) {                                   // y-faces folded: 4 corners per interior plane; the planes 0 / NZ-1: perimeter | whole
+        fg.ring = 4;
+        const long long per = (s->w36.faces & 4) ? 2LL * g.NX + 2LL * (g.NY - 2) : (long long)g.NX * g.NY;
+        fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * per + 4LL * planes;
+    }
     fg.nb_bnd = (int)std::min<long long>((fg.nbnd + 255) / 256, 2LL * s->ctx->num_cu);      // grid-stride: the 29 KB table is loaded per workgroup
+    fg.bnd_last = s->ctx->el_bnd_last != 0 ? 1 : 0;
+    fg.nt = s->ctx->el_fast_nt & 3;
+    // timing aid (results are wrong with it): 1 = marching part only, 2 = boundary pass only
+    if (s->ctx->el_debug_part == 1) { fg.nb_bnd = 0; fg.nbnd = 0; }
+    if (s->ctx->el_debug_part == 2) { fg.nb_fast = 0; fg.nzc = 0; }
     fg.mask = s->d_mask;
+    fg.gf = reinterpret_cast<const double*>(s->d_mask + 32);
 }
 
 int el_apply(ElSession* s, const ElArgs& a, int mode) {
@@ -1078,12 +1342,19 @@ int el_apply(ElSession* s, const ElArgs& a, int mode) {
         const ElFastGeom& fg = s->fgeom;
         const int nb = fg.nb_fast + fg.nb_bnd;
         const bool yx = s->ctx->el_fast_yx != 0;
-        if (s->fast_ry == 2) {
-            if (yx) hipLaunchKernelGGL((k_el_fast<2, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-            else hipLaunchKernelGGL((k_el_fast<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+        // (ZF = with the code for the planes 0 / NZ-1: it costs 60 VGPRs, so slabs without such a plane and sessions that leave those
+        // planes to the class-table pass run the lean instantiation)
+        const bool zf = (s->w36.faces & 4) != 0;
+        auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w18, fg); };
+        if (s->fast_ry == 4) {
+            if (yx) { if (zf) launch(k_el_fast<4, true, true>); else launch(k_el_fast<4, true, false>); }
+            else { if (zf) launch(k_el_fast<4, false, true>); else launch(k_el_fast<4, false, false>); }
+        } else if (s->fast_ry == 2) {
+            if (yx) { if (zf) launch(k_el_fast<2, true, true>); else launch(k_el_fast<2, true, false>); }
+            else { if (zf) launch(k_el_fast<2, false, true>); else launch(k_el_fast<2, false, false>); }
         } else {
-            if (yx) hipLaunchKernelGGL((k_el_fast<1, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
-            else hipLaunchKernelGGL((k_el_fast<1, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w36, fg);
+            if (yx) { if (zf) launch(k_el_fast<1, true, true>); else launch(k_el_fast<1, true, false>); }
+            else { if (zf) launch(k_el_fast<1, false, true>); else launch(k_el_fast<1, false, false>); }
         }
         PG_HIP(s->ctx, hipGetLastError());
         s->last_apply_blocks = nb;
@@ -1194,7 +1465,7 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     PG_HIP(ctx, hipMalloc(&s->tab, 27 * PG_NOFF15 * 9 * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->dinv, 81 * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->scal, ESC_COUNT * sizeof(double)));
-    PG_HIP(ctx, hipMalloc(&s->d_mask, 32 * sizeof(unsigned)));
+    PG_HIP(ctx, hipMalloc(&s->d_mask, 32 * sizeof(unsigned) + 32 * sizeof(double)));      // + the 27 face remainder numbers
     PG_HIP(ctx, hipHostMalloc(&s->h_pin, ESC_COUNT * sizeof(double)));
     PG_HIP(ctx, hipMemsetAsync(s->scal, 0, ESC_COUNT * sizeof(double), ctx->stream));
     double h[3] = {1, 1, 1};
@@ -1203,15 +1474,28 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     PG_HIP(ctx, hipGetLastError());
     for (int q = 0; q < PG_NOFF15; ++q) fold_elasticity_block(grid->dim, h, s->lam, s->mu, 13, q, s->interior.w + q * 9);
     size_t npart = (size_t)s->nblk;
-    s->fast_ry = ctx->el_fast_ry == 2 ? 2 : 1;
+    s->fast_ry = ctx->el_fast_ry == 4 ? 4 : (ctx->el_fast_ry == 2 ? 2 : 1);
     s->fast = grid->dim == 3 && s->g.NX >= 3 && s->g.NY >= 3 && s->g.NZ >= 3 && el_fast_weights(s->interior.w, &s->w36);
-    s->w36.xface = 0;
+    s->w36.faces = 0;
     if (s->fast && ctx->el_fast_xface) {
         // x-face rows inside the marching kernel: only when the host table has the structure the kernel relies on
         std::vector<double> htab((size_t)27 * PG_NOFF15 * 9);
         for (int e = 0; e < 27 * PG_NOFF15; ++e) fold_elasticity_block(grid->dim, h, s->lam, s->mu, e / PG_NOFF15, e % PG_NOFF15, htab.data() + (size_t)e * 9);
-        s->w36.xface = el_xface_weights(htab.data(), &s->w36) ? 1 : 0;
+        double gf[3][3][3] = {};
+        s->w36.faces = el_face_weights(htab.data(), 0, gf[0]) ? 1 : 0;
+        // y- and z-faces as well: they are natural faces here (only x = 0 is clamped); a slab without an interior plane has no
+        // marching chunk to attach its end planes to
+        const bool yz_natural = s->g.bc_mode == PDEGPU_BC_DIRECTIONAL && !s->g.bc_present[2];
+        if (s->w36.faces && ctx->el_fast_yzface && yz_natural && el_face_weights(htab.data(), 1, gf[1])) {
+            const bool has_lo = s->g.k0 == 0, has_hi = s->g.k0 + s->g.nkl == s->g.NZ;
+            const int planes = s->g.nkl - (has_hi ? 1 : 0) - (has_lo ? 1 : 0);
+            s->w36.faces |= 2;
+            if ((ctx->el_fast_yzface & 2) && (has_lo || has_hi) && planes >= 1 && el_face_weights(htab.data(), 2, gf[2])) s->w36.faces |= 4;
+        }
+        PG_HIP(ctx, hipMemcpyAsync(s->d_mask + 32, gf, sizeof(gf), hipMemcpyHostToDevice, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));      // gf is a local
     }
+    if (s->fast && !el_pack_weights(s->w36, &s->w18)) s->fast = false;
     if (s->fast) {
         el_fast_geometry(s);
         if (s->fgeom.nbnd > 0x7fffffffLL) s->fast = false;

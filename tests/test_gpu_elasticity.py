@@ -53,7 +53,7 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
     outs = {}
     try:
         for fast, ry, waves, yx in ((0, 1, 2048, 1), (1, 1, 2048, 1), (1, 2, 2048, 1), (1, 1, 1, 1), (1, 2, 100000, 1), (1, 1, 2048, 0),
-                                    (1, 2, 2048, 0), (1, 2, 1, 0)):
+                                    (1, 2, 2048, 0), (1, 2, 1, 0), (1, 4, 2048, 1), (1, 4, 2048, 0), (1, 4, 1, 1)):
             for k, v in (("el_fast", fast), ("el_fast_ry", ry), ("el_fast_waves", waves), ("el_fast_yx", yx)):
                 _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
             y = np.full_like(u, np.nan)
@@ -256,12 +256,13 @@ def test_row_and_kernel_variants_agree(lib, gpu_ctx):
     outs = []
     try:
         for cfg in (dict(el_fast=1, el_fast_ry=2, el_fast_yx=1), dict(el_fast=1, el_fast_ry=1, el_fast_yx=1), dict(el_fast=1, el_fast_ry=2, el_fast_yx=0),
-                    dict(el_fast=0), dict(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=0), dict(el_grid_mult=1), dict(el_grid_mult=16, el_fast_waves=300)):
+                    dict(el_fast=0), dict(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=0), dict(el_grid_mult=1), dict(el_grid_mult=16, el_fast_waves=300),
+                    dict(el_fast_ry=4, el_fast_yx=1), dict(el_fast_ry=4, el_fast_yx=0), dict(el_fast_xface=0), dict(el_fast_xface=0, el_fast_ry=1)):
             tun(**cfg)
             outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress",
                                                                rtol=1e-12))
     finally:
-        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=4096)
+        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=4096, el_fast_xface=1)
     ref = o.solve_elasticity_3d(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress")
     for f in outs:
         assert rel_err(f.values, ref.values) < TOL

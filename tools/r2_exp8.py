@@ -11,7 +11,7 @@ lib = L.load_library()
 ctx = L.context(0)
 el = L.Elasticity()
 el.E, el.nu = 210e9, 0.3
-cfgs = [dict(el_fast_waves=w, el_fast_ry=ry) for ry in (2, 1) for w in (2880, 4096, 6144, 8192, 12288, 16384)]
+cfgs = [dict(el_fast_waves=w, el_fast_ry=ry) for ry in (2, 4) for w in (1152, 2048, 2304, 2880, 4096, 6144)]
 for n in ((256, 64, 64), (512, 128, 128)):
     g = L.make_grid(3, n, (1.0, 0.25, 0.25))
     nodes = (n[0] + 1) * (n[1] + 1) * (n[2] + 1)
