@@ -60,6 +60,7 @@ struct pdegpu_ctx {
     int persist2d = 1;          // 2-D grids up to 1024 cells wide and 8 rows per CU: the whole CG loop in ONE cooperative launch with the state
                                 // in registers (persist2d.hip); 0 = one launch per kernel
     int plane2d = 1;            // 2-D grids: 1 = the two CG kernels load their tile in one round (k_plane2d); 0 = flat view of the marching kernels
+    int hybrid_k2 = 1;          // hybrid sessions: 1 = 64 B/DoF variant as on Dirichlet grids (K1 stores no q, K2 applies the operator again: marching + boundary launch)
     int hybrid_fx = 1;          // hybrid sessions: 1 = the marching kernel computes the x-face rows too (the class-table pass keeps the y / z faces)
     int hybrid_bc = 1;          // 3-D grids with natural faces: 1 = marching kernel for the interior + class-table kernel for the boundary
                                 // nodes; 0 = class-table kernel everywhere

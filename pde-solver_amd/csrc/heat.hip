@@ -194,7 +194,7 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     if (a.bnd_n <= 0) return PDEGPU_OK;
     if (a.bnd_n > 0x7fffffffLL) return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "hybrid path: more than 2^31 boundary nodes");
     const int n1 = li_fast ? li_fast->grid : 0;
-    a.partials = s->d_part + n1;
+    a.partials = a.partials + n1;                 // appended to the marching launch's (K2: wherever the caller keeps its r.r partials)
     a.dot_which = -1;
     LaunchInfo l2;
     PG_TRY(stencil_general(s->ctx, a, mode, &l2));
@@ -277,7 +277,15 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
 
 // 64 B/DoF variant (K2 recomputes q with the marching stencil): pays for the 7-point operator only — with the
 // 15-point operator the second stencil pass costs more than the 8 B/DoF it saves (measured)
-bool k2_is_stencil(const pdegpu_session* s) { return s->fast && !s->hybrid && s->ctx->cg_variant == 1 && s->npt == 7; }
+// Hybrid sessions too (tunable hybrid_k2): their second stencil pass has a boundary launch of its own — on a slab that owns every plane
+// only: K1 forms p_n on the ghost planes for the rows the marching kernel owns, not for the boundary rows, so a slab with neighbours
+// keeps the 72-B form (q stored, r and p exchanged).  It also needs hybrid_fx: K2 updates r in place, and the marching kernel stores 0 at
+// the nodes of its rows it does not compute — right for Dirichlet nodes, fatal for x-face nodes that the boundary launch still has to read.
+bool k2_is_stencil(const pdegpu_session* s) {
+    const bool whole = s->g.k0 == 0 && s->g.nkl == s->g.NZ;
+    const bool hyb_ok = s->ctx->hybrid_k2 && s->ctx->hybrid_fx && !s->weighted && whole;
+    return s->fast && (!s->hybrid || hyb_ok) && s->ctx->cg_variant == 1 && s->npt == 7;
+}
 
 // lk_lo < lk_hi: one part of a split K1 (marching sessions only) — the launch covers the local planes [lk_lo, lk_hi), appends its
 // partials at part_off and leaves the p ping-pong alone (the caller flips it after the last part)
@@ -367,7 +375,17 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
-        return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
+        if (!s->hybrid) return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
+        a.free_x = s->ctx->hybrid_fx ? 2 : 1;
+        a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
+        a.dot_which = -1;
+        a.tabA = s->tabs.d_tabA;
+        a.off_mask = table_mask(s->hA);
+        LaunchInfo lf;
+        PG_TRY(stencil_fast(s->ctx, a, APPLY_CG_K2, &lf));
+        PG_TRY(hybrid_boundary(s, a, APPLY_CG_K2, &lf));
+        if (li) *li = lf;
+        return PDEGPU_OK;
     }
     // nullptr: partials only, reduced by k_reduce (always so when K1's dot has a second launch to wait for: hybrid / 2-D tile sessions)
     unsigned* cnt = use_inlaunch(s) ? s->d_counter : nullptr;
@@ -429,7 +447,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -464,6 +482,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "extrapolate")) return &ctx->extrapolate;
     if (!strcmp(key, "hybrid_bc")) return &ctx->hybrid_bc;
     if (!strcmp(key, "hybrid_fx")) return &ctx->hybrid_fx;
+    if (!strcmp(key, "hybrid_k2")) return &ctx->hybrid_k2;
     if (!strcmp(key, "plane2d")) return &ctx->plane2d;
     if (!strcmp(key, "persist2d")) return &ctx->persist2d;
     if (!strcmp(key, "persist2d_sr")) return &ctx->persist2d_sr;

@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
     const GridDev& g = a.g;
     const bool bnd = a.bnd_n > 0;
     const long long total = bnd ? a.bnd_n : (long long)g.nkl * g.PP;
-    double alpha_prev = 0.0, beta = 0.0;
+    double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
     if (MODE == APPLY_CG_K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
+    if (MODE == APPLY_CG_K2) res_scale = cg_alpha_in(a.di, a.scal, sRed);      // r -= alpha A p on the boundary nodes of a hybrid session
 
     double acc = 0.0;
     for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += (long long)gridDim.x * 256) {
@@ -165,13 +166,13 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
         if (MODE == APPLY_PLAIN) {
             a.out[idx] = s;
             if (real) acc += a.in[idx] * s;
-        } else if (MODE == APPLY_RESIDUAL) {
+        } else if (MODE == APPLY_RESIDUAL || MODE == APPLY_CG_K2) {
             double rv = 0.0;
-            if (real && !dir) rv = (a.rhs ? a.rhs[idx] : a.rhs_const) - s;
+            if (real && !dir) rv = (a.rhs ? a.rhs[idx] : a.rhs_const) - res_scale * s;
             a.out[idx] = rv;
             acc += rv * rv;
         } else {
-            a.out[idx] = s;
+            if (a.out) a.out[idx] = s;                        // (64-B variant: q is not stored, K2 applies the operator again)
             acc += pn * s;
         }
     }
@@ -1066,6 +1067,7 @@ int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo*
         switch (mode) {
             case APPLY_PLAIN: hipLaunchKernelGGL((k_general<APPLY_PLAIN, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
             case APPLY_RESIDUAL: hipLaunchKernelGGL((k_general<APPLY_RESIDUAL, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
+            case APPLY_CG_K2: hipLaunchKernelGGL((k_general<APPLY_CG_K2, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
             default: hipLaunchKernelGGL((k_general<APPLY_CG_K1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a); break;
         }
     }

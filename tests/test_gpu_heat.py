@@ -218,6 +218,32 @@ def test_hybrid_path_tile_edges_and_modes(lib, gpu_ctx, nx, steady):
         assert rel_err(a.values, o.solve_heat_3d(**kw).values) < TOL
 
 
+@pytest.mark.parametrize("nx", [20, 128, 129, 200])
+def test_hybrid_64_byte_variant_matches_stored_q_variant(lib, gpu_ctx, nx):
+    """steady natural-face runs: K2 applying the operator again (marching + boundary launch, r updated in place; hybrid_k2 = 1) vs the
+    form that stores q (hybrid_k2 = 0), faces free on one or both x-sides, with and without the x-face rows in the marching kernel
+    (without them the 64-byte form must switch itself off), and vs the oracle"""
+    from pdegpu import heat, _lib
+    for bcs in (dict(T_left=3.0, T_right=None, T_side=None), dict(T_left=None, T_right=None, T_side=1.0), dict(T_left=1.0, T_right=2.0, T_side=None)):
+        kw = dict(Lx=1.5, Ly=0.5, Lz=0.45, nx=nx, ny=7, nz=6, diffusivity=0.8, T_boundary=0.0, T_initial=2.0, dt=0.02, num_steps=1,
+                  source_type="constant", source_value=1.2, steady=True, **bcs)
+        runs = {}
+        try:
+            for k2s, fx in ((1, 1), (0, 1), (1, 0)):
+                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"hybrid_k2", k2s))
+                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"hybrid_fx", fx))
+                runs[(k2s, fx)] = heat._solve_heat_3d_raw(**kw, rtol=1e-12)
+        finally:
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"hybrid_k2", 1))
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"hybrid_fx", 1))
+        a = runs[(1, 1)]
+        assert a.meta["solver_path"] == "fast+boundary"
+        for r in runs.values():
+            assert rel_err(a.values, r.values) < 1e-9
+        if nx <= 129:
+            assert rel_err(a.values, o.solve_heat_3d(**kw).values) < TOL
+
+
 @pytest.mark.parametrize("nx", [127, 128, 200])
 @pytest.mark.parametrize("steady", [False, True])
 def test_hybrid_x_faces_in_the_marching_kernel_q1_and_p1(lib, gpu_ctx, nx, steady):
@@ -389,7 +415,8 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs,
                 engs.append(GpuSlabEngine(grid, h, k0, nk, 0, stream))
                 _lib.check(engs[-1].ctx, lib.pdegpu_set_tunable(engs[-1].ctx, b"cg_variant", variant))
             # the 64-B variant keeps p on the ghost planes itself: only r is exchanged
-            assert engs[0].needs_p_halo() == (not (fast == 1 and variant == 1))      # hybrid: q is stored, r and p travel
+            # hybrid slabs with neighbours: q is stored, r and p travel; a hybrid session that owns every plane uses the 64-B form too
+            assert engs[0].needs_p_halo() == (not (variant == 1 and (fast == 1 or (hybrid and ns == 1))))
             vecs = (VEC_R, VEC_P) if engs[0].needs_p_halo() else (VEC_R,)
 
             def exchange():
@@ -660,7 +687,7 @@ def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, ca
 
 @pytest.mark.parametrize("setting", [dict(fast_ry=1), dict(fast_ry=2), dict(fast_ry=4), dict(fast_ry=8), dict(fast_nt=0), dict(fast_nt=3), dict(fast_ex=0),
                                      dict(fast_wg_per_cu=2), dict(fast_wg_per_cu=6), dict(fast_wg_per_cu_k2=3), dict(grid_mult=2), dict(k2_grid_mult=8),
-                                     dict(extrapolate=0), dict(hybrid_bc=0), dict(hybrid_fx=0), dict(fast_minlen=4), dict(fast_small_mult=4),
+                                     dict(extrapolate=0), dict(hybrid_bc=0), dict(hybrid_fx=0), dict(hybrid_k2=0), dict(fast_minlen=4), dict(fast_small_mult=4),
                                      dict(cg_variant=0), dict(cg_variant=0, fast_ex=0, fast_ry=4), dict(fast_ex_all=1), dict(fast_pf=1),
                                      dict(fast_ex_all=1, fast_pf=1, fast_ry=4), dict(fast_zlen=3), dict(tile3d_max_nodes=0),
                                      # per-mode configuration words: ry + 16 wg + 256 ex + 512 pf
@@ -670,7 +697,7 @@ def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kerne
     64-B variant), a 3-D transient (15-point) and a natural-face problem, against the default run"""
     from pdegpu import heat, _lib
     defaults = dict(fast_ry=0, fast_nt=-1, fast_ex=1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, extrapolate=1,
-                    hybrid_bc=1, hybrid_fx=1, fast_minlen=1, fast_small_mult=1, cg_variant=1, fast_ex_all=0, fast_pf=0, fast_zlen=0, tile3d_max_nodes=3000000,
+                    hybrid_bc=1, hybrid_fx=1, hybrid_k2=1, fast_minlen=1, fast_small_mult=1, cg_variant=1, fast_ex_all=0, fast_pf=0, fast_zlen=0, tile3d_max_nodes=3000000,
                     fast_cfg_plain=-1, fast_cfg_res=-1, fast_cfg_k1=-1, fast_cfg_k2=-1)
     def runs():
         a = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 140, 13, 11, 0.9, 1.5, 20.0, 0.003, 1, steady=True, source_type="constant", source_value=2.0, rtol=1e-12)

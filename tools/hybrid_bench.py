@@ -9,9 +9,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0))
 N = (n + 1) ** 3
 for steady in (1, 0):
-    for hyb, fx in ((1, 1), (1, 0), (0, 0), (1, 1), (1, 0)):
+    for hyb, fx, k2s in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 0, 0), (1, 1, 1), (1, 1, 0)):
         L.check(ctx, lib.pdegpu_set_tunable(ctx, b"hybrid_bc", hyb))
         L.check(ctx, lib.pdegpu_set_tunable(ctx, b"hybrid_fx", fx))
+        L.check(ctx, lib.pdegpu_set_tunable(ctx, b"hybrid_k2", k2s))
         h = L.Heat()
         h.kappa, h.dt, h.steady, h.source = 1.0, 0.0025, steady, 1.0
         h.bc_mode, h.fast_path = L.BC_DIRECTIONAL, 1
@@ -25,5 +26,5 @@ for steady in (1, 0):
         L.check(ctx, lib.pdegpu_session_iterate(s, 20, 1, st))
         rr = C.c_double(); L.check(ctx, lib.pdegpu_session_rr(s, C.byref(rr)))
         k1, k2 = st.kernel_ms[0] / 20, st.kernel_ms[1] / 20
-        print(f"steady={steady} hybrid_bc={hyb} hybrid_fx={fx}: K1 {k1:.3f} ms  K2 {k2:.3f} ms  -> {N/(k1+k2)/1e6:.1f} GDoF/s (72 B/DoF: {72*N/(k1+k2)/1e6:.0f} GB/s)  rr {rr.value:.6e}", flush=True)
+        print(f"steady={steady} hybrid_bc={hyb} hybrid_fx={fx} hybrid_k2={k2s}: K1 {k1:.3f} ms  K2 {k2:.3f} ms  -> {N/(k1+k2)/1e6:.1f} GDoF/s   rr {rr.value:.6e}", flush=True)
         lib.pdegpu_session_destroy(s)
