@@ -22,6 +22,7 @@ struct pdegpu_ctx {
                                 // (3 when one slab vector exceeds 64 MiB, i.e. nothing stays cache-resident)
     int fast_ex = 1;            // 1: CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
                                 // instead of 2-lane global loads (measured: 1.65 -> 1.52 ms per 512^3 CG iteration)
+    int fast_nt_in = 0;         // one-vector marching modes on HBM-resident grids: non-temporal loads of the input (1 inner rows, 2 all rows)
     int fast_ex_all = 0;        // 1: the bare apply / residual pass use the LDS edge hand-off too (default: CG kernels only)
     int fast_pf = 0;            // 1: bare apply / residual / stencil K2 (7-point) request plane lk+2 before computing plane lk
     // per-mode overrides of the marching kernels, index = ApplyMode (PLAIN, RESIDUAL, CG_K1, CG_K2); -1 = follow the global tunables.
@@ -214,6 +215,7 @@ struct StencilArgs {
     int bnd_lkb = 0;          // first local plane that is interior in z
     int bnd_ring = 0;         // boundary nodes of such a plane: 2 NX + 2 (NY - 2)
     int bnd_xcover = 0;       // columns [0, bnd_xcover) of interior rows get p / x from the marching kernel (128-node tiles)
+    int nt_in = 0;            // marching kernel, one-vector modes: 1 = non-temporal loads of the rows no other workgroup reads, 2 = of every row
     int fx_hi = 0;            // free_x == 2: the tiles reach the node NX-1 (no extra tile is spent on it: a fifth, one-node tile column
                               // per 513-node row was measured 27 % SLOWER than leaving that column to the class-table pass)
     int bnd_xcols = 2;        // boundary pass: x-face columns of the interior rows it still owns (2 both, 1 only x = NX-1, 0 none)

@@ -313,7 +313,16 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 val.y = rr.y + beta * po.y;
                 if (po_out) *po_out = po;
             } else {
-                const double2 v = load_pair(a.in, off);
+                // (rows 2 .. RY-1 of a tile are read by no other workgroup; rows 1 / RY are the y-neighbour's halo, 0 / RY+1 its own rows)
+                const int rr = j - j0 + 1;
+                const bool nt = a.nt_in == 2 || (a.nt_in == 1 && rr >= 2 && rr <= RY - 1);      // kernel- / unroll-uniform
+                double2 v;
+                if (nt) {
+                    const dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(a.in + off));
+                    v = make_double2(t.x, t.y);
+                } else {
+                    v = load_pair(a.in, off);
+                }
                 val.x = v.x + shift;
                 val.y = v.y + shift;
             }
@@ -1102,7 +1111,10 @@ GridDev stencil_flat2d_view(const GridDev& g) {
     return v;
 }
 
-int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo* li) {
+    StencilArgs a = a_in;
+    const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
+    a.nt_in = (mode != APPLY_CG_K1 && hbm) ? ctx->fast_nt_in : 0;
     if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
     const int ry = mode_cfg(ctx, mode).ry;
     if (a.npt == 7) {
