@@ -335,7 +335,42 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             return a.in[off] + shift;
         };
         // edge values of one plane: E[r] = value at node i0-1 (lane 0) / i0+2 (lane 63) of row r
-        auto plane_edges = [&](int lk, const double2* rows, double* E, bool all_rows) {
+        // EX: tile-edge neighbours that belong to ANOTHER workgroup (or to no tile: the x-face node NX-1 of a natural-face grid at 2^k + 1
+        // nodes per row) still come from global memory.  Those loads are issued with the plane's other loads (edge_global, unconditional
+        // like them, wave-uniform branch) and only selected here: inside `if (lane == 63)` their first use was a `s_waitcnt vmcnt(0)` in
+        // every z-step that also drained the prefetch of the next plane (natural-face K2: 0.75 ms against 0.55 ms on a Dirichlet grid).
+        const int il_t = xt * 128 - 1, ir_t = xt * 128 + 128;
+        const bool cgvec_t = (K1 || K2) && !a.free_x;
+        const bool has_l_t = wave_x > 0, has_r_t = (wave_x < fg.wxt - 1) && (xt + 1 < fg.ntx);
+        const bool gl_t = !has_l_t && il_t >= 0 && (il_t >= 1 || !cgvec_t) && active;
+        const bool gr_t = !has_r_t && ir_t <= g.NX - 1 && (ir_t <= g.NX - 2 || !cgvec_t) && active;
+        const bool need_ge = EX && __builtin_amdgcn_readfirstlane((int)(gl_t || gr_t)) != 0;      // wave-uniform
+        // (the empty asm with a memory clobber pins the loads here: left alone the compiler sinks them to their only use — the edge lanes'
+        // branch of plane_edges, behind the wait for the whole plane — and waits for them right there; the arithmetic p = r + beta p /
+        // in + shift happens at the use for the same reason.  A volatile load is no alternative: it is followed by `s_waitcnt vmcnt(0)`.)
+        auto edge_global = [&](int lk, double* EG, double* EGp, bool all_rows) {
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                EG[r] = 0.0;
+                EGp[r] = 0.0;
+            }
+            if (need_ge) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const bool own = (r >= 1) && (r <= RY);
+                    if (all_rows || own) {
+                        const bool want = (lane == 0 && gl_t) || (lane == 63 && gr_t);
+                        const int j = j0 - 1 + r;
+                        const long long off = (want && row_ok(j)) ? (long long)lk * g.PP + (long long)j * g.PX + i0 + edge_off : 0;
+                        EG[r] = a.in[off];
+                        if (K1) EGp[r] = a.p_old[off];
+                        // (a lane that does not want the value reads offset 0 and never uses it; a row outside the grid: offset 0, masked below)
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        };
+        auto plane_edges = [&](int lk, const double2* rows, double* E, bool all_rows, const double* EG, const double* EGp) {
             if (!EX) {
 #pragma unroll
                 for (int r = 0; r < RH; ++r) {
@@ -352,14 +387,9 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 if (lane == 63) sEdge[buf][wv][r][1] = rows[r].y;
             }
             __syncthreads();
-            // x-neighbour wave inside this workgroup (and covering real nodes: an inactive right neighbour holds zeros)
-            const bool has_l = wave_x > 0, has_r = (wave_x < fg.wxt - 1) && (xt + 1 < fg.ntx);
-            // a global load only where the neighbour tile belongs to another workgroup AND the node can be non-zero:
-            // CG vectors (K1: r, p; K2: p) vanish on the Dirichlet columns, PLAIN / RESIDUAL inputs carry boundary values
-            const int il = xt * 128 - 1, ir = xt * 128 + 128;
-            const bool cgvec = (K1 || K2) && !a.free_x;
-            const bool gl = !has_l && il >= 0 && (il >= 1 || !cgvec) && active;
-            const bool gr = !has_r && ir <= g.NX - 1 && (ir <= g.NX - 2 || !cgvec) && active;
+            // x-neighbour wave inside this workgroup (and covering real nodes: an inactive right neighbour holds zeros); a global value
+            // (EG, see edge_global) only where the neighbour tile belongs to another workgroup AND the node can be non-zero: CG vectors
+            // (K1: r, p; K2: p) vanish on the Dirichlet columns, PLAIN / RESIDUAL inputs carry boundary values
 #pragma unroll
             for (int r = 0; r < RH; ++r) {
                 const bool own = (r >= 1) && (r <= RY);
@@ -367,17 +397,11 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 if (all_rows || own) {
                     const int j = j0 - 1 + r;
                     if (lane == 0) {
-                        if (has_l) e = sEdge[buf][wv - 1][r][1];
-                        else if (gl && row_ok(j)) {
-                            const long long off = (long long)lk * g.PP + (long long)j * g.PX + il;
-                            e = K1 ? a.in[off] + beta * a.p_old[off] : a.in[off] + shift;
-                        }
+                        if (has_l_t) e = sEdge[buf][wv - 1][r][1];
+                        else if (gl_t && row_ok(j)) e = K1 ? EG[r] + beta * EGp[r] : EG[r] + shift;
                     } else if (lane == 63) {
-                        if (has_r) e = sEdge[buf][wv + 1][r][0];
-                        else if (gr && row_ok(j)) {
-                            const long long off = (long long)lk * g.PP + (long long)j * g.PX + ir;
-                            e = K1 ? a.in[off] + beta * a.p_old[off] : a.in[off] + shift;
-                        }
+                        if (has_r_t) e = sEdge[buf][wv + 1][r][0];
+                        else if (gr_t && row_ok(j)) e = K1 ? EG[r] + beta * EGp[r] : EG[r] + shift;
                     }
                 }
                 E[r] = e;
@@ -420,15 +444,20 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             C[r] = value_row(lk0, j, &po);
             if (K1 && own) own_update(lk0, j, C[r], po, own_xload(lk0, j));
         }
-        if (W15) plane_edges(lk0 - 1, P, EP, true);
-        plane_edges(lk0, C, EC, W15);
+        double EG[RH], EGp[RH];
+        if (W15) {
+            edge_global(lk0 - 1, EG, EGp, true);
+            plane_edges(lk0 - 1, P, EP, true, EG, EGp);
+        }
+        edge_global(lk0, EG, EGp, W15);
+        plane_edges(lk0, C, EC, W15, EG, EGp);
         if (PF) {
 #pragma unroll
             for (int r = 0; r < RH; ++r) {
                 N[r] = value_row(lk0 + 1, j0 - 1 + r, nullptr);
                 EN[r] = 0.0;
             }
-            if (!EX) plane_edges(lk0 + 1, N, EN, W15);
+            if (!EX) plane_edges(lk0 + 1, N, EN, W15, EG, EGp);
         }
 
         // K1 keeps p_n valid on the ghost planes of the slab (same formula, same inputs as the neighbour rank)
@@ -457,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                     N2[r] = value_row(lkn, j0 - 1 + r, nullptr);
                     EN2[r] = 0.0;
                 }
-                if (!EX) plane_edges(lkn, N2, EN2, W15);
+                if (!EX) plane_edges(lkn, N2, EN2, W15, EG, EGp);
             } else {
 #pragma unroll
                 for (int r = 0; r < RH; ++r) {
@@ -469,7 +498,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
 #pragma unroll
                     for (int r = 0; r < RY; ++r) XV[r] = own_xload(lk + 1, j0 + r);
                 }
-                if (!EX) plane_edges(lk + 1, N, EN, W15);      // global edge loads: issue them with the plane's loads
+                if (!EX) plane_edges(lk + 1, N, EN, W15, EG, EGp);      // global edge loads: issue them with the plane's loads
+                else edge_global(lk + 1, EG, EGp, W15);                 // (EX: the few that no wave of the workgroup can hand over)
             }
             double2 RHS[RY];
             if (RES) {
@@ -484,7 +514,10 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 }
             }
 
-            if (EX) plane_edges(lk + 1, N, EN, W15);           // LDS hand-off of the new plane's tile-edge values
+            if (EX) {
+                if (PF) edge_global(lk + 1, EG, EGp, W15);          // (with the deeper prefetch the plane was requested a step ago: not these)
+                plane_edges(lk + 1, N, EN, W15, EG, EGp);      // LDS hand-off of the new plane's tile-edge values
+            }
             // ---- stencil of plane lk -----------------------------------------------------------
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
