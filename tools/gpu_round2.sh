@@ -23,5 +23,7 @@ timeout -k 10 300 tools/build/membw > gpurun_out/r2p/membw.log 2>&1; echo "membw
 timeout -k 10 300 python tools/slab_surrogate.py gpurun_out/r2p/slab_surrogate.json > gpurun_out/r2p/surrogate.log 2>&1; echo "surrogate exit $?"
 timeout -k 10 200 python tools/c2_persist.py 40 > gpurun_out/r2p/c2_persist.log 2>&1; echo "c2_persist exit $?"
 timeout -k 10 200 python tools/hybrid_bench.py 512 > gpurun_out/r2p/hybrid.log 2>&1; echo "hybrid exit $?"
+timeout -k 10 200 python tools/r2_exp12.py > gpurun_out/r2p/exp12.log 2>&1; echo "exp12 exit $?"
+timeout -k 10 300 python tools/r2_exp13.py > gpurun_out/r2p/exp13.log 2>&1; echo "exp13 exit $?"
 find gpurun_out/prof gpurun_out/prof_el gpurun_out/prof_c25 gpurun_out/prof_c2p -size +8M -delete 2>/dev/null
 find gpurun_out/prof* -name "*kernel_stats.csv" | head
