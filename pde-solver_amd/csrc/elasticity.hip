@@ -260,6 +260,7 @@ struct ElFastGeom {
     int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
     int nb_bnd;                // boundary workgroups
     int bnd_last;              // 1: they take the LAST block indices
+    int xt;                    // nodes a wave owns per row: 62 (lanes 1 .. 62), or 48: tiles then start on 128-byte boundaries and store whole lines
     int nt;                    // bit 0: non-temporal stores of the marching part, bit 1: non-temporal loads of its own rows
     int full_lo, full_hi;      // 1: this slab owns the global plane 0 / NZ-1 (all of its nodes are boundary nodes)
     int ring;                  // boundary nodes of an interior plane: 2 NX + 2 (NY - 2)
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
         }
         const bool ghost_wave = YX && yt >= fg.nty;           // beyond the last row tile: takes part in the barriers only
         if (ghost_wave) yt = fg.nty - 1;                      // (loads stay inside the grid; nothing is stored)
-        const int i = xt * 62 + lane;                         // lanes 0 and 63: x-halo only (lane 0 of the first tile: the face x = 0)
+        const int i = xt * fg.xt + lane;                         // lanes 0 and 63: x-halo only (lane 0 of the first tile: the face x = 0)
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
         const int lk0 = fg.lkb + zc * fg.zlen;
         const int lk1 = min(lk0 + fg.zlen, fg.lke);
@@ -486,9 +487,9 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             // x-faces: lane 0 of the first tile is the node i = 0 (clamped: its row is 0 when Dirichlet rows are masked), the node
             // i = NX-1 (traction-free) sits on one of the lanes 1 .. 62 of the last tile
             const bool face_lo = (w.faces & 1) && i == 0, face_hi = (w.faces & 1) && i == g.NX - 1;
-            const bool wave_has_face = (w.faces & 1) && (xt == 0 || (xt + 1) * 62 >= g.NX - 1);      // wave-uniform
+            const bool wave_has_face = (w.faces & 1) && (xt == 0 || (xt + 1) * fg.xt >= g.NX - 1);      // wave-uniform
             const double kup = face_hi ? 0.0 : 1.0, klo = face_lo ? 0.0 : 1.0;      // no coupling across the face (the lanes beyond hold finite pad values)
-            const bool out_x = (lane >= 1 && lane <= 62 && i <= g.NX - ((w.faces & 1) ? 1 : 2)) || face_lo;
+            const bool out_x = (lane >= 1 && lane <= fg.xt && i <= g.NX - ((w.faces & 1) ? 1 : 2)) || face_lo;
             const int rows_out = ghost_wave ? 0 : min(RY, g.NY - 1 - j0);      // owned rows inside the grid (wave-uniform)
             // lanes beyond the padded row (the last 62-node tile overshoots: 558 columns for a 513-node row) read the row's last pad
             // entry instead of the next row's data: same cache line as real data, no traffic of their own (9 % of the loads at
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             const bool ylo_wave = yz && !ghost_wave && yt == 0;                       // row 0 = the halo row below the first row tile
             const int r_hi = (yz && !ghost_wave && yt == fg.nty - 1) ? g.NY - j0 : 0;       // held-row index of the row NY-1 (2 .. RY+1)
             const bool zlo_chunk = zf && fg.full_lo && zc == 0, zhi_chunk = zf && fg.full_hi && lk1 == fg.lke;
-            const bool out_f = lane >= 1 && lane <= 62 && i >= 1 && i <= g.NX - 2;      // face nodes proper (the x-ends are edges of the box)
+            const bool out_f = lane >= 1 && lane <= fg.xt && i >= 1 && i <= g.NX - 2;      // face nodes proper (the x-ends are edges of the box)
             auto face_finish = [&](long long o, const double* c0, double* y, const double* U, const double* Lw) __attribute__((always_inline)) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
@@ -1309,7 +1310,8 @@ void el_fast_geometry(ElSession* s) {
     fg.lke = g.nkl - fg.full_hi;
     const int planes = std::max(0, fg.lke - fg.lkb);
     const bool xface = s->w36.faces != 0;
-    fg.ntx = (g.NX - (xface ? 1 : 2) + 61) / 62;
+    fg.xt = s->ctx->el_fast_xt == 48 ? 48 : 62;
+    fg.ntx = (g.NX - (xface ? 1 : 2) + fg.xt - 1) / fg.xt;
     fg.nty = (g.NY - 2 + RY - 1) / RY;
     fg.nyg = (fg.nty + 3) / 4;
     const bool yx = s->ctx->el_fast_yx != 0;

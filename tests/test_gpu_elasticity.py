@@ -63,6 +63,18 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
     finally:
         for k, v in (("el_fast", 1), ("el_fast_ry", 2), ("el_fast_waves", 4096), ("el_fast_yx", 1)):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+    # 48-node tiles (128-byte aligned, whole-line stores): same per-node arithmetic, different lanes
+    try:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_fast_xt", 48))
+        for ry, yx in ((2, 1), (1, 0)):
+            for k, v in (("el_fast_ry", ry), ("el_fast_yx", yx)):
+                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+            y = np.full_like(u, np.nan)
+            _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 0))
+            assert np.array_equal(y, outs[(1, ry, 2048, yx)]), (ry, yx)
+    finally:
+        for k, v in (("el_fast_xt", 62), ("el_fast_ry", 2), ("el_fast_yx", 1)):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
     # z-chunking does not change a single bit (same per-node arithmetic)
     assert np.array_equal(outs[(1, 1, 2048, 1)], outs[(1, 1, 1, 1)])
     # neither does handing the y-halo rows through LDS instead of loading them
