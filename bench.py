@@ -191,6 +191,7 @@ class Runner:
         with torch.cuda.stream(self.stream):
             eng = GpuSlabEngine(grid, heat, k0, nk, self.local_rank, self.stream)
             cg = SlabCG(eng, rank, world, overlap=not self.args.no_overlap)
+            cg.force_collectives = bool(case.get("force_collectives"))
             if extras_n1:
                 # in-run streaming ceilings and the bare SpMV are measured FIRST (they use r, q, b as scratch, so they must precede
                 # the CG set-up; they also bring the device to its sustained clocks before the warm-up steps)
@@ -343,6 +344,27 @@ def main():
             except Exception as e:                          # an extra must never void the main number
                 extras[f"{wl}_{sc}"] = {"failed": repr(e)}
                 break
+        if world == 1 and not extras.get("config4_strong", {}).get("failed"):
+            # what the collective calls themselves cost (no wire): the same 512^3 loop with its two 8-byte all-reduces per iteration going
+            # through a ONE-rank RCCL process group — torch.distributed's stream hand-over + RCCL's launch path, on this GPU
+            try:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                R.dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.torch.device(f"cuda:{R.local_rank}"))
+                c3 = dict(case)
+                c3["force_collectives"] = True
+                st3 = max(20, args.steps // 2)
+                r3 = R.run_case(c3, st3, max(5, args.warmup // 2))
+                extras["collective_calls_one_rank"] = {
+                    "what": "main workload with both scalar all-reduces of every iteration issued through a 1-rank RCCL group (no wire time)",
+                    "steps": st3, "ms_per_step": r3["elapsed"] / st3 * 1e3, "value": r3["unknowns"] * st3 / r3["elapsed"], "unit": "DoF/s",
+                    "ms_per_step_without": ms_per_step}
+                R.dist.destroy_process_group()
+            except Exception as e:
+                extras["collective_calls_one_rank"] = {"failed": repr(e)}
         wd.cancel()
         out["extras"] = extras
 

@@ -270,6 +270,7 @@ class SlabCG:
 
     def __init__(self, engine, rank: int, world: int, group=None, overlap: bool = True):
         self.e, self.rank, self.world, self.group = engine, rank, world, group
+        self.force_collectives = False      # measurement aid: run the scalar all-reduces through the process group at world == 1 too
         self.overlap = overlap
         self.iterations = 0
 
@@ -347,7 +348,7 @@ class SlabCG:
     def allreduce(self, which: int):
         """local partial -> global scalar(s) (sum over ranks), in place; which: 0 after k1, 1 after k2"""
         self.e.local_to_global(which)
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             if hasattr(self.e, "global_slots"):
                 a, b = self.e.global_slots(which)
             else:
