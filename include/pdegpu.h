@@ -137,7 +137,8 @@ const char* pdegpu_version(void);
  * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "fast_cfg_plain|res|k1|k2" (per-mode
  * word ry + 16 wg + 256 ex + 512 pf, -1 = global tunables), "el_fast_xface" (1 = x-face rows inside the elasticity marching kernel),
  * "el_fast_yzface" (bit 0: its y-face rows, bit 1: the planes 0 / NZ-1 as well — the class-table pass then keeps the edges of the box), "el_fast_nt"
- * (non-temporal hint bits of that kernel), "el_fast_xt" (62 | 48 nodes per wave and row; 48 = 128-byte aligned tiles, measured slower), "el_bnd_last" (1 = its boundary workgroups take the last block indices), "el_debug_part" (timing aid, 0;
+ * (non-temporal stores of that kernel's output: 1 | 0, -1 = where the vectors are HBM-resident), "el_fast_xt" (62 | 48 nodes per wave and row;
+ * 48 = 128-byte aligned tiles, measured slower), "el_fast_npl" (1 | 2 nodes per lane; 2 = k_el_fast2 with 16-byte accesses, measured slower), "el_bnd_last" (1 = its boundary workgroups take the last block indices), "el_debug_part" (timing aid, 0;
  * 1 / 2 launch only the marching / boundary workgroups: WRONG results), "hybrid_fx" (1 = natural x-face rows inside the heat marching kernel),
  * "hybrid_k2" (1 = steady natural-face sessions on one slab use the 64 B/DoF form: K2 applies the operator again, marching + boundary launch).
  * Results do not depend on them beyond the solver tolerance. */

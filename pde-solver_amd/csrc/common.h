@@ -47,8 +47,9 @@ struct pdegpu_ctx {
     int el_fast_xface = 1;      // k_el_fast: 1 = the x-face nodes (interior in y, z) are computed by the marching part (edge lanes carry the
                                 // face-class weights); 0 = by the class-table boundary pass (45 uncoalesced loads per node)
     int el_fast_yzface = 3;     // k_el_fast also computes: bit 0 the y-face nodes, bit 1 (with bit 0) the nodes of the planes 0 / NZ-1
+    int el_fast_npl = 1;        // k_el_fast: nodes per lane, 1 | 2 (2 = k_el_fast2: 16-byte accesses, 124-node tiles)
     int el_fast_xt = 62;        // k_el_fast: nodes per wave and row, 62 | 48 (48: 128-byte aligned tiles, whole-line stores, a quarter of the lanes idle)
-    int el_fast_nt = 0;         // k_el_fast: bit 0 = non-temporal stores, bit 1 = non-temporal loads of the own rows
+    int el_fast_nt = -1;        // k_el_fast / k_el_fast2: non-temporal stores of the output: 1 | 0; -1 = where the vectors are HBM-resident
     int el_bnd_last = 0;        // k_el_fast: 1 = the boundary workgroups take the last block indices instead of the first
     int el_debug_part = 0;      // timing aid for tools/: 1 = k_el_fast launches its marching part only, 2 = its boundary workgroups only (wrong results)
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -260,8 +261,8 @@ struct ElFastGeom {
     int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
     int nb_bnd;                // boundary workgroups
     int bnd_last;              // 1: they take the LAST block indices
+    int npl;                   // nodes per lane: 1 (k_el_fast) | 2 (k_el_fast2)
     int xt;                    // nodes a wave owns per row: 62 (lanes 1 .. 62), or 48: tiles then start on 128-byte boundaries and store whole lines
-    int nt;                    // bit 0: non-temporal stores of the marching part, bit 1: non-temporal loads of its own rows
     int full_lo, full_hi;      // 1: this slab owns the global plane 0 / NZ-1 (all of its nodes are boundary nodes)
     int ring;                  // boundary nodes of an interior plane: 2 NX + 2 (NY - 2)
     long long nbnd;            // boundary nodes of the slab
@@ -352,8 +353,99 @@ __device__ __forceinline__ void el_face_node(const ElW36& w, const double (*G)[3
     el_off3(w.dg[3], n1, HIGH ? Lw : U);
 }
 
+// Boundary workgroups of the marching launches: the nodes the marching part does not compute (all boundary nodes, or with faces folded in the
+// edges and corners of the box), one thread per node, truncated class stencils from LDS.  Returns this thread's share of p . q.
+__device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, const ElFastGeom& fg, int bidx, double* sTab, unsigned* sMask) {
+    const GridDev& g = a.g;
+    double acc = 0.0;
+    // ---- boundary nodes: one thread per node, truncated class stencils from LDS -----------------------------
+    for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
+    if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
+    __syncthreads();
+    for (long long e0 = (long long)bidx * 256 + threadIdx.x; e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * 256) {
+        unsigned e = (unsigned)e0;                        // 32-bit divisions (nbnd < 2^31 is checked on the host)
+        int i, j, lk;
+        const unsigned plane_nodes = (unsigned)g.NX * (unsigned)g.NY;
+        if (faces & 2) {
+            // y-faces folded: the planes 0 / NZ-1 this slab owns (their perimeter only when the z-faces are folded as well), then the
+            // four corners of every other plane
+            const unsigned ringp = 2u * (unsigned)g.NX + 2u * (unsigned)(g.NY - 2);
+            const unsigned per = (faces & 4) ? ringp : plane_nodes;
+            const unsigned nlo = fg.full_lo ? per : 0u, nhi = fg.full_hi ? per : 0u;
+            if (e < nlo + nhi) {
+                lk = e < nlo ? -g.k0 : g.NZ - 1 - g.k0;
+                const int t = (int)(e < nlo ? e : e - nlo);
+                if (!(faces & 4)) { j = t / g.NX; i = t % g.NX; }
+                else if (t < g.NX) { j = 0; i = t; }
+                else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
+                else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
+            } else {
+                e -= nlo + nhi;
+                lk = fg.lkb + (int)(e >> 2);
+                j = (e & 2u) ? g.NY - 1 : 0;
+                i = (e & 1u) ? g.NX - 1 : 0;
+            }
+        } else if (fg.full_lo && e < plane_nodes) {
+            lk = -g.k0;                                   // global plane 0
+            j = (int)(e / (unsigned)g.NX);
+            i = (int)(e % (unsigned)g.NX);
+        } else {
+            e -= fg.full_lo ? plane_nodes : 0u;
+            if (fg.full_hi && e < plane_nodes) {
+                lk = g.NZ - 1 - g.k0;
+                j = (int)(e / (unsigned)g.NX);
+                i = (int)(e % (unsigned)g.NX);
+            } else {
+                e -= fg.full_hi ? plane_nodes : 0u;
+                lk = fg.lkb + (int)(e / (unsigned)fg.ring);
+                const int t = (int)(e % (unsigned)fg.ring);
+                if (t < g.NX) { j = 0; i = t; }
+                else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
+                else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }      // (ring = 2 NX with xface: never here)
+            }
+        }
+        const int kg = g.k0 + lk;
+        const long long idx = (long long)lk * g.PP + (long long)j * g.PX + i;
+        double dval;
+        const bool dir = a.mask_dirichlet && pg_dirichlet(g, i, j, kg, &dval);
+        double pc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pc[c] = a.in[c * a.stride + idx];
+        // All 15 neighbours are loaded unconditionally (45 loads in flight instead of 15 dependent round trips): an
+        // offset that leaves the grid still lands inside the allocation (ghost planes / guards / row pads, all zero
+        // or finite neighbour data) and meets a class weight that is exactly 0.
+        double s[3] = {0.0, 0.0, 0.0};
+        double nv[PG_NOFF15][3];
+#pragma unroll
+        for (int q = 0; q < PG_NOFF15; ++q) {
+            const int o = pg_off15(q);
+            const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+            const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nv[q][c] = a.in[c * a.stride + nb];
+        }
+        if (!dir) {
+            const int cls = pg_axis_class(i, g.NX) + 3 * pg_axis_class(j, g.NY) + 9 * pg_axis_class(kg, g.NZ);
+            const double* wtab = &sTab[cls * PG_NOFF15 * 9];
+#pragma unroll
+            for (int q = 0; q < PG_NOFF15; ++q) {
+                const double* blk = wtab + q * 9;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) s[r] += blk[r * 3] * nv[q][0] + blk[r * 3 + 1] * nv[q][1] + blk[r * 3 + 2] * nv[q][2];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.out[c * a.stride + idx] = s[c];
+            acc += pc[c] * s[c];
+        }
+    }
+    return acc;
+}
+
 // (min. 3 workgroups per CU for RY <= 2: the code fits 168 VGPRs without a spill, but left alone the scheduler trades the third wave per SIMD away)
-template <int RY, bool YX, bool ZF>
+// NTS: non-temporal stores of the output (a compile-time choice: behind a runtime branch the compiler merges the two stores and drops the hint)
+template <int RY, bool YX, bool ZF, bool NTS>
 __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, ElW18 wk, ElFastGeom fg) {
     const ElW36 w = el_expand_weights(wk);
     __shared__ double sTab[27 * PG_NOFF15 * 9];
@@ -366,88 +458,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
     // marching workgroups retire, filling the tail of the launch)
     const int bidx = fg.bnd_last ? ((int)blockIdx.x >= fg.nb_fast ? (int)blockIdx.x - fg.nb_fast : -1) : ((int)blockIdx.x < fg.nb_bnd ? (int)blockIdx.x : -1);
     if (bidx >= 0) {
-        // ---- boundary nodes: one thread per node, truncated class stencils from LDS -----------------------------
-        for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
-        if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
-        __syncthreads();
-        for (long long e0 = (long long)bidx * 256 + threadIdx.x; e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * 256) {
-            unsigned e = (unsigned)e0;                        // 32-bit divisions (nbnd < 2^31 is checked on the host)
-            int i, j, lk;
-            const unsigned plane_nodes = (unsigned)g.NX * (unsigned)g.NY;
-            if (w.faces & 2) {
-                // y-faces folded: the planes 0 / NZ-1 this slab owns (their perimeter only when the z-faces are folded as well), then the
-                // four corners of every other plane
-                const unsigned ringp = 2u * (unsigned)g.NX + 2u * (unsigned)(g.NY - 2);
-                const unsigned per = (w.faces & 4) ? ringp : plane_nodes;
-                const unsigned nlo = fg.full_lo ? per : 0u, nhi = fg.full_hi ? per : 0u;
-                if (e < nlo + nhi) {
-                    lk = e < nlo ? -g.k0 : g.NZ - 1 - g.k0;
-                    const int t = (int)(e < nlo ? e : e - nlo);
-                    if (!(w.faces & 4)) { j = t / g.NX; i = t % g.NX; }
-                    else if (t < g.NX) { j = 0; i = t; }
-                    else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
-                    else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
-                } else {
-                    e -= nlo + nhi;
-                    lk = fg.lkb + (int)(e >> 2);
-                    j = (e & 2u) ? g.NY - 1 : 0;
-                    i = (e & 1u) ? g.NX - 1 : 0;
-                }
-            } else if (fg.full_lo && e < plane_nodes) {
-                lk = -g.k0;                                   // global plane 0
-                j = (int)(e / (unsigned)g.NX);
-                i = (int)(e % (unsigned)g.NX);
-            } else {
-                e -= fg.full_lo ? plane_nodes : 0u;
-                if (fg.full_hi && e < plane_nodes) {
-                    lk = g.NZ - 1 - g.k0;
-                    j = (int)(e / (unsigned)g.NX);
-                    i = (int)(e % (unsigned)g.NX);
-                } else {
-                    e -= fg.full_hi ? plane_nodes : 0u;
-                    lk = fg.lkb + (int)(e / (unsigned)fg.ring);
-                    const int t = (int)(e % (unsigned)fg.ring);
-                    if (t < g.NX) { j = 0; i = t; }
-                    else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
-                    else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }      // (ring = 2 NX with xface: never here)
-                }
-            }
-            const int kg = g.k0 + lk;
-            const long long idx = (long long)lk * g.PP + (long long)j * g.PX + i;
-            double dval;
-            const bool dir = a.mask_dirichlet && pg_dirichlet(g, i, j, kg, &dval);
-            double pc[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) pc[c] = a.in[c * a.stride + idx];
-            // All 15 neighbours are loaded unconditionally (45 loads in flight instead of 15 dependent round trips): an
-            // offset that leaves the grid still lands inside the allocation (ghost planes / guards / row pads, all zero
-            // or finite neighbour data) and meets a class weight that is exactly 0.
-            double s[3] = {0.0, 0.0, 0.0};
-            double nv[PG_NOFF15][3];
-#pragma unroll
-            for (int q = 0; q < PG_NOFF15; ++q) {
-                const int o = pg_off15(q);
-                const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
-                const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) nv[q][c] = a.in[c * a.stride + nb];
-            }
-            if (!dir) {
-                const int cls = pg_axis_class(i, g.NX) + 3 * pg_axis_class(j, g.NY) + 9 * pg_axis_class(kg, g.NZ);
-                const double* wtab = &sTab[cls * PG_NOFF15 * 9];
-#pragma unroll
-                for (int q = 0; q < PG_NOFF15; ++q) {
-                    const double* blk = wtab + q * 9;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) s[r] += blk[r * 3] * nv[q][0] + blk[r * 3 + 1] * nv[q][1] + blk[r * 3 + 2] * nv[q][2];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                a.out[c * a.stride + idx] = s[c];
-                acc += pc[c] * s[c];
-            }
-        }
+        acc = el_boundary_role(a, w.faces, fg, bidx, sTab, sMask);
     } else {
         // ---- interior nodes: z-marching ------------------------------------------------------------------------
         const int lane = threadIdx.x & 63;
@@ -517,8 +528,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const double* src = a.in + c * a.stride + base + (long long)r * g.PX;
-                        // rows 2 .. RY-1 of the inner waves are read by nobody else (rows 1 / RY of the edge waves: by the y-neighbour workgroup)
-                        P[r][c] = (fg.nt & 2) ? __builtin_nontemporal_load(src) : *src;
+                        P[r][c] = *src;
                     }
                 if (lo_global) {                              // wave-uniform
 #pragma unroll
@@ -662,7 +672,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             double* dst = a.out + c * a.stride + obase + (long long)r * g.PX;
-                            if (fg.nt & 1) __builtin_nontemporal_store(y[c], dst);      // the output is not read again by this launch
+                            if constexpr (NTS) __builtin_nontemporal_store(y[c], dst);      // the output is not read again by this launch
                             else *dst = y[c];
                             acc += P0[r][c] * y[c];
                         }
@@ -707,6 +717,310 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                 load_plane(lkf, PA);
                 load_plane(lkf - 1, PB);
                 zface_hi(lkf, PA, PB);
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same marching scheme with TWO adjacent nodes per lane (16-byte loads and stores).  tools/marchbw.hip moves the bare access pattern of
+// the one-node kernel (8 B per lane, 512-B segments, 62-node tiles) at 3.8 TB/s — what k_el_fast reaches — and the two-node pattern with
+// non-temporal 16-byte stores at 5.6-5.9 TB/s.  A lane holds the nodes a = i, b = i + 1 (i even: 16-byte aligned) of every held row as
+// double2; lanes 0 and 63 are x-halo lanes, a wave owns 124 columns.  x-shifts: node a takes U from b of the same lane and Lw from b of the
+// lane below; node b takes U from a of the lane above and Lw from a of the same lane: 6 DPP pairs per two nodes.  Everything else — plane
+// rotation by name, y hand-off through LDS, faces, weights — is k_el_fast's, per node.  x-faces must be folded in (faces bit 0).
+struct ElV3 { double v[3]; };
+__device__ __forceinline__ ElV3 el_node(const double2 (*P)[3], int r, int n) {
+    ElV3 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o.v[c] = n ? P[r][c].y : P[r][c].x;
+    return o;
+}
+__device__ __forceinline__ ElV3 el_add(const ElV3& p, const ElV3& q) { return ElV3{{p.v[0] + q.v[0], p.v[1] + q.v[1], p.v[2] + q.v[2]}}; }
+__device__ __forceinline__ ElV3 el_sub(const ElV3& p, const ElV3& q) { return ElV3{{p.v[0] - q.v[0], p.v[1] - q.v[1], p.v[2] - q.v[2]}}; }
+
+// PF: a fourth plane buffer receives plane k+2 while plane k is computed (k_el_fast's scheme); without it three buffers rotate, a wave
+// requests plane k+2 into the buffer of plane k-1 as soon as that one is dead and waits for it at once — other waves cover the latency —
+// and the registers of one plane (36 with two nodes per lane and RY = 1) are free
+template <int RY, bool YX, bool ZF, bool PF, bool NTS>
+__global__ __launch_bounds__(256, 2) void k_el_fast2(ElArgs a, ElW18 wk, ElFastGeom fg) {
+    typedef double el_d2 __attribute__((ext_vector_type(2)));
+    const ElW36 w = el_expand_weights(wk);
+    __shared__ double sTab[2 * 4 * 2 * 3 * 128 + 32];         // boundary role: the class table (3645); marching: y hand-off block + face numbers
+    __shared__ unsigned sMask[27];
+    __shared__ double sRed[8];
+    constexpr int RH = RY + 2;
+    constexpr int GOFF = 2 * 4 * 2 * 3 * 128;
+    const GridDev& g = a.g;
+    double acc = 0.0;
+    const int bidx = fg.bnd_last ? ((int)blockIdx.x >= fg.nb_fast ? (int)blockIdx.x - fg.nb_fast : -1) : ((int)blockIdx.x < fg.nb_bnd ? (int)blockIdx.x : -1);
+    if (bidx >= 0) {
+        acc = el_boundary_role(a, w.faces, fg, bidx, sTab, sMask);
+    } else {
+        const int lane = threadIdx.x & 63;
+        int bm = fg.bnd_last ? (int)blockIdx.x : (int)blockIdx.x - fg.nb_bnd;
+        if ((fg.nb_fast & 7) == 0) bm = (bm & 7) * (fg.nb_fast >> 3) + (bm >> 3);
+        if (threadIdx.x < 27) sTab[GOFF + threadIdx.x] = fg.gf[threadIdx.x];
+        __syncthreads();
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        int xt, yt, zc;
+        if (YX) {
+            xt = bm % fg.ntx;
+            yt = ((bm / fg.ntx) % fg.nyg) * 4 + wv;
+            zc = fg.nzc - 1 - bm / (fg.ntx * fg.nyg);
+        } else {
+            const int wid = bm * 4 + wv;
+            xt = wid % fg.ntx;
+            yt = (wid / fg.ntx) % fg.nty;
+            zc = fg.nzc - 1 - wid / (fg.ntx * fg.nty);
+        }
+        const bool ghost_wave = YX && yt >= fg.nty;
+        if (ghost_wave) yt = fg.nty - 1;
+        const int ia = xt * 124 + 2 * lane - 2;               // node a of this lane (b = ia + 1); lanes 0 and 63: x-halo only
+        const int j0 = 1 + yt * RY;
+        const int lk0 = fg.lkb + zc * fg.zlen;
+        const int lk1 = min(lk0 + fg.zlen, fg.lke);
+        if (zc >= 0 && lk0 < lk1) {
+            const bool inner = lane >= 1 && lane <= 62;
+            const int in_[2] = {ia, ia + 1};
+            // per-lane node flags in ONE register (as separate masks and factors they cost 8 VGPRs + 8 SGPR pairs that this kernel does not have):
+            // bit n: node n is stored by interior rows; 2 + n: by face rows / planes (the x-ends are edges of the box); 4 + n: node n is the face
+            // x = 0; 6 + n: the face x = NX-1
+            int nflags = 0;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if (inner && in_[n] >= 0 && in_[n] <= g.NX - 1) nflags |= 1 << n;
+                if (inner && in_[n] >= 1 && in_[n] <= g.NX - 2) nflags |= 4 << n;
+                if (in_[n] == 0) nflags |= 16 << n;
+                if (in_[n] == g.NX - 1) nflags |= 64 << n;
+            }
+            const bool wave_has_face = xt == 0 || (xt + 1) * 124 > g.NX - 1;       // wave-uniform
+            const int rows_out = ghost_wave ? 0 : min(RY, g.NY - 1 - j0);
+            // addresses: rows are contiguous, so ia = -2 (first tile, lane 0) reads the pad of the row before — finite, never used; beyond
+            // the padded row the pair is clamped to the row's last pad pair
+            const long long col = (long long)(j0 - 1) * g.PX + (ia + 1 < g.PX ? ia : g.PX - 2);
+            double2 PA[RH][3], PB[RH][3], PC[RH][3], PD[PF ? RH : 1][3];
+            auto ld2 = [&](const double* p) __attribute__((always_inline)) { return *reinterpret_cast<const double2*>(p); };
+            auto load_plane = [&](int lk, double2 (*P)[3]) __attribute__((always_inline)) {
+                const long long base = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 0; r < RH; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[r][c] = ld2(a.in + c * a.stride + base + (long long)r * g.PX);
+            };
+            const bool lo_global = !YX || wv == 0;
+            const bool hi_global = !YX || wv == 3 || (yt + 1 >= fg.nty);
+            auto load_own = [&](int lk, double2 (*P)[3]) __attribute__((always_inline)) {
+                const long long base = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 1; r <= RY; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[r][c] = ld2(a.in + c * a.stride + base + (long long)r * g.PX);
+                if (lo_global) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[0][c] = ld2(a.in + c * a.stride + base);
+                }
+                if (hi_global) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[RH - 1][c] = ld2(a.in + c * a.stride + base + (long long)(RH - 1) * g.PX);
+                }
+            };
+            double2* sY = reinterpret_cast<double2*>(sTab);   // [2][4 waves][first | last own row][3][64] pairs
+            auto face_g = [&](int ax) __attribute__((always_inline)) {
+                int off = GOFF + 9 * ax;
+                asm volatile("" : "+v"(off));
+                return reinterpret_cast<const double (*)[3]>(sTab + off);
+            };
+            auto y_exchange = [&](int ybuf, double2 (*P)[3]) __attribute__((always_inline)) {
+                double2* mine = sY + ((ybuf * 4 + wv) * 2) * 192;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    mine[c * 64 + lane] = P[1][c];
+                    mine[192 + c * 64 + lane] = P[RY][c];
+                }
+                __syncthreads();
+                if (!lo_global) {
+                    const double2* below = sY + ((ybuf * 4 + wv - 1) * 2 + 1) * 192;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[0][c] = below[c * 64 + lane];
+                }
+                if (!hi_global) {
+                    const double2* above = sY + ((ybuf * 4 + wv + 1) * 2) * 192;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) P[RH - 1][c] = above[c * 64 + lane];
+                }
+            };
+            const bool yz = (w.faces & 2) != 0, zf = ZF && (w.faces & 4) != 0;
+            const bool ylo_wave = yz && !ghost_wave && yt == 0;
+            const int r_hi = (yz && !ghost_wave && yt == fg.nty - 1) ? g.NY - j0 : 0;
+            const bool zlo_chunk = zf && fg.full_lo && zc == 0, zhi_chunk = zf && fg.full_hi && lk1 == fg.lke;
+            // x-shifts of the two accumulated 3-vectors, then the stores (o = offset of node a; mask = which of the two nodes are stored)
+            auto finish = [&](long long o, const ElV3* c0, ElV3* y, const ElV3* U, const ElV3* Lw, int mshift, bool xfaces,
+                              const ElV3* corr) __attribute__((always_inline)) {
+                const bool m0 = (nflags >> mshift) & 1, m1 = (nflags >> (mshift + 1)) & 1;
+                double kup[2] = {1.0, 1.0}, klo[2] = {1.0, 1.0};
+                if (xfaces) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        klo[n] = (nflags & (16 << n)) ? 0.0 : 1.0;
+                        kup[n] = (nflags & (64 << n)) ? 0.0 : 1.0;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double up_a = U[1].v[c], lo_a = el_dpp_lower(Lw[1].v[c]);
+                    const double up_b = el_dpp_upper(U[0].v[c]), lo_b = Lw[0].v[c];
+                    if (xfaces) {
+                        // face nodes: in-face part halved + the antisymmetric remainder, no coupling across the face (factors, not selects:
+                        // the shifts must run with every lane active)
+                        const double fa = 0.5 * (kup[0] + klo[0]), ga = klo[0] - kup[0], fb = 0.5 * (kup[1] + klo[1]), gb = klo[1] - kup[1];
+                        y[0].v[c] = fa * y[0].v[c] + (kup[0] * up_a + klo[0] * lo_a) + ga * corr[0].v[c];
+                        y[1].v[c] = fb * y[1].v[c] + (kup[1] * up_b + klo[1] * lo_b) + gb * corr[1].v[c];
+                        if (a.mask_dirichlet) {
+                            if (nflags & 16) y[0].v[c] = 0.0;
+                            if (nflags & 32) y[1].v[c] = 0.0;
+                        }
+                    } else {
+                        y[0].v[c] += up_a + lo_a;
+                        y[1].v[c] += up_b + lo_b;
+                    }
+                }
+                if (m0 && m1) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const el_d2 t = {y[0].v[c], y[1].v[c]};
+                        if constexpr (NTS) __builtin_nontemporal_store(t, reinterpret_cast<el_d2*>(a.out + c * a.stride + o));      // not read again by this launch
+                        else *reinterpret_cast<el_d2*>(a.out + c * a.stride + o) = t;
+                        acc += c0[0].v[c] * y[0].v[c] + c0[1].v[c] * y[1].v[c];
+                    }
+                } else if (m0 || m1) {
+                    const int n = m0 ? 0 : 1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        a.out[c * a.stride + o + n] = n ? y[1].v[c] : y[0].v[c];
+                        acc += (n ? c0[1].v[c] * y[1].v[c] : c0[0].v[c] * y[0].v[c]);
+                    }
+                }
+            };
+            auto zface = [&](auto high, int lk, double2 (*P0)[3], double2 (*Pin)[3]) __attribute__((always_inline)) {
+                constexpr bool HIGH = decltype(high)::value;
+                const long long obase = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) {
+                    ElV3 y[2], U[2], Lw[2], c0[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        c0[n] = el_node(P0, r, n);
+                        const ElV3 e1p = el_node(P0, r + 1, n), e1m = el_node(P0, r - 1, n), n0 = el_node(Pin, r, n), n1 = el_node(Pin, HIGH ? r - 1 : r + 1, n);
+                        el_face_node<2, HIGH>(w, face_g(2), c0[n].v, e1p.v, e1m.v, n0.v, n1.v, y[n].v, U[n].v, Lw[n].v);
+                    }
+                    if (r <= rows_out) finish(obase + (long long)r * g.PX, c0, y, U, Lw, 2, false, nullptr);
+                }
+            };
+            auto step = [&](int lk, double2 (*Pm)[3], double2 (*P0)[3], double2 (*Pp)[3], double2 (*Pn)[3]) __attribute__((always_inline)) {
+                if (YX) {
+                    if (PF) load_own(min(lk + 2, lk1), Pn);
+                    if (lk > lk0) y_exchange((lk - lk0) & 1, Pp);
+                } else if (PF) {
+                    load_plane(min(lk + 2, lk1), Pn);
+                }
+                const long long obase = (long long)lk * g.PP + col;
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) {
+                    // the shifted parts of both nodes first, then the unshifted part node by node: fewer 3-vectors alive at once (two nodes per
+                    // lane leave little room next to the four plane buffers)
+                    ElV3 y[2], U[2], Lw[2], c0[2], corr[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        c0[n] = el_node(P0, r, n);
+                        U[n] = ElV3{{0.0, 0.0, 0.0}};
+                        el_sym6(w.ax[0], c0[n].v, U[n].v);
+                        Lw[n] = U[n];
+                        el_off3(w.dg[0], el_node(P0, r + 1, n).v, U[n].v);
+                        el_off3(w.dg[1], el_node(Pp, r, n).v, U[n].v);
+                        el_off3(w.dg[3], el_node(Pp, r + 1, n).v, U[n].v);
+                        el_off3(w.dg[0], el_node(P0, r - 1, n).v, Lw[n].v);
+                        el_off3(w.dg[1], el_node(Pm, r, n).v, Lw[n].v);
+                        el_off3(w.dg[3], el_node(Pm, r - 1, n).v, Lw[n].v);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        y[n] = ElV3{{0.0, 0.0, 0.0}};
+                        el_sym6(w.c, c0[n].v, y[n].v);
+                        el_sym6(w.ax[1], el_add(el_node(P0, r + 1, n), el_node(P0, r - 1, n)).v, y[n].v);
+                        el_sym6(w.ax[2], el_add(el_node(Pp, r, n), el_node(Pm, r, n)).v, y[n].v);
+                        el_off3(w.dg[2], el_add(el_node(Pp, r + 1, n), el_node(Pm, r - 1, n)).v, y[n].v);
+                        if (wave_has_face) {
+                            const double (*G0)[3] = face_g(0);
+                            corr[n] = ElV3{{0.0, 0.0, 0.0}};
+                            el_rem<0>(G0[0], 1.0, el_sub(el_node(P0, r + 1, n), el_node(P0, r - 1, n)).v, corr[n].v);
+                            el_rem<0>(G0[1], 1.0, el_sub(el_node(Pp, r, n), el_node(Pm, r, n)).v, corr[n].v);
+                            el_rem<0>(G0[2], 1.0, el_sub(el_node(Pp, r + 1, n), el_node(Pm, r - 1, n)).v, corr[n].v);
+                        }
+                    }
+                    if (r <= rows_out) finish(obase + (long long)r * g.PX, c0, y, U, Lw, 0, wave_has_face, corr);
+                }
+                if (ylo_wave) {
+                    ElV3 y[2], U[2], Lw[2], c0[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        c0[n] = el_node(P0, 0, n);
+                        el_face_node<1, false>(w, face_g(1), c0[n].v, el_node(Pp, 0, n).v, el_node(Pm, 0, n).v, el_node(P0, 1, n).v, el_node(Pp, 1, n).v,
+                                               y[n].v, U[n].v, Lw[n].v);
+                    }
+                    finish(obase, c0, y, U, Lw, 2, false, nullptr);
+                }
+                if (r_hi > 0) {
+#pragma unroll
+                    for (int r = 2; r < RH; ++r)
+                        if (r == r_hi) {
+                            ElV3 y[2], U[2], Lw[2], c0[2];
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) {
+                                c0[n] = el_node(P0, r, n);
+                                el_face_node<1, true>(w, face_g(1), c0[n].v, el_node(Pp, r, n).v, el_node(Pm, r, n).v, el_node(P0, r - 1, n).v,
+                                                      el_node(Pm, r - 1, n).v, y[n].v, U[n].v, Lw[n].v);
+                            }
+                            finish(obase + (long long)r * g.PX, c0, y, U, Lw, 2, false, nullptr);
+                        }
+                }
+                if (!PF && lk + 1 < lk1) {                    // plane lk-1 is dead: its buffer takes plane lk+2
+                    if (YX) load_own(lk + 2, Pm);
+                    else load_plane(lk + 2, Pm);
+                }
+            };
+            load_plane(lk0 - 1, PA);
+            load_plane(lk0, PB);
+            load_plane(lk0 + 1, PC);
+            if constexpr (ZF)
+                if (zlo_chunk) zface(std::false_type{}, lk0 - 1, PA, PB);
+            if constexpr (PF) {
+                for (int lk = lk0; lk < lk1; lk += 4) {
+                    step(lk, PA, PB, PC, PD);
+                    if (lk + 1 >= lk1) break;
+                    step(lk + 1, PB, PC, PD, PA);
+                    if (lk + 2 >= lk1) break;
+                    step(lk + 2, PC, PD, PA, PB);
+                    if (lk + 3 >= lk1) break;
+                    step(lk + 3, PD, PA, PB, PC);
+                }
+            } else {
+                for (int lk = lk0; lk < lk1; lk += 3) {
+                    step(lk, PA, PB, PC, PD);
+                    if (lk + 1 >= lk1) break;
+                    step(lk + 1, PB, PC, PA, PD);
+                    if (lk + 2 >= lk1) break;
+                    step(lk + 2, PC, PA, PB, PD);
+                }
+            }
+            if constexpr (ZF) if (zhi_chunk) {
+                int lkf = lk1;
+                asm volatile("" : "+s"(lkf));
+                load_plane(lkf, PA);
+                load_plane(lkf - 1, PB);
+                zface(std::true_type{}, lkf, PA, PB);
             }
         }
     }
@@ -1312,6 +1626,8 @@ void el_fast_geometry(ElSession* s) {
     const bool xface = s->w36.faces != 0;
     fg.xt = s->ctx->el_fast_xt == 48 ? 48 : 62;
     fg.ntx = (g.NX - (xface ? 1 : 2) + fg.xt - 1) / fg.xt;
+    fg.npl = (s->ctx->el_fast_npl == 2 && xface) ? 2 : 1;       // two nodes per lane: 124 owned columns per wave, the x-faces inside
+    if (fg.npl == 2) fg.ntx = (g.NX + 123) / 124;
     fg.nty = (g.NY - 2 + RY - 1) / RY;
     fg.nyg = (fg.nty + 3) / 4;
     const bool yx = s->ctx->el_fast_yx != 0;
@@ -1331,7 +1647,6 @@ void el_fast_geometry(ElSession* s) {
     }
     fg.nb_bnd = (int)std::min<long long>((fg.nbnd + 255) / 256, 2LL * s->ctx->num_cu);      // grid-stride: the 29 KB table is loaded per workgroup
     fg.bnd_last = s->ctx->el_bnd_last != 0 ? 1 : 0;
-    fg.nt = s->ctx->el_fast_nt & 3;
     // timing aid (results are wrong with it): 1 = marching part only, 2 = boundary pass only
     if (s->ctx->el_debug_part == 1) { fg.nb_bnd = 0; fg.nbnd = 0; }
     if (s->ctx->el_debug_part == 2) { fg.nb_fast = 0; fg.nzc = 0; }
@@ -1348,15 +1663,29 @@ int el_apply(ElSession* s, const ElArgs& a, int mode) {
         // planes to the class-table pass run the lean instantiation)
         const bool zf = (s->w36.faces & 4) != 0;
         auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w18, fg); };
-        if (s->fast_ry == 4) {
-            if (yx) { if (zf) launch(k_el_fast<4, true, true>); else launch(k_el_fast<4, true, false>); }
-            else { if (zf) launch(k_el_fast<4, false, true>); else launch(k_el_fast<4, false, false>); }
-        } else if (s->fast_ry == 2) {
-            if (yx) { if (zf) launch(k_el_fast<2, true, true>); else launch(k_el_fast<2, true, false>); }
-            else { if (zf) launch(k_el_fast<2, false, true>); else launch(k_el_fast<2, false, false>); }
+        // non-temporal stores where the vectors are HBM-resident (beyond 64 MiB per component set, the heat kernels' threshold): on cache-
+        // resident grids the next kernel finds q in L2 / MALL and the hint costs time
+        const bool nts = s->ctx->el_fast_nt < 0 ? (long long)s->stride * 3 * 8 > (64LL << 20) : (s->ctx->el_fast_nt & 1) != 0;
+        const int ry = s->fast_ry >= 2 ? 2 : 1;
+        const int key = (ry == 2 ? 8 : 0) | (yx ? 4 : 0) | (zf ? 2 : 0) | (nts ? 1 : 0);
+        if (fg.npl == 2) {
+            switch (key) {
+#define EL_CASE2(K, RYv, YXv, ZFv, NTv) case K: launch(k_el_fast2<RYv, YXv, ZFv, false, NTv>); break;
+                EL_CASE2(0, 1, false, false, false) EL_CASE2(1, 1, false, false, true) EL_CASE2(2, 1, false, true, false) EL_CASE2(3, 1, false, true, true)
+                EL_CASE2(4, 1, true, false, false) EL_CASE2(5, 1, true, false, true) EL_CASE2(6, 1, true, true, false) EL_CASE2(7, 1, true, true, true)
+                EL_CASE2(8, 2, false, false, false) EL_CASE2(9, 2, false, false, true) EL_CASE2(10, 2, false, true, false) EL_CASE2(11, 2, false, true, true)
+                EL_CASE2(12, 2, true, false, false) EL_CASE2(13, 2, true, false, true) EL_CASE2(14, 2, true, true, false) EL_CASE2(15, 2, true, true, true)
+#undef EL_CASE2
+            }
         } else {
-            if (yx) { if (zf) launch(k_el_fast<1, true, true>); else launch(k_el_fast<1, true, false>); }
-            else { if (zf) launch(k_el_fast<1, false, true>); else launch(k_el_fast<1, false, false>); }
+            switch (key) {
+#define EL_CASE1(K, RYv, YXv, ZFv, NTv) case K: launch(k_el_fast<RYv, YXv, ZFv, NTv>); break;
+                EL_CASE1(0, 1, false, false, false) EL_CASE1(1, 1, false, false, true) EL_CASE1(2, 1, false, true, false) EL_CASE1(3, 1, false, true, true)
+                EL_CASE1(4, 1, true, false, false) EL_CASE1(5, 1, true, false, true) EL_CASE1(6, 1, true, true, false) EL_CASE1(7, 1, true, true, true)
+                EL_CASE1(8, 2, false, false, false) EL_CASE1(9, 2, false, false, true) EL_CASE1(10, 2, false, true, false) EL_CASE1(11, 2, false, true, true)
+                EL_CASE1(12, 2, true, false, false) EL_CASE1(13, 2, true, false, true) EL_CASE1(14, 2, true, true, false) EL_CASE1(15, 2, true, true, true)
+#undef EL_CASE1
+            }
         }
         PG_HIP(s->ctx, hipGetLastError());
         s->last_apply_blocks = nb;
@@ -1476,7 +1805,7 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     PG_HIP(ctx, hipGetLastError());
     for (int q = 0; q < PG_NOFF15; ++q) fold_elasticity_block(grid->dim, h, s->lam, s->mu, 13, q, s->interior.w + q * 9);
     size_t npart = (size_t)s->nblk;
-    s->fast_ry = ctx->el_fast_ry == 4 ? 4 : (ctx->el_fast_ry == 2 ? 2 : 1);
+    s->fast_ry = ctx->el_fast_ry >= 2 ? 2 : 1;          // (4 rows per wave were measured, never faster, and are gone)
     s->fast = grid->dim == 3 && s->g.NX >= 3 && s->g.NY >= 3 && s->g.NZ >= 3 && el_fast_weights(s->interior.w, &s->w36);
     s->w36.faces = 0;
     if (s->fast && ctx->el_fast_xface) {

@@ -81,6 +81,41 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
     assert np.array_equal(outs[(1, 1, 2048, 1)], outs[(1, 1, 2048, 0)]) and np.array_equal(outs[(1, 2, 2048, 1)], outs[(1, 2, 2048, 0)])
 
 
+@pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((122, 4, 5), (2.0, 0.3, 0.2)), ((123, 3, 3), (2.0, 0.3, 0.2)), ((124, 2, 9), (1.0, 0.2, 0.5)),
+                                  ((125, 5, 3), (1.0, 0.2, 0.1)), ((2, 2, 2), (1.0, 1.0, 1.0)), ((20, 11, 8), (1.0, 0.5, 0.4)), ((9, 23, 6), (0.5, 1.0, 0.3)),
+                                  ((250, 8, 12), (1.0, 0.2, 0.3))])
+def test_two_nodes_per_lane_apply_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
+    """k_el_fast2 (two adjacent nodes per lane, 16-byte accesses, 124-node tiles): rows per wave 1 | 2, y hand-off on / off, faces folded
+    in or left to the class-table pass, non-temporal stores on / off (both kernels), one plane per z-chunk to the whole column, x-tiles ending at 123 / 124 / 125 / 126 nodes — against
+    the assembled matrix and, to round-off, against the one-node kernel"""
+    from pdegpu import _lib
+    E, nu = 210e9, 0.3
+    lam, mu = o.lame(E, nu)
+    c, cells = o.box_mesh(*Ls, *n)
+    K = o.assemble_elasticity(c, cells, lam, mu)
+    u = np.random.default_rng(12).uniform(-1, 1, (c.shape[0], 3))
+    ref = (K @ u.ravel()).reshape(-1, 3)
+    el = _lib.Elasticity()
+    el.E, el.nu = E, nu
+    g = _lib.make_grid(3, n, Ls)
+    keys = ("el_fast_npl", "el_fast_ry", "el_fast_waves", "el_fast_yx", "el_fast_yzface", "el_fast_nt")
+    try:
+        base = None
+        for cfg in ((1, 2, 4096, 1, 3, 0), (1, 2, 4096, 1, 3, 1), (1, 1, 1, 0, 1, 1), (2, 1, 4096, 1, 3, 0), (2, 2, 4096, 1, 3, 1), (2, 1, 1, 1, 3, 1),
+                    (2, 2, 100000, 0, 3, 0), (2, 1, 4096, 0, 1, 1), (2, 2, 4096, 1, 0, 0)):
+            for k, v in zip(keys, cfg):
+                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+            y = np.full_like(u, np.nan)
+            _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 0))
+            assert rel_err(y, ref) < 1e-12, cfg
+            if base is None:
+                base = y
+            assert rel_err(y, base) < 1e-13, cfg
+    finally:
+        for k, v in zip(keys, (1, 2, 4096, 1, 3, -1)):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
+
+
 @pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((37, 3, 2), (2.0, 0.3, 0.2)), ((16, 1, 1), (1.0, 0.1, 0.1))])
 def test_mfma_element_by_element_apply_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
     """v_mfma_f64_16x16x4_f64 element-by-element form (24x24 macro element, scatter by fp64 atomics) == matrix;

@@ -12,12 +12,10 @@ for n in ((256, 64, 64), (512, 128, 128), (500, 100, 100), (128, 128, 128)):
     g = L.make_grid(3, n, (1.0, 0.25, 0.25))
     res = {}
     for rnd in range(3):
-        for yz, xt in ((0, 62), (3, 62), (3, 48)):
-            for ry in (2, 1):
-                L.check(ctx, lib.pdegpu_set_tunable(ctx, b"el_fast_xt", xt))
-                L.check(ctx, lib.pdegpu_set_tunable(ctx, b"el_fast_yzface", yz))
-                L.check(ctx, lib.pdegpu_set_tunable(ctx, b"el_fast_ry", ry))
-                ms = C.c_double()
-                L.check(ctx, lib.pdegpu_elasticity_time_apply(ctx, g, el, 0, 30, C.byref(ms)))
-                res.setdefault((yz, xt, ry), []).append(ms.value * 1e3)
-    print(n, {f"yzface={k[0]} xt={k[1]} ry={k[2]}": round(float(np.median(v)), 1) for k, v in res.items()}, "us", flush=True)
+        for npl, pf, ry in ((1, 0, 2), (1, 1, 2), (1, 1, 1), (2, 0, 1), (2, 1, 1), (2, 1, 2)):
+            for k, v in (("el_fast_npl", npl), ("el_fast_nt", pf), ("el_fast_ry", ry)):
+                L.check(ctx, lib.pdegpu_set_tunable(ctx, k.encode(), v))
+            ms = C.c_double()
+            L.check(ctx, lib.pdegpu_elasticity_time_apply(ctx, g, el, 0, 30, C.byref(ms)))
+            res.setdefault((npl, pf, ry), []).append(ms.value * 1e3)
+    print(n, {f"nodes/lane={k[0]} nt-store={k[1]} ry={k[2]}": round(float(np.median(v)), 1) for k, v in res.items()}, "us", flush=True)

@@ -22,7 +22,7 @@ def run(**tun):
     lib.pdegpu_elasticity_solve(ctx, g, el, L.dptr(field), None, st)      # ends with 'not converged' by design: the statistics are filled
     d = st.as_dict()
     return d["cg_ms"] * 1e3 / max(1, d["cg_iterations"])
-variants = [dict(el_grid_mult=m, el_fast_yzface=3) for m in (1, 2, 3, 4)] + [dict(el_grid_mult=4, el_fast_yzface=0)]
+variants = [dict(el_grid_mult=4, el_fast_yzface=3, el_fast_nt=nt) for nt in (-1, 0, 1)] + [dict(el_grid_mult=4, el_fast_yzface=0, el_fast_nt=0)]
 res = {}
 for rnd in range(3):
     for k, v in enumerate(variants):
