@@ -1028,8 +1028,30 @@ __global__ __launch_bounds__(256, 2) void k_el_fast2(ElArgs a, ElW18 wk, ElFastG
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
+// 16-byte accesses of the flat PCG kernels; NT = non-temporal (compile-time: HBM-resident grids only — on config 5 each kernel reads what the
+// previous one left in L2 / MALL and the hint costs 3-5 us per iteration)
+typedef double el_dbl2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 el_ld2(const double* p) {
+    if constexpr (NT) {
+        const el_dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const el_dbl2*>(p));
+        return make_double2(t.x, t.y);
+    } else {
+        return *reinterpret_cast<const double2*>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void el_st2(double* p, const double2& v) {
+    if constexpr (NT) {
+        const el_dbl2 t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<el_dbl2*>(p));
+    } else {
+        *reinterpret_cast<double2*>(p) = v;
+    }
+}
+
 // r -= alpha q;  partial r.z (z = D^-1 r, not stored) and r.r     (use_alpha == 0: alpha = 0, the sums only)
-template <int D>
+template <int D, bool NT>
 __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restrict__ q, double* __restrict__ r, int use_alpha) {
     __shared__ double sRed[4];
     __shared__ double sDinv[27 * 3];
@@ -1074,12 +1096,12 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
         if (j >= g.NY) { j -= g.NY; ++lk; }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            double2 rv = *reinterpret_cast<double2*>(r + c * a.stride + idx);
+            double2 rv = el_ld2<NT>(r + c * a.stride + idx);
             if (use_alpha) {
-                const double2 qv = *reinterpret_cast<const double2*>(q + c * a.stride + idx);
+                const double2 qv = el_ld2<NT>(q + c * a.stride + idx);
                 rv.x -= alpha * qv.x;
                 rv.y -= alpha * qv.y;
-                *reinterpret_cast<double2*>(r + c * a.stride + idx) = rv;
+                el_st2<NT>(r + c * a.stride + idx, rv);
             }
             // z = D^-1 r is not stored: the p-update forms it again from r (one vector pass less per iteration)
             const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv.x, sDinv[cls1 * 3 + c] * rv.y);
@@ -1097,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
 
 // p_n = z_n + beta p_{n-1};  x += alpha_{n-1} p_{n-1}   over the owned planes AND the ghost planes inside the domain
 // (so that the block apply that follows finds p_n on the ghosts: z and p_{n-1} were exchanged before)
-template <int D>
+template <int D, bool NT>
 __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, long long total) {
     __shared__ double sRed2[8];
     __shared__ double sDinv[27 * 3];
@@ -1157,15 +1179,16 @@ __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, l
         if (j >= g.NY) { j -= g.NY; ++lk; }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const double2 po = *reinterpret_cast<const double2*>(a.p_old + c * a.stride + idx);
-            const double2 rv = *reinterpret_cast<const double2*>(a.in + c * a.stride + idx);
+            const double2 po = el_ld2<NT>(a.p_old + c * a.stride + idx);
+            const double2 rv = el_ld2<NT>(a.in + c * a.stride + idx);
             const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv.x, sDinv[cls1 * 3 + c] * rv.y);
+            // (p_n is read by the block apply that follows: a plain store even with NT)
             *reinterpret_cast<double2*>(a.p_new + c * a.stride + idx) = make_double2(zv.x + beta * po.x, zv.y + beta * po.y);
             if (alpha_prev != 0.0) {
-                double2 xv = *reinterpret_cast<double2*>(a.x + c * a.stride + idx);
+                double2 xv = el_ld2<NT>(a.x + c * a.stride + idx);
                 xv.x += alpha_prev * po.x;
                 xv.y += alpha_prev * po.y;
-                *reinterpret_cast<double2*>(a.x + c * a.stride + idx) = xv;
+                el_st2<NT>(a.x + c * a.stride + idx, xv);
             }
         }
     }
@@ -1654,6 +1677,11 @@ void el_fast_geometry(ElSession* s) {
     fg.gf = reinterpret_cast<const double*>(s->d_mask + 32);
 }
 
+// non-temporal hints where the vectors are HBM-resident (one component set beyond 64 MiB, the heat kernels' threshold); el_fast_nt = 0 | 1 forces
+bool el_vec_nt(const ElSession* s) {
+    return s->ctx->el_fast_nt < 0 ? (long long)s->stride * 3 * 8 > (64LL << 20) : (s->ctx->el_fast_nt & 1) != 0;
+}
+
 int el_apply(ElSession* s, const ElArgs& a, int mode) {
     if (mode == APPLY_PLAIN && s->fast && s->ctx->el_fast) {
         const ElFastGeom& fg = s->fgeom;
@@ -1665,7 +1693,7 @@ int el_apply(ElSession* s, const ElArgs& a, int mode) {
         auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s->ctx->stream, a, s->w18, fg); };
         // non-temporal stores where the vectors are HBM-resident (beyond 64 MiB per component set, the heat kernels' threshold): on cache-
         // resident grids the next kernel finds q in L2 / MALL and the hint costs time
-        const bool nts = s->ctx->el_fast_nt < 0 ? (long long)s->stride * 3 * 8 > (64LL << 20) : (s->ctx->el_fast_nt & 1) != 0;
+        const bool nts = el_vec_nt(s);
         const int ry = s->fast_ry >= 2 ? 2 : 1;
         const int key = (ry == 2 ? 8 : 0) | (yx ? 4 : 0) | (zf ? 2 : 0) | (nts ? 1 : 0);
         if (fg.npl == 2) {
@@ -1707,8 +1735,12 @@ int el_k2(ElSession* s, int use_alpha, ElLazy* lazy = nullptr) {
         a.din_n = s->last_apply_blocks;
         a.s_rz = lazy->cur;
     }
-    if (s->D == 3) hipLaunchKernelGGL(k_el_k2<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, use_alpha);
-    else hipLaunchKernelGGL(k_el_k2<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, use_alpha);
+    if (s->D == 3) {
+        if (el_vec_nt(s)) hipLaunchKernelGGL((k_el_k2<3, true>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, use_alpha);
+        else hipLaunchKernelGGL((k_el_k2<3, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, use_alpha);
+    } else {
+        hipLaunchKernelGGL((k_el_k2<2, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, use_alpha);
+    }
     PG_HIP(s->ctx, hipGetLastError());
     if (lazy) {
         lazy->pend = true;
@@ -1752,8 +1784,12 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
     }
     const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
     const long long first = -(long long)lo * s->g.PP, total = (long long)(s->g.nkl + lo + hi) * s->g.PP;
-    if (s->D == 3) hipLaunchKernelGGL(k_el_pupdate<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
-    else hipLaunchKernelGGL(k_el_pupdate<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
+    if (s->D == 3) {
+        if (el_vec_nt(s)) hipLaunchKernelGGL((k_el_pupdate<3, true>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
+        else hipLaunchKernelGGL((k_el_pupdate<3, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
+    } else {
+        hipLaunchKernelGGL((k_el_pupdate<2, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
+    }
     PG_HIP(s->ctx, hipGetLastError());
     s->pcur ^= 1;
     ElArgs b = s->args();

@@ -48,17 +48,34 @@ __global__ __launch_bounds__(256) void k_set_bc(GridDev g, double* __restrict__ 
 }
 
 // r -= alpha q, partial r.r      (n2 = number of double2 elements)
+// NT: non-temporal loads and stores (HBM-resident vectors: tools/membw.hip, in-place axpy with 2 workgroups per CU 5.6 -> 6.3 TB/s).  A
+// compile-time choice: behind a runtime switch the compiler merges the two forms and drops the hint.
+typedef double vk_d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
 __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
                                              double* scal, double* __restrict__ partials, unsigned* counter, DotIn di) {
     __shared__ double sRed[4];
     const double alpha = cg_alpha_in(di, scal, sRed);
     double acc = 0.0;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long long)gridDim.x * 256) {
-        double2 rv = r[e];
-        const double2 qv = q[e];
+        double2 rv, qv;
+        if constexpr (NT) {
+            const vk_d2 a = __builtin_nontemporal_load(reinterpret_cast<const vk_d2*>(r + e));
+            const vk_d2 b = __builtin_nontemporal_load(reinterpret_cast<const vk_d2*>(q + e));
+            rv = make_double2(a.x, a.y);
+            qv = make_double2(b.x, b.y);
+        } else {
+            rv = r[e];
+            qv = q[e];
+        }
         rv.x -= alpha * qv.x;
         rv.y -= alpha * qv.y;
-        r[e] = rv;
+        if constexpr (NT) {
+            const vk_d2 o = {rv.x, rv.y};
+            __builtin_nontemporal_store(o, reinterpret_cast<vk_d2*>(r + e));
+        } else {
+            r[e] = rv;
+        }
         acc += rv.x * rv.x + rv.y * rv.y;
     }
     const double tot = block_sum_256(acc, sRed);
@@ -194,8 +211,11 @@ int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double
     if (nbl > (long long)ctx->k2_grid_mult * ctx->num_cu) nbl = (long long)ctx->k2_grid_mult * ctx->num_cu;
     const int nb = nbl < 1 ? 1 : (int)nbl;
     if (li) { li->grid = nb; li->block = 256; }
-    hipLaunchKernelGGL(k_k2, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                       reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
+    const bool nt = ctx->fast_nt < 0 ? n2 * 16 > (64LL << 20) : (ctx->fast_nt & 3) == 3;      // the marching kernels' policy
+    if (nt) hipLaunchKernelGGL(k_k2<true>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                               reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
+    else hipLaunchKernelGGL(k_k2<false>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
+                            reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

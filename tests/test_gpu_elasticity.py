@@ -295,7 +295,8 @@ def test_lazy_dot_products_are_bitwise_the_eager_ones(lib, gpu_ctx, dim):
 
 def test_row_and_kernel_variants_agree(lib, gpu_ctx):
     """3-D PCG with the marching block apply at 1 | 2 rows per column, with / without the LDS y-hand-off, with the
-    thread-per-node kernels, eager dot products: the same solution to solver tolerance (partial sums are grouped differently)"""
+    thread-per-node kernels, eager dot products, non-temporal hints in the apply and the flat kernels, two nodes per lane, faces folded in or
+    not: the same solution to solver tolerance (partial sums are grouped differently)"""
     from pdegpu import elasticity, _lib
     def tun(**kw):
         for k, v in kw.items():
@@ -304,12 +305,13 @@ def test_row_and_kernel_variants_agree(lib, gpu_ctx):
     try:
         for cfg in (dict(el_fast=1, el_fast_ry=2, el_fast_yx=1), dict(el_fast=1, el_fast_ry=1, el_fast_yx=1), dict(el_fast=1, el_fast_ry=2, el_fast_yx=0),
                     dict(el_fast=0), dict(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=0), dict(el_grid_mult=1), dict(el_grid_mult=16, el_fast_waves=300),
-                    dict(el_fast_ry=4, el_fast_yx=1), dict(el_fast_ry=4, el_fast_yx=0), dict(el_fast_xface=0), dict(el_fast_xface=0, el_fast_ry=1)):
+                    dict(el_fast_ry=4, el_fast_yx=1), dict(el_fast_ry=4, el_fast_yx=0), dict(el_fast_xface=0), dict(el_fast_xface=0, el_fast_ry=1),
+                    dict(el_fast_nt=1), dict(el_fast_nt=1, el_fast_npl=2, el_fast_ry=1), dict(el_fast_yzface=1), dict(el_fast_yzface=0, el_fast_nt=0)):
             tun(**cfg)
             outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress",
                                                                rtol=1e-12))
     finally:
-        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=4096, el_fast_xface=1)
+        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=4096, el_fast_xface=1, el_fast_nt=-1, el_fast_npl=1, el_fast_yzface=3)
     ref = o.solve_elasticity_3d(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress")
     for f in outs:
         assert rel_err(f.values, ref.values) < TOL
