@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                     RHS[r] = make_double2(sa * a.rhs_const, sb * a.rhs_const);      // (a constant load is halved on an x-face)
                     if (a.rhs) {                                   // kernel-uniform; the load itself is unconditional (see value_row)
                         const bool ok = j <= fg.jmax && lane_ok;
-                        RHS[r] = load_pair(a.rhs, ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0);
+                        RHS[r] = load_pair_x<NT>(a.rhs + (ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0));      // read once: streaming hint
                     }
                 }
             }
