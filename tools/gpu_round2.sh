@@ -20,10 +20,12 @@ B="python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras"
 (cd /tmp && PDEGPU_PERSIST2D=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c25/stats -- python3 $R/tools/c2_prof.py > $R/gpurun_out/r2p/prof_c25.log 2>&1); echo "c25 stats exit $?"
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2p/stats -- python3 $R/tools/c2_prof.py > $R/gpurun_out/r2p/prof_c2p.log 2>&1); echo "c2 persistent stats exit $?"
 timeout -k 10 300 tools/build/membw > gpurun_out/r2p/membw.log 2>&1; echo "membw exit $?"
+timeout -k 10 200 tools/build/marchbw > gpurun_out/r2p/marchbw.log 2>&1; echo "marchbw exit $?"
 timeout -k 10 300 python tools/slab_surrogate.py gpurun_out/r2p/slab_surrogate.json > gpurun_out/r2p/surrogate.log 2>&1; echo "surrogate exit $?"
 timeout -k 10 200 python tools/c2_persist.py 40 > gpurun_out/r2p/c2_persist.log 2>&1; echo "c2_persist exit $?"
 timeout -k 10 200 python tools/hybrid_bench.py 512 > gpurun_out/r2p/hybrid.log 2>&1; echo "hybrid exit $?"
 timeout -k 10 200 python tools/r2_exp12.py > gpurun_out/r2p/exp12.log 2>&1; echo "exp12 exit $?"
 timeout -k 10 300 python tools/r2_exp13.py > gpurun_out/r2p/exp13.log 2>&1; echo "exp13 exit $?"
+timeout -k 10 300 python tools/r2_exp13.py 512 128 128 >> gpurun_out/r2p/exp13.log 2>&1; echo "exp13 large exit $?"
 find gpurun_out/prof gpurun_out/prof_el gpurun_out/prof_c25 gpurun_out/prof_c2p -size +8M -delete 2>/dev/null
 find gpurun_out/prof* -name "*kernel_stats.csv" | head
