@@ -1149,7 +1149,13 @@ int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo*
     const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
     a.nt_in = (mode != APPLY_CG_K1 && hbm) ? ctx->fast_nt_in : 0;
     if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
-    const int ry = mode_cfg(ctx, mode).ry;
+    int ry = mode_cfg(ctx, mode).ry;
+    // planes so wide that ONE z-chunk of 2-row tiles already is four workgroups per CU (1024^3: 1024 workgroups): the stencil-K2 takes 4 rows
+    // per thread — back to two long-lived workgroups per CU (measured at 1024^3: K2 5.02 -> 4.34 ms; K1 within 2 % either way, left alone)
+    if (mode == APPLY_CG_K2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && a.npt == 7 && a.g.dim == 3 && !a.g.flat2d) {
+        const long long wgx = ((a.g.NX - 2 + 127) / 128 + 3) / 4, wgy = (a.g.NY - 2 + 1) / 2;
+        if (wgx * wgy >= 4LL * ctx->num_cu) ry = 4;
+    }
     if (a.npt == 7) {
         if (ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
         if (ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);

@@ -310,3 +310,31 @@ def test_random_mid_grids_fast_paths_match_the_oracle(lib, gpu_ctx):
         paths.append(got.meta["solver_path"])
         assert rel(got.values, ref.values) < 1e-9, (case, dim, n, got.meta["solver_path"])
     assert paths.count("fast") >= 12 and "fast+boundary" in paths and "general" not in paths
+
+
+def test_wide_planes_take_four_rows_per_thread_in_k2_and_agree(lib, gpu_ctx):
+    """planes of 1025 x 1025 nodes: one z-chunk of 2-row tiles already is four workgroups per CU, so the stencil-K2 switches to 4 rows per
+    thread by itself (stencil_fast); forcing 2 rows must give the same solve — same iteration count, fields to round-off — and the field must
+    satisfy its equation (independent residual through the bare operator)"""
+    from pdegpu import heat, _lib
+    kw = dict(Lx=1.0, Ly=1.0, Lz=0.01, nx=1024, ny=1024, nz=6, diffusivity=1.0, T_boundary=0.0, T_initial=0.0, dt=0.01, num_steps=1,
+              source_type="constant", source_value=3.0, steady=True)
+    a = heat._solve_heat_3d_raw(**kw, rtol=1e-10)
+    _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"fast_cfg_k2", 2 + 16 * 2 + 256))
+    try:
+        b = heat._solve_heat_3d_raw(**kw, rtol=1e-10)
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"fast_cfg_k2", -1))
+    assert a.meta["solver_path"] == "fast" and a.meta["cg_iterations"] == b.meta["cg_iterations"] > 0
+    assert np.abs(a.values - b.values).max() <= 1e-9 * np.abs(a.values).max()
+    # K u = f m on the free nodes: residual through the unmasked operator, load from the same call
+    g = _lib.make_grid(3, (1024, 1024, 6), (1.0, 1.0, 0.01))
+    u = np.ascontiguousarray(a.values[0])
+    y = np.empty_like(u)
+    load = np.empty_like(u)
+    _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, g, 0.0, 1.0, _lib.dptr(u), _lib.dptr(y), _lib.dptr(load), 0))
+    free = np.zeros((7, 1025, 1025), bool)
+    free[1:-1, 1:-1, 1:-1] = True
+    free = free.ravel()
+    r = 3.0 * load[free] - y[free]
+    assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(3.0 * load[free])
