@@ -284,7 +284,7 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
 bool k2_is_stencil(const pdegpu_session* s) {
     const bool whole = s->g.k0 == 0 && s->g.nkl == s->g.NZ;
     const bool hyb_ok = s->ctx->hybrid_k2 && s->ctx->hybrid_fx && !s->weighted && whole;
-    return s->fast && (!s->hybrid || hyb_ok) && s->ctx->cg_variant == 1 && s->npt == 7;
+    return s->fast && (!s->hybrid || hyb_ok) && ((s->ctx->cg_variant == 1 && s->npt == 7) || (s->ctx->cg_variant == 2 && (s->npt == 7 || s->npt == 15)));
 }
 
 // lk_lo < lk_hi: one part of a split K1 (marching sessions only) — the launch covers the local planes [lk_lo, lk_hi), appends its
