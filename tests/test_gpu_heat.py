@@ -688,7 +688,7 @@ def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, ca
 @pytest.mark.parametrize("setting", [dict(fast_ry=1), dict(fast_ry=2), dict(fast_ry=4), dict(fast_ry=8), dict(fast_nt=0), dict(fast_nt=3), dict(fast_ex=0),
                                      dict(fast_wg_per_cu=2), dict(fast_wg_per_cu=6), dict(fast_wg_per_cu_k2=3), dict(grid_mult=2), dict(k2_grid_mult=8),
                                      dict(extrapolate=0), dict(hybrid_bc=0), dict(hybrid_fx=0), dict(hybrid_k2=0), dict(fast_minlen=4), dict(fast_small_mult=4),
-                                     dict(cg_variant=0), dict(cg_variant=0, fast_ex=0, fast_ry=4), dict(fast_ex_all=1), dict(fast_pf=1),
+                                     dict(cg_variant=0), dict(cg_variant=2), dict(cg_variant=0, fast_ex=0, fast_ry=4), dict(fast_ex_all=1), dict(fast_pf=1),
                                      dict(fast_ex_all=1, fast_pf=1, fast_ry=4), dict(fast_zlen=3), dict(tile3d_max_nodes=0),
                                      # per-mode configuration words: ry + 16 wg + 256 ex + 512 pf
                                      dict(fast_cfg_plain=4 + 16 * 2 + 512, fast_cfg_res=2 + 256 + 512, fast_cfg_k1=4 + 16 * 3 + 256, fast_cfg_k2=1 + 16 + 512)])
