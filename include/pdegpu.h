@@ -128,7 +128,7 @@ const char* pdegpu_version(void);
  * launch instead of a separate one-workgroup reduce launch; measured slower), "lazy_dot" (1 = the next
  * kernel's prologue sums the previous launch's partials, no reduce launches inside a single-slab CG chunk; same bits),
  * "direct_1d" (1 = 1-D grids use the Thomas recurrence inside one launch, 0 = CG), "el_fast" (1 = 3-D elasticity
- * z-marching block stencil), "el_fast_ry" (1|2 rows per column), "el_fast_waves" (wavefront target of the marching part),
+ * z-marching block stencil), "el_fast_ry" (1|2 rows per column), "el_fast_waves" (wavefront target of the marching part; 0 = 4096, 8192 on HBM-resident grids),
  * "el_fast_yx" (1 = y-halo rows handed between the workgroup's waves through LDS), "hybrid_bc" (1 = 3-D grids with natural faces: marching kernel on the interior + class-table
  * kernel on the boundary nodes), "extrapolate" (1 = transient solves start CG from 2 u^n - u^{n-1}), "fast_minlen" /
  * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2",

@@ -53,7 +53,7 @@ struct pdegpu_ctx {
     int el_bnd_last = 0;        // k_el_fast: 1 = the boundary workgroups take the last block indices instead of the first
     int el_debug_part = 0;      // timing aid for tools/: 1 = k_el_fast launches its marching part only, 2 = its boundary workgroups only (wrong results)
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
-    int el_fast_waves = 4096;   // wavefronts the marching part aims for (sets the z-chunk length)
+    int el_fast_waves = 0;      // wavefronts the marching part aims for (sets the z-chunk length); 0 = 4096, 8192 on HBM-resident grids
     int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never
     int tile3d_plain = 1;       // tile sessions: the bare masked apply uses the tile form too
     int plane2d_ry = 4;         // rows per wavefront tile of k_plane2d (2 | 4 | 8)

@@ -61,7 +61,7 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
             assert rel_err(y, ref) < 1e-12, (fast, ry, waves, yx)
             outs[(fast, ry, waves, yx)] = y
     finally:
-        for k, v in (("el_fast", 1), ("el_fast_ry", 2), ("el_fast_waves", 4096), ("el_fast_yx", 1)):
+        for k, v in (("el_fast", 1), ("el_fast_ry", 2), ("el_fast_waves", 0), ("el_fast_yx", 1)):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
     # 48-node tiles (128-byte aligned, whole-line stores): same per-node arithmetic, different lanes
     try:
@@ -112,7 +112,7 @@ def test_two_nodes_per_lane_apply_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
                 base = y
             assert rel_err(y, base) < 1e-13, cfg
     finally:
-        for k, v in zip(keys, (1, 2, 4096, 1, 3, -1)):
+        for k, v in zip(keys, (1, 2, 0, 1, 3, -1)):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
 
 
@@ -311,7 +311,7 @@ def test_row_and_kernel_variants_agree(lib, gpu_ctx):
             outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress",
                                                                rtol=1e-12))
     finally:
-        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=4096, el_fast_xface=1, el_fast_nt=-1, el_fast_npl=1, el_fast_yzface=3)
+        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=0, el_fast_xface=1, el_fast_nt=-1, el_fast_npl=1, el_fast_yzface=3)
     ref = o.solve_elasticity_3d(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress")
     for f in outs:
         assert rel_err(f.values, ref.values) < TOL
