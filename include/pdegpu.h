@@ -119,7 +119,7 @@ const char* pdegpu_last_error(const pdegpu_ctx* ctx);
 int         pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen);
 const char* pdegpu_version(void);
 /* performance tunables of a context (also read from PDEGPU_<KEY> at pdegpu_create): "fast_ry" rows per thread of
- * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_ex" (1 = LDS hand-off of tile-edge values in the CG kernels), "fast_ex_all" (1 = also in the bare apply / residual pass), "fast_pf" (1 = the one-vector marching modes request plane k+2 before computing plane k), "fast_wg_per_cu" (0 = occupancy API),
+ * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_ex" (1 = LDS hand-off of tile-edge values in the CG kernels), "fast_ex_all" (1 = also in the bare apply / residual pass), "fast_pf" (deeper prefetch, plane k+2 requested before plane k is computed: -1 = bare apply / residual pass, 1 = every one-vector mode, 0 = off), "fast_wg_per_cu" (0 = occupancy API),
  * "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
  * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration, for the 7-point operator; 2 = for the 15-point operator of transient
  * runs as well (measured within 1 % of the stored-q form); 0 = K1 stores q, 72 B/DoF), "use_graph"

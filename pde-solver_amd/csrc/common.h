@@ -24,7 +24,7 @@ struct pdegpu_ctx {
                                 // instead of 2-lane global loads (measured: 1.65 -> 1.52 ms per 512^3 CG iteration)
     int fast_nt_in = 0;         // one-vector marching modes on HBM-resident grids: non-temporal loads of the input (1 inner rows, 2 all rows)
     int fast_ex_all = 0;        // 1: the bare apply / residual pass use the LDS edge hand-off too (default: CG kernels only)
-    int fast_pf = 0;            // 1: bare apply / residual / stencil K2 (7-point) request plane lk+2 before computing plane lk
+    int fast_pf = -1;           // deeper prefetch (plane k+2 requested before plane k is computed): -1 = bare apply / residual pass only, 1 = every one-vector mode, 0 = off
     // per-mode overrides of the marching kernels, index = ApplyMode (PLAIN, RESIDUAL, CG_K1, CG_K2); -1 = follow the global tunables.
     // value = ry + 16 * wg_per_cu + 256 * ex + 512 * pf  (ry in {1, 2, 4, 8}, wg_per_cu 0 = occupancy API)
     int fast_cfg[4] = {-1, -1, -1, -1};
@@ -251,7 +251,7 @@ struct CgGraph {
 };
 inline long long tunable_key(const pdegpu_ctx* c) {
     return (((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 128 + c->grid_mult) * 128 + c->k2_grid_mult) * 4 +
-            c->cg_variant) * 8 + c->fast_ex * 4 + c->fast_ex_all * 2 + c->fast_pf) * 1024 + c->fast_zlen +
+            c->cg_variant) * 8 + c->fast_ex * 4 + c->fast_ex_all * 2 + (c->fast_pf != 0)) * 1024 + (c->fast_pf < 0 ? 512 : 0) + c->fast_zlen +
            (((long long)c->fast_cfg[0] * 1031 + c->fast_cfg[1]) * 1031 + c->fast_cfg[2]) * 1031 + c->fast_cfg[3];
 }
 

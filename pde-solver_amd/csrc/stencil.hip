@@ -881,9 +881,8 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
-FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0, int slack8 = 0, int cover_hi = 0) {
+FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0, int slack8 = 0, int resident_cap = 0) {
     FastGeom fg{};
-    (void)cover_hi;
     fg.ntx = (g.NX - 1 + 127) / 128;
     fg.jbase = g.flat2d ? 0 : 1;
     fg.jmax = g.flat2d ? 0 : g.NY - 2;
@@ -928,6 +927,9 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     long long best = -1;
     if (slack8 && xy > 0) {
         direct_nzc = (int)((target + xy - 1) / xy);
+        // ... but never more workgroups than are resident at once (resident_cap = occupancy x CUs of this instantiation): 400^3 with the
+        // deeper prefetch (2 workgroups per CU resident) got 6 chunks = 600 workgroups and ran its last 88 as a second round (0.27 vs 0.19 ms)
+        if (resident_cap > 0 && (long long)xy * direct_nzc > resident_cap && direct_nzc > 1) direct_nzc = std::max(1, resident_cap / xy);
         if (direct_nzc > maxc) direct_nzc = maxc;
         if (direct_nzc < 1) direct_nzc = 1;
     }
@@ -957,7 +959,9 @@ ModeCfg mode_cfg(const pdegpu_ctx* ctx, int mode) {
     c.ry = ctx->fast_ry > 0 ? ctx->fast_ry : ((mode == APPLY_PLAIN || mode == APPLY_RESIDUAL) ? 4 : 2);
     c.wg = (mode == APPLY_CG_K2 && ctx->fast_wg_per_cu_k2 >= 1) ? ctx->fast_wg_per_cu_k2 : ctx->fast_wg_per_cu;
     c.ex = ctx->fast_ex && (mode == APPLY_CG_K1 || mode == APPLY_CG_K2 || ctx->fast_ex_all);
-    c.pf = ctx->fast_pf != 0 && mode != APPLY_CG_K1;
+    // deeper prefetch: on by default in the bare apply / residual pass (fast_pf = -1; 512^3 SpMV 0.382 -> 0.376 ms, 400^3 0.208 -> 0.195, 640^3
+    // 0.955 -> 0.910), 1 = also in the stencil-K2, 0 = nowhere
+    c.pf = ctx->fast_pf < 0 ? (mode == APPLY_PLAIN || mode == APPLY_RESIDUAL) : (ctx->fast_pf != 0 && mode != APPLY_CG_K1);
     const int v = ctx->fast_cfg[mode & 3];
     if (v >= 0) {
         c.ry = v & 15;
@@ -992,7 +996,7 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     int slack8 = 0;
     if (mc.wg >= 1 && mc.wg <= 16) wg_per_cu = mc.wg;
     else if (hbm) { wg_per_cu = 2; slack8 = 1; }
-    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, a.lk_lo, a.lk_hi, slack8);
+    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, a.lk_lo, a.lk_hi, slack8, occ[mode] * ctx->num_cu);
     const int G = fg.nxg * fg.nyg * fg.nzc;
     if (li) { li->grid = G; li->block = 256; }
     if (G == 0) return PDEGPU_OK;
