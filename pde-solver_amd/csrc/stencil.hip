@@ -887,7 +887,10 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     fg.jbase = g.flat2d ? 0 : 1;
     fg.jmax = g.flat2d ? 0 : g.NY - 2;
     fg.nty = (fg.jmax - fg.jbase + 1 + RY - 1) / RY;
-    fg.wxt = fg.ntx >= 4 ? 4 : (fg.ntx >= 2 ? 2 : 1);
+    // waves of a workgroup along x: as many (4, 2, 1) as divide the tile count — a workgroup column with idle waves wastes their slots for the
+    // whole march (577 nodes per row = 5 tiles: 4 + 1 left 3 of 8 waves idle, 52 instead of ~85 GDoF/s); the price of fewer x-adjacent waves
+    // is more tile-edge values from global memory instead of the LDS hand-off
+    fg.wxt = (fg.ntx % 4 == 0) ? 4 : ((fg.ntx % 2 == 0) ? 2 : 1);
     fg.wyt = 4 / fg.wxt;
     fg.nxg = (fg.ntx + fg.wxt - 1) / fg.wxt;
     fg.nyg = (fg.nty + fg.wyt - 1) / fg.wyt;
@@ -925,7 +928,11 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     // chunks that fill whole rounds beat one partly filled round.
     int nzc = 1;
     long long best = -1;
-    if (slack8 && xy > 0) {
+    // (a single chunk that overflows what is resident at once — 1024^3: 1024 workgroups on 768 slots, 897 nodes per row: 784 — leaves a thin
+    // second round marching the whole column: there the rounds x planes model below decides, with the resident capacity as its round size)
+    const bool overflow = resident_cap > 0 && xy > resident_cap;
+    if (overflow) target = resident_cap;
+    if (slack8 && xy > 0 && !overflow) {
         direct_nzc = (int)((target + xy - 1) / xy);
         // ... but never more workgroups than are resident at once (resident_cap = occupancy x CUs of this instantiation): 400^3 with the
         // deeper prefetch (2 workgroups per CU resident) got 6 chunks = 600 workgroups and ran its last 88 as a second round (0.27 vs 0.19 ms)
@@ -997,7 +1004,9 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     if (mc.wg >= 1 && mc.wg <= 16) wg_per_cu = mc.wg;
     else if (hbm) { wg_per_cu = 2; slack8 = 1; }
     FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, a.lk_lo, a.lk_hi, slack8, occ[mode] * ctx->num_cu);
-    const int G = fg.nxg * fg.nyg * fg.nzc;
+    // a multiple of 8 workgroups, so that the XCD-aware tile order of the kernel always applies (the surplus ones find zc >= nzc and idle;
+    // 701 nodes per row: 525 workgroups -> 528)
+    const int G = (fg.nxg * fg.nyg * fg.nzc + 7) / 8 * 8;
     if (li) { li->grid = G; li->block = 256; }
     if (G == 0) return PDEGPU_OK;
     switch (mode) {
@@ -1154,12 +1163,11 @@ int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo*
     a.nt_in = (mode != APPLY_CG_K1 && hbm) ? ctx->fast_nt_in : 0;
     if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
     int ry = mode_cfg(ctx, mode).ry;
-    // planes so wide that ONE z-chunk of 2-row tiles already is four workgroups per CU (1024^3: 1024 workgroups): the stencil-K2 takes 4 rows
-    // per thread — back to two long-lived workgroups per CU (measured at 1024^3: K2 5.02 -> 4.34 ms; K1 within 2 % either way, left alone)
-    if (mode == APPLY_CG_K2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && a.npt == 7 && a.g.dim == 3 && !a.g.flat2d) {
-        const long long wgx = ((a.g.NX - 2 + 127) / 128 + 3) / 4, wgy = (a.g.NY - 2 + 1) / 2;
-        if (wgx * wgy >= 4LL * ctx->num_cu) ry = 4;
-    }
+    // rows of seven or more 128-node tiles (more than 769 nodes): one z-chunk of 2-row tiles is then three or more workgroups per CU, and the
+    // stencil-K2 runs better with 4 rows per thread — fewer, longer-lived workgroups again (896^3: 3.96 -> 3.28 ms, 1024^3: 5.02 -> 4.34; five
+    // or six tiles per row: within the noise with the automatic chunking, left alone, as is K1)
+    if (mode == APPLY_CG_K2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && a.npt == 7 && a.g.dim == 3 && !a.g.flat2d &&
+        (a.g.NX - 1 + 127) / 128 >= 7) ry = 4;
     if (a.npt == 7) {
         if (ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
         if (ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);
