@@ -26,6 +26,8 @@
 #include "common.h"
 #include "dot_finish.h"
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
-FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int lk_lo = 0, int lk_hi = 0, int slack8 = 0, int resident_cap = 0) {
+FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int mode, int lk_lo = 0, int lk_hi = 0, int slack8 = 0, int resident_cap = 0) {
     FastGeom fg{};
     fg.ntx = (g.NX - 1 + 127) / 128;
     fg.jbase = g.flat2d ? 0 : 1;
@@ -905,10 +907,8 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     const int xy = fg.nxg * fg.nyg;
     // one resident round: (workgroups that fit per CU) x CUs, at least 8 planes per chunk
     int target = wg_per_cu * ctx->num_cu;
-    // slack8 (HBM-resident grids, launch_fast): the chunk count is set directly — as few z-chunks as give every CU its
-    // wg_per_cu workgroups — instead of by the rounds x planes model below, which prefers many short chunks as soon as they
-    // pack the rounds a little better (512^3: 9 chunks = 2304 workgroups, measured slower in K2 / SpMV and +8 % HBM traffic
-    // against 2 chunks = 512 workgroups: profiles/r02_pmc_by_geometry.txt)
+    // slack8 (HBM-resident grids, launch_fast): the chunk count is set directly by the fitted efficiency model further down instead of by
+    // the rounds x planes model of the cache-resident grids
     int direct_nzc = 0;
     // chunks of >= 8 planes keep the redundant two-plane prologue below 25 % when there is parallelism to spare; a grid too
     // small to fill the device is latency-bound on the serial march instead (every plane step is a dependent memory round
@@ -932,12 +932,40 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     // second round marching the whole column: there the rounds x planes model below decides, with the resident capacity as its round size)
     const bool overflow = resident_cap > 0 && xy > resident_cap;
     if (overflow) target = resident_cap;
-    if (slack8 && xy > 0 && !overflow) {
-        direct_nzc = (int)((target + xy - 1) / xy);
-        // ... but never more workgroups than are resident at once (resident_cap = occupancy x CUs of this instantiation): 400^3 with the
-        // deeper prefetch (2 workgroups per CU resident) got 6 chunks = 600 workgroups and ran its last 88 as a second round (0.27 vs 0.19 ms)
-        if (resident_cap > 0 && (long long)xy * direct_nzc > resident_cap && direct_nzc > 1) direct_nzc = std::max(1, resident_cap / xy);
-        if (direct_nzc > maxc) direct_nzc = maxc;
+    if (slack8 && xy > 0) {
+        // Chunk count of an HBM-resident grid, fitted to the z-chunk-count sweeps of 19 cube sizes (profiles/r02_exp16_chunk_count_sweep.log):
+        //  * one resident round of W = xy * c workgroups runs best with W just below 2 per CU (512^3: 2 x 256 = 512 -> K1 0.78 of the HBM
+        //    peak; W = 768 — three per CU, all resident — 0.64: more concurrent streams, not more bandwidth); below that it degrades like
+        //    W / 512 (K2 faster: 448 -> 0.82), and the stencil-K2 (fewer streams per workgroup) is as good with W just below 3 per CU;
+        //  * otherwise MANY chunks (W >> 512) that the dispatcher hands out as slots free up reach ~0.92 of the perfect fit, whatever the
+        //    exact count — where the registers allow exactly 2 workgroups per CU (bare apply with 4 rows and the deeper prefetch) the
+        //    rounds are real and W just below a multiple of 512 is best;
+        //  * what the old rule (as few chunks as give every CU 2 workgroups, then 1/8 slack) got wrong is everything in between: 768^3 ran
+        //    ONE chunk of 576 workgroups (0.56 of the peak; now 8 chunks, 0.72), 700^3 525 (0.49 -> 0.68), 448^3 3 x 224 (0.58 -> 0.70).
+        // Every chunk marches a two-plane prologue (useful = planes / (c * (zlen + 2))).
+        const double S1 = 2.0 * ctx->num_cu;
+        const bool k2 = (mode == APPLY_CG_K2);
+        const bool hard_rounds = resident_cap > 0 && resident_cap <= 2 * ctx->num_cu;
+        const long long pcap = stencil_max_partials(const_cast<pdegpu_ctx*>(ctx));
+        double best_eff = -1.0;
+        for (int c = 1; c <= maxc; ++c) {
+            const int zl = (planes + c - 1) / c;
+            if ((planes + zl - 1) / zl != c) continue;           // (this chunk length gives fewer chunks: already scored)
+            const double W = (double)xy * c;
+            if ((long long)xy * c > pcap && c > 1) break;
+            const double useful = (double)planes / ((double)c * (zl + 2));
+            double q;
+            if (W <= S1) q = k2 ? std::pow(W / S1, 1.5) : W / S1;
+            else if (k2 && W <= 1.5 * S1 && (resident_cap == 0 || W <= resident_cap)) q = 0.985 * W / (1.5 * S1);
+            else if (hard_rounds) q = 0.97 * W / (std::ceil(W / S1) * S1);
+            else q = 0.92 * W / (W + 0.5 * S1);                 // (tail: about half a round of workgroups short of a full device)
+            if (W > S1 && c > 1 && zl < 24 && planes >= 48) continue;      // (chunks this short pay more than the two planes: ramp-up per workgroup)
+            const double eff = q * useful;
+            if (eff > best_eff * 1.005) {                        // (ties: fewer, longer chunks)
+                best_eff = eff;
+                direct_nzc = c;
+            }
+        }
         if (direct_nzc < 1) direct_nzc = 1;
     }
     for (int c = 1; c <= maxc && direct_nzc == 0; ++c) {
@@ -997,23 +1025,46 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     }
     int wg_per_cu = occ[mode];
     const ModeCfg mc = mode_cfg(ctx, mode);
+    // residency cap (fast_occ_*): more resident workgroups than ~2 per CU mean more concurrent HBM streams, not more bandwidth (512^3 K1:
+    // 3 per CU 0.64 of the peak against 0.74 with 2, profiles/r02_exp16_chunk_count_sweep.log).  A dynamic LDS request the kernel never
+    // touches makes the hardware hold the rest back, so a launch of many short z-chunks is dispatched 2 (3, 4) per CU as slots free up.
+    int res_occ = occ[mode];
+    size_t dyn_lds = 0;
+    {
+        const int cap = ctx->fast_occ[mode & 3];
+        if (cap >= 2 && cap <= 4 && cap < res_occ) {
+            static const size_t kb[3] = {60, 48, 36};      // 160 KB of LDS per CU: floor(160 / 60) = 2, floor(160 / 48) = 3, floor(160 / 36) = 4
+            dyn_lds = kb[cap - 2] * 1024 - 1024;           // (the static arrays of the kernel stay below 1 KB)
+            res_occ = cap;
+        }
+    }
     // HBM-resident vectors (the same threshold as the non-temporal hints): two workgroups per CU, i.e. as few and as long z-chunks
     // as fill the device; fast_geom adds 1/8 of slack so that e.g. 3 x 192 tiles count as one round
     const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
     int slack8 = 0;
     if (mc.wg >= 1 && mc.wg <= 16) wg_per_cu = mc.wg;
     else if (hbm) { wg_per_cu = 2; slack8 = 1; }
-    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, a.lk_lo, a.lk_hi, slack8, occ[mode] * ctx->num_cu);
+    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, mode, a.lk_lo, a.lk_hi, slack8, res_occ * ctx->num_cu);
     // a multiple of 8 workgroups, so that the XCD-aware tile order of the kernel always applies (the surplus ones find zc >= nzc and idle;
     // 701 nodes per row: 525 workgroups -> 528)
     const int G = (fg.nxg * fg.nyg * fg.nzc + 7) / 8 * 8;
     if (li) { li->grid = G; li->block = 256; }
+    {   // PDEGPU_DEBUG_GEOM=1: the geometry of every new (mode, chunking) on stderr (tools/)
+        static const bool dbg = getenv("PDEGPU_DEBUG_GEOM") != nullptr;
+        static long long last[4] = {-1, -1, -1, -1};
+        const long long key = ((long long)fg.nxg * fg.nyg) * 100000 + fg.nzc * 1000LL + a.g.NX % 1000;
+        if (dbg && last[mode & 3] != key) {
+            last[mode & 3] = key;
+            fprintf(stderr, "[pdegpu geom] mode %d npt %d ry %d ex %d pf %d: %d x %d x %d nodes, xy %d x %d workgroups (%d x %d waves), %d chunks of %d planes, occ %d -> grid %d\n",
+                    mode, NPT, RY, EX, PF, a.g.NX, a.g.NY, a.g.nkl, fg.nxg, fg.nyg, fg.wxt, fg.wyt, fg.nzc, fg.zlen, occ[mode], G);
+        }
+    }
     if (G == 0) return PDEGPU_OK;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
+        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
+        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
