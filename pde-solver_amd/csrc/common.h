@@ -30,6 +30,7 @@ struct pdegpu_ctx {
     int fast_cfg[4] = {-1, -1, -1, -1};
     int fast_occ[4] = {0, 0, 0, 0};   // per mode: at most this many workgroups of a marching kernel resident per CU (2 | 3 | 4; enforced by a dynamic
                                 // LDS request of 60 / 48 / 36 KB per workgroup that the kernel never touches); 0 = whatever the registers allow
+    int fast_linear = 1;        // marching kernels: 1 = a workgroup takes four consecutive tiles of the row-major tile order (LDS edge hand-off at any tile count per row)
     int fast_zlen = 0;          // > 0: planes per z-chunk of the marching kernels (0 = chosen by fast_geom)
     int fast_minlen = 1;        // shortest z-chunk of the marching kernels on grids too small to fill the device
     int fast_small_mult = 1;    // such grids may launch this many resident rounds of workgroups
@@ -255,7 +256,7 @@ inline long long tunable_key(const pdegpu_ctx* c) {
     return (((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 128 + c->grid_mult) * 128 + c->k2_grid_mult) * 4 +
             c->cg_variant) * 8 + c->fast_ex * 4 + c->fast_ex_all * 2 + (c->fast_pf != 0)) * 1024 + (c->fast_pf < 0 ? 512 : 0) + c->fast_zlen +
            (((long long)c->fast_cfg[0] * 1031 + c->fast_cfg[1]) * 1031 + c->fast_cfg[2]) * 1031 + c->fast_cfg[3] +
-           (((long long)c->fast_occ[0] * 7 + c->fast_occ[1]) * 7 + c->fast_occ[2]) * 7 + c->fast_occ[3];
+           (((long long)c->fast_occ[0] * 7 + c->fast_occ[1]) * 7 + c->fast_occ[2]) * 7 + c->fast_occ[3] + 3001LL * c->fast_linear;
 }
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);

@@ -447,7 +447,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_nt_in", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_occ_plain", "fast_occ_res", "fast_occ_k1", "fast_occ_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_xt", "el_fast_npl", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_nt_in", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear", "fast_occ_plain", "fast_occ_res", "fast_occ_k1", "fast_occ_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_xt", "el_fast_npl", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -468,6 +468,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_cfg_res")) return &ctx->fast_cfg[APPLY_RESIDUAL];
     if (!strcmp(key, "fast_cfg_k1")) return &ctx->fast_cfg[APPLY_CG_K1];
     if (!strcmp(key, "fast_cfg_k2")) return &ctx->fast_cfg[APPLY_CG_K2];
+    if (!strcmp(key, "fast_linear")) return &ctx->fast_linear;
     if (!strcmp(key, "fast_occ_plain")) return &ctx->fast_occ[APPLY_PLAIN];
     if (!strcmp(key, "fast_occ_res")) return &ctx->fast_occ[APPLY_RESIDUAL];
     if (!strcmp(key, "fast_occ_k1")) return &ctx->fast_occ[APPLY_CG_K1];
@@ -994,13 +995,24 @@ extern "C" int pdegpu_session_rr(pdegpu_session* s, double* rr_out) {
     return PDEGPU_OK;
 }
 
+namespace {
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+}  // namespace
+
 extern "C" int pdegpu_session_time_apply(pdegpu_session* s, int reps, double* avg_ms_out) {
     if (!s || reps < 1 || !avg_ms_out) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;
     PG_HIP(ctx, hipSetDevice(ctx->device));
-    hipEvent_t e0, e1;
-    PG_HIP(ctx, hipEventCreate(&e0));
-    PG_HIP(ctx, hipEventCreate(&e1));
+    EventPair ev;
+    PG_HIP(ctx, hipEventCreate(&ev.a));
+    PG_HIP(ctx, hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     PG_TRY(op_plain(s, 0, s->r.v, 0.0, s->b.v, 1));          // warm-up
     PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < reps; ++i) PG_TRY(op_plain(s, 0, s->r.v, 0.0, s->b.v, 1));
@@ -1008,8 +1020,6 @@ extern "C" int pdegpu_session_time_apply(pdegpu_session* s, int reps, double* av
     PG_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0;
     PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *avg_ms_out = ms / reps;
     return PDEGPU_OK;
 }
@@ -1019,9 +1029,10 @@ extern "C" int pdegpu_session_membench(pdegpu_session* s, int which, int reps, d
     if (!s || reps < 1 || !avg_ms_out || which < 0 || which > 4) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;
     PG_HIP(ctx, hipSetDevice(ctx->device));
-    hipEvent_t e0, e1;
-    PG_HIP(ctx, hipEventCreate(&e0));
-    PG_HIP(ctx, hipEventCreate(&e1));
+    EventPair ev;
+    PG_HIP(ctx, hipEventCreate(&ev.a));
+    PG_HIP(ctx, hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     PG_TRY(vec_membench(ctx, s->g, which, s->r.v, s->q.v, s->b.v, s->d_part));
     PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < reps; ++i) PG_TRY(vec_membench(ctx, s->g, which, s->r.v, s->q.v, s->b.v, s->d_part));
@@ -1029,8 +1040,6 @@ extern "C" int pdegpu_session_membench(pdegpu_session* s, int which, int reps, d
     PG_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0;
     PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *avg_ms_out = ms / reps;
     PG_TRY(vec_zero(ctx, s->g, &s->b));        // b was the scratch target: restore "pads and unconstrained garbage are zero"
     return PDEGPU_OK;
@@ -1099,13 +1108,7 @@ int cg_solve(pdegpu_session* s, double bnorm2, double rr, double rtol, int max_i
     // consecutive solves of a session (time steps) need nearly the same number of iterations: the first poll of this solve is
     // placed at 85 % of the previous count, the remaining ones by the rate predictor
     int chunk = s->last_iters > 16 ? (int)(0.85 * s->last_iters) : 8;
-    struct Events {                // destroyed on every exit path (a failed iterate / rr returns through PG_TRY)
-        hipEvent_t a = nullptr, b = nullptr;
-        ~Events() {
-            if (a) (void)hipEventDestroy(a);
-            if (b) (void)hipEventDestroy(b);
-        }
-    } ev;
+    EventPair ev;                  // destroyed on every exit path (a failed iterate / rr returns through PG_TRY)
     PG_HIP(ctx, hipEventCreate(&ev.a));
     PG_HIP(ctx, hipEventCreate(&ev.b));
     hipEvent_t e0 = ev.a, e1 = ev.b;

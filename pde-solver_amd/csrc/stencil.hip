@@ -188,8 +188,9 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct FastGeom {
     int ntx, nty;          // 128-node x-tiles, RY-row y-tiles covering the interior
-    int wxt, wyt;          // waves of a workgroup along x / y (wxt*wyt == 4)
-    int nxg, nyg, nzc;     // workgroup counts along x, y; z-chunks
+    int wxt, wyt;          // waves of a workgroup along x / y (wxt*wyt == 4); linear: unused
+    int nxg, nyg, nzc;     // workgroup counts along x, y; z-chunks (linear: nxg = workgroups per z-chunk, nyg = 1)
+    int linear;            // 1: the waves of a z-chunk are numbered row by row (w = yt * ntx + xt) and a workgroup takes four consecutive ones
     int lkb, lke;          // local interior plane range [lkb, lke)
     int zlen;              // planes per z-chunk
     int jbase, jmax;       // first / last free row of the middle axis (1 .. NY-2; 0 .. 0 for the flat 2-D view)
@@ -255,13 +256,18 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     int wid = blockIdx.x;
     if ((G & 7) == 0) wid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int xg = wid % fg.nxg, yg = (wid / fg.nxg) % fg.nyg, zc = wid / (fg.nxg * fg.nyg);
-    const int xt = xg * fg.wxt + (wv % fg.wxt), yt = yg * fg.wyt + (wv / fg.wxt);
+    int xt = xg * fg.wxt + (wv % fg.wxt), yt = yg * fg.wyt + (wv / fg.wxt);
+    if (fg.linear) {                                         // four consecutive tiles of the row-major tile order, whatever the tile count per row
+        const int w = xg * 4 + wv;
+        xt = w % fg.ntx;
+        yt = w / fg.ntx;
+    }
     const int i0 = xt * 128 + 2 * lane;
     const int j0 = fg.jbase + yt * RY;
     const int lk0 = fg.lkb + zc * fg.zlen;
     const int lk1 = min(lk0 + fg.zlen, fg.lke);
     const bool active = (xt < fg.ntx) && (yt < fg.nty) && (lk0 < lk1);
-    const int wave_x = wv % fg.wxt;                          // position of this wave among the workgroup's x-adjacent tiles
+    const int wave_x = fg.linear ? wv : wv % fg.wxt;         // position of this wave among the workgroup's x-adjacent tiles
     int estep = 0;                                            // LDS edge-exchange counter (same in every wave of the workgroup)
 
     double acc = 0.0;
@@ -343,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         // every z-step that also drained the prefetch of the next plane (natural-face K2: 0.75 ms against 0.55 ms on a Dirichlet grid).
         const int il_t = xt * 128 - 1, ir_t = xt * 128 + 128;
         const bool cgvec_t = (K1 || K2) && !a.free_x;
-        const bool has_l_t = wave_x > 0, has_r_t = (wave_x < fg.wxt - 1) && (xt + 1 < fg.ntx);
+        // (linear: wave wv - 1 / wv + 1 of the workgroup holds the tile to the left / right unless this tile starts / ends its row)
+        const bool has_l_t = fg.linear ? (wv > 0 && xt > 0) : wave_x > 0;
+        const bool has_r_t = fg.linear ? (wv < 3 && xt + 1 < fg.ntx) : (wave_x < fg.wxt - 1) && (xt + 1 < fg.ntx);
         const bool gl_t = !has_l_t && il_t >= 0 && (il_t >= 1 || !cgvec_t) && active;
         const bool gr_t = !has_r_t && ir_t <= g.NX - 1 && (ir_t <= g.NX - 2 || !cgvec_t) && active;
         const bool need_ge = EX && __builtin_amdgcn_readfirstlane((int)(gl_t || gr_t)) != 0;      // wave-uniform
@@ -896,6 +904,14 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     fg.wyt = 4 / fg.wxt;
     fg.nxg = (fg.ntx + fg.wxt - 1) / fg.wxt;
     fg.nyg = (fg.nty + fg.wyt - 1) / fg.wyt;
+    // fast_linear (default): a workgroup takes four CONSECUTIVE tiles of the row-major tile order instead of a wxt x wyt block, so three of
+    // every four tile boundaries inside a row are handed over through LDS at ANY tile count per row (5 or 7 tiles: none before, 6: three of
+    // five); for 1, 2 and 4k tiles per row the two orders are the same workgroups
+    fg.linear = ctx->fast_linear != 0;
+    if (fg.linear) {
+        fg.nxg = (int)(((long long)fg.ntx * fg.nty + 3) / 4);
+        fg.nyg = 1;
+    }
     fg.lkb = g.k0 >= 1 ? 0 : 1 - g.k0;
     fg.lke = (g.NZ - 1 - g.k0) < g.nkl ? (g.NZ - 1 - g.k0) : g.nkl;
     if (lk_hi > lk_lo) {                       // plane-range launch (K1 split of the multi-GPU loop)
