@@ -1230,11 +1230,20 @@ int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo*
     a.nt_in = (mode != APPLY_CG_K1 && hbm) ? ctx->fast_nt_in : 0;
     if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
     int ry = mode_cfg(ctx, mode).ry;
-    // rows of seven or more 128-node tiles (more than 769 nodes): one z-chunk of 2-row tiles is then three or more workgroups per CU, and the
-    // stencil-K2 runs better with 4 rows per thread — fewer, longer-lived workgroups again (896^3: 3.96 -> 3.28 ms, 1024^3: 5.02 -> 4.34; five
-    // or six tiles per row: within the noise with the automatic chunking, left alone, as is K1)
-    if (mode == APPLY_CG_K2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && a.npt == 7 && a.g.dim == 3 && !a.g.flat2d &&
-        (a.g.NX - 1 + 127) / 128 >= 7) ry = 4;
+    // stencil-K2 with 4 rows per thread: only where that makes ONE resident round of (almost) exactly two workgroups per CU and 2 rows do not
+    // (1024^3: 8 tiles x 256 row tiles / 4 = 512 workgroups, K2 0.757 of the HBM peak against 0.644 with many chunks of 2-row tiles; at
+    // 832^3 / 896^3 / 960^3, where neither fits, 2 rows win by 2-10 % under the fitted chunk policy: profiles/r02_ab_k2_rows.log)
+    if (mode == APPLY_CG_K2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && a.npt == 7 && a.g.dim == 3 && !a.g.flat2d && hbm) {
+        const long long ntx = (a.g.NX - 1 + 127) / 128, rows = a.g.NY - 2;
+        const double S1 = 2.0 * ctx->num_cu;
+        auto fits = [&](int r) {
+            const long long xy = (ntx * ((rows + r - 1) / r) + 3) / 4;
+            for (int c = 1; c <= 8; ++c)
+                if ((double)xy * c <= S1 && (double)xy * c >= 0.97 * S1) return true;
+            return false;
+        };
+        if (!fits(2) && fits(4)) ry = 4;
+    }
     if (a.npt == 7) {
         if (ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
         if (ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);
