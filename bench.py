@@ -199,10 +199,10 @@ class Runner:
                 ceil = {}
                 for which, name, nvec in ((1, "read_1R", 1), (2, "write_1W", 1), (0, "copy_1R1W", 2), (3, "triad_2R1W", 3)):
                     mb = C.c_double()
-                    L.check(eng.ctx, eng.lib.pdegpu_session_membench(eng.s, which, 20, C.byref(mb)))
+                    L.check(eng.ctx, eng.lib.pdegpu_session_membench(eng.s, which, self.args.ceiling_reps, C.byref(mb)))
                     ceil[name] = nvec * vec_bytes / (mb.value * 1e-3) / 1e9
                 ms = C.c_double()
-                L.check(eng.ctx, eng.lib.pdegpu_session_time_apply(eng.s, 50, C.byref(ms)))
+                L.check(eng.ctx, eng.lib.pdegpu_session_time_apply(eng.s, max(50, 2 * self.args.ceiling_reps), C.byref(ms)))
                 res["ceilings"], res["spmv_ms"] = ceil, ms.value
             cg.start(0.0)
             cg.iterate(warmup)
@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--cells", type=int, default=512, help="cells per axis (BASELINE config 3: 512; config 4 uses 2*cells on the long axis)")
     ap.add_argument("--workload", choices=("config3", "config4"), default="config3")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="config3 only: per-GPU grid fixed (weak) or total grid fixed (strong)")
+    ap.add_argument("--ceiling-reps", type=int, default=20, help="launches per in-run streaming ceiling (the bare SpMV gets 50 or twice as many); they run "
+                    "BEFORE the CG warm-up (more of them do not change the CG timing: measured, no clock-ramp effect)")
     ap.add_argument("--no-extras", action="store_true", help="do not measure the other workloads after the main one")
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="seconds the extra legs may take before the main line is printed without them")
     ap.add_argument("--no-overlap", action="store_true", help="exchange halos before K1 instead of overlapping them with its bulk")
