@@ -146,6 +146,11 @@ const char* pdegpu_version(void);
  * "hybrid_k2" (1 = steady natural-face sessions on one slab use the 64 B/DoF form: K2 applies the operator again, marching + boundary launch).
  * Results do not depend on them beyond the solver tolerance. */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
+/* Host-only diagnostic (needs no GPU): launch geometry of the 7-point z-marching kernels for a single-slab 3-D grid of nx x ny x nz NODES on
+ * a device with num_cu compute units and resident_wg_per_cu resident workgroups of that kernel per CU (gfx950 build: PLAIN 2, K1 3, K2 4),
+ * default tunables.  mode: 0 bare apply, 1 residual, 2 CG K1, 3 CG K2.  out4 = {rows per thread, workgroups per z-chunk, z-chunks, planes per
+ * chunk}.  The chunk policy is fitted to measurements; tests pin the geometry of BASELINE's grids through this call. */
+int         pdegpu_marching_geometry(int num_cu, int nx_nodes, int ny_nodes, int nz_nodes, int mode, int resident_wg_per_cu, int32_t* out4);
 
 /* ---- heat: replaces mesh+FunctionSpace+DirichletBC+solve(a==L) of _solve_heat_{1,2,3}d_raw
  *      (:229-318, :369-447, :533-716).  Node order of every array: x fastest, then y, then z

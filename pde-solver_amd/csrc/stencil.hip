@@ -1224,17 +1224,15 @@ GridDev stencil_flat2d_view(const GridDev& g) {
     return v;
 }
 
-int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo* li) {
-    StencilArgs a = a_in;
-    const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
-    a.nt_in = (mode != APPLY_CG_K1 && hbm) ? ctx->fast_nt_in : 0;
-    if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
+// rows per thread of a marching launch (7- / 15-point operator; Q1 is fixed at 2)
+static int fast_rows(const pdegpu_ctx* ctx, const GridDev& g, int npt, int mode) {
+    const bool hbm = (long long)g.nkl * g.PP * 8 > (64LL << 20);
     int ry = mode_cfg(ctx, mode).ry;
     // stencil-K2 with 4 rows per thread: only where that makes ONE resident round of (almost) exactly two workgroups per CU and 2 rows do not
     // (1024^3: 8 tiles x 256 row tiles / 4 = 512 workgroups, K2 0.757 of the HBM peak against 0.644 with many chunks of 2-row tiles; at
     // 832^3 / 896^3 / 960^3, where neither fits, 2 rows win by 2-10 % under the fitted chunk policy: profiles/r02_ab_k2_rows.log)
-    if (mode == APPLY_CG_K2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && a.npt == 7 && a.g.dim == 3 && !a.g.flat2d && hbm) {
-        const long long ntx = (a.g.NX - 1 + 127) / 128, rows = a.g.NY - 2;
+    if (mode == APPLY_CG_K2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && npt == 7 && g.dim == 3 && !g.flat2d && hbm) {
+        const long long ntx = (g.NX - 1 + 127) / 128, rows = g.NY - 2;
         const double S1 = 2.0 * ctx->num_cu;
         auto fits = [&](int r) {
             const long long xy = (ntx * ((rows + r - 1) / r) + 3) / 4;
@@ -1244,6 +1242,15 @@ int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo*
         };
         if (!fits(2) && fits(4)) ry = 4;
     }
+    return ry;
+}
+
+int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo* li) {
+    StencilArgs a = a_in;
+    const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
+    a.nt_in = (mode != APPLY_CG_K1 && hbm) ? ctx->fast_nt_in : 0;
+    if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
+    const int ry = fast_rows(ctx, a.g, a.npt, mode);
     if (a.npt == 7) {
         if (ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
         if (ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);
@@ -1256,3 +1263,35 @@ int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo*
 }
 
 int stencil_max_partials(pdegpu_ctx* ctx) { return 64 * ctx->num_cu + 4096; }
+
+
+// Host-only (no GPU): the launch geometry the 7-point marching kernels of a 3-D single-slab grid would get on a device with num_cu compute
+// units, with the default tunables — what tests/ pin so that a change of the chunk policy cannot silently move the headline geometry.
+extern "C" int pdegpu_marching_geometry(int num_cu, int nx_nodes, int ny_nodes, int nz_nodes, int mode, int resident_wg_per_cu, int32_t* out4) {
+    if (!out4 || num_cu < 1 || nx_nodes < 3 || ny_nodes < 3 || nz_nodes < 3 || mode < 0 || mode > 3 || resident_wg_per_cu < 1) return PDEGPU_EINVAL;
+    pdegpu_ctx c;
+    c.num_cu = num_cu;
+    GridDev g{};
+    g.dim = 3;
+    g.NX = nx_nodes;
+    g.NY = ny_nodes;
+    g.NZ = nz_nodes;
+    g.PX = (nx_nodes + 15) / 16 * 16;
+    g.PP = (long long)g.PX * ny_nodes;
+    g.nkl = nz_nodes;
+    g.k0 = 0;
+    g.bc_mode = PDEGPU_BC_UNIFORM;
+    g.bc_present[0] = 1;
+    const int ry = fast_rows(&c, g, 7, mode);
+    const bool hbm = (long long)g.nkl * g.PP * 8 > (64LL << 20);
+    const ModeCfg mc = mode_cfg(&c, mode);
+    int wg = resident_wg_per_cu, slack8 = 0;
+    if (mc.wg >= 1 && mc.wg <= 16) wg = mc.wg;
+    else if (hbm) { wg = 2; slack8 = 1; }
+    const FastGeom fg = fast_geom(&c, g, ry, wg, mode, 0, 0, slack8, resident_wg_per_cu * num_cu);
+    out4[0] = ry;
+    out4[1] = fg.nxg * fg.nyg;
+    out4[2] = fg.nzc;
+    out4[3] = fg.zlen;
+    return PDEGPU_OK;
+}

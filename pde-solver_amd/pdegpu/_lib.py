@@ -77,6 +77,7 @@ SYMBOLS = {
     "pdegpu_device_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "pdegpu_version": (C.c_char_p, []),
     "pdegpu_set_tunable": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "pdegpu_marching_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "pdegpu_heat_num_snapshots": (C.c_int, [C.POINTER(Heat)]),
     "pdegpu_heat_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_heat_solve_weighted": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.POINTER(Heat), _dp, _dp, C.POINTER(Stats)]),

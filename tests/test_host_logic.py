@@ -305,3 +305,43 @@ def test_snapshot_policy_error_mode_and_hopeless_requests(monkeypatch):
     monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "1")
     with pytest.raises(L.PdeGpuError, match="first and the last"):
         L.snapshot_policy(200, 513 ** 3, 1, False)
+
+
+def _geom(lib, nodes, mode, occ={0: 2, 1: 2, 2: 3, 3: 4}, cus=256):
+    out = (C.c_int32 * 4)()
+    assert lib.pdegpu_marching_geometry(cus, nodes[0], nodes[1], nodes[2], mode, occ[mode], out) == 0
+    return dict(ry=out[0], wg_per_chunk=out[1], chunks=out[2], planes=out[3])
+
+
+def test_marching_geometry_of_the_baseline_grids_is_pinned(lib):
+    """The z-chunk policy of the marching kernels is FITTED to sweeps (profiles/r02_exp16_chunk_count_sweep.log); this pins what it
+    must give on BASELINE's grids so that a re-fit cannot silently move the headline geometry (host-only entry point, no GPU):
+    configs[2] 512^3: one resident round of 2 x 256 = 512 workgroups in both CG kernels, 4 x 128 (4 rows per thread) in the bare SpMV;
+    configs[3] 1024x512x512 on one GPU and on 2 / 4 / 8 slabs across the long axis: the same 512 workgroups, longer or shorter chunks."""
+    for mode in (2, 3):
+        g = _geom(lib, (513, 513, 513), mode)
+        assert (g["ry"], g["wg_per_chunk"], g["chunks"], g["planes"]) == (2, 256, 2, 256), g
+    g = _geom(lib, (513, 513, 513), 0)
+    assert (g["ry"], g["wg_per_chunk"], g["chunks"]) == (4, 128, 4), g
+    for planes in (1025, 513, 257, 129):
+        g = _geom(lib, (513, 513, planes), 2)
+        assert (g["ry"], g["wg_per_chunk"], g["chunks"]) == (2, 256, 2), (planes, g)
+        assert g["chunks"] * g["planes"] >= planes - 2 > (g["chunks"] - 1) * g["planes"]
+
+
+def test_marching_geometry_away_from_512_uses_many_chunks_or_a_fitting_round(lib):
+    """what the sweeps showed: a single chunk of 525 / 576 workgroups (700^3 / 768^3, the old rule) runs at 0.49-0.56 of the HBM peak, many
+    dispatcher-scheduled chunks at 0.70; a round that fits 2 workgroups per CU is taken where one exists"""
+    for n in (576, 640, 700, 768, 896):
+        g = _geom(lib, (n + 1,) * 3, 2)
+        W = g["wg_per_chunk"] * g["chunks"]
+        assert W >= 4 * 512 and 24 <= g["planes"] <= 160, (n, g)
+    for n, fit in ((320, 480), (384, 432), (448, 448), (480, 480)):
+        g = _geom(lib, (n + 1,) * 3, 2)
+        assert g["wg_per_chunk"] * g["chunks"] == fit, (n, g)
+    g = _geom(lib, (1025,) * 3, 3)                  # stencil-K2 at 8 tiles per row: 4 rows make the one fitting round
+    assert (g["ry"], g["wg_per_chunk"], g["chunks"]) == (4, 512, 1), g
+    g = _geom(lib, (897,) * 3, 3)                   # ... at 7 they do not: 2 rows, many chunks
+    assert g["ry"] == 2 and g["wg_per_chunk"] * g["chunks"] > 2048, g
+    with pytest.raises(Exception):
+        assert lib.pdegpu_marching_geometry(0, 10, 10, 10, 2, 2, (C.c_int32 * 4)()) == 0
