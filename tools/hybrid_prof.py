@@ -11,6 +11,8 @@ h = L.Heat()
 h.kappa, h.dt, h.steady, h.source = 1.0, 0.0025, 1, 1.0
 h.bc_mode, h.fast_path = L.BC_DIRECTIONAL, 1
 h.bc_present[0], h.bc_value[0] = 1, 10.0
+if len(sys.argv) > 1 and sys.argv[1] == "lr":
+    h.bc_present[1], h.bc_value[1] = 1, 0.0
 s = C.c_void_p()
 L.check(ctx, lib.pdegpu_session_create(ctx, grid, h, 0, n + 1, C.byref(s)))
 L.check(ctx, lib.pdegpu_session_begin(s, 0.0))
