@@ -191,11 +191,10 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     // The column x = NX-1 that the tiles do not reach (2^k * 128 + 1 nodes per row) is the expensive part of this pass — one node per 4 KB row, 57 of
     // its 97 us in K1 and 32 of 56 us in K2 at 512^3 (profiles/r02_exp20_*.log).  Where that face is Dirichlet there is nothing to compute on it:
     // the CG vectors r, p vanish there and stay so (only these two passes write them: K1 would store p = 0 + beta 0, the in-place K2 r = 0), x keeps
-    // its boundary value.  So the two CG passes of the 64 B/DoF form leave the column out; every other pass (residual, bare apply, K1 that stores q)
-    // still visits it, which also re-establishes the zeros at the start of every solve.
-    if (fx && a.bnd_xcols == 1 && g.bc_mode == PDEGPU_BC_DIRECTIONAL && g.bc_present[1] && a.mask_dirichlet &&
-        ((mode == APPLY_CG_K1 && !a.out) || (mode == APPLY_CG_K2 && a.out == a.rhs)))
-        a.bnd_xcols = 0;
+    // its boundary value; a stored q is zero there since pdegpu_session_begin and nothing but K1 writes it between solves (lift_norm clears its use).
+    // So K1 and the in-place K2 leave the column out; every other pass (residual, bare apply) still visits it.
+    const bool cg_pass = g.bc_mode == PDEGPU_BC_DIRECTIONAL && a.mask_dirichlet && (mode == APPLY_CG_K1 || (mode == APPLY_CG_K2 && a.out == a.rhs));
+    if (fx && a.bnd_xcols == 1 && cg_pass && g.bc_present[1]) a.bnd_xcols = 0;
     a.bnd_ring = 2 * g.NX + a.bnd_xcols * (g.NY - 2);
     a.bnd_xcover = std::min(g.PX, ((g.NX - 1 + 127) / 128) * 128);
     a.bnd_n = (long long)(a.bnd_full_lo + a.bnd_full_hi) * g.NX * g.NY + (long long)planes * a.bnd_ring;

@@ -19,6 +19,8 @@ for steady in (1, 0):
         h.bc_present[0], h.bc_value[0] = 1, 10.0
         if len(sys.argv) > 2 and sys.argv[2] == "lr":          # T_left and T_right given, sides natural (a rod between two temperatures)
             h.bc_present[1], h.bc_value[1] = 1, 0.0
+        if len(sys.argv) > 2 and sys.argv[2] == "side":        # T_side only: x-faces natural
+            h.bc_present[0], h.bc_present[2], h.bc_value[2] = 0, 1, 3.0
         s = C.c_void_p()
         L.check(ctx, lib.pdegpu_session_create(ctx, grid, h, 0, n + 1, C.byref(s)))
         L.check(ctx, lib.pdegpu_session_begin(s, 0.0))
