@@ -1,5 +1,7 @@
 """Parity at BASELINE.json's full size (config 3: 512^3 cells, 513^3 nodes), where the oracle cannot run:
 size-independent properties of the operator and an independent residual check of a real solve."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -313,9 +315,9 @@ def test_random_mid_grids_fast_paths_match_the_oracle(lib, gpu_ctx):
 
 
 def test_wide_planes_take_four_rows_per_thread_in_k2_and_agree(lib, gpu_ctx):
-    """planes of 1025 x 1025 nodes: one z-chunk of 2-row tiles already is four workgroups per CU, so the stencil-K2 switches to 4 rows per
-    thread by itself (stencil_fast); forcing 2 rows must give the same solve — same iteration count, fields to round-off — and the field must
-    satisfy its equation (independent residual through the bare operator)"""
+    """planes of 1025 x 1025 nodes (8 tiles per row): the stencil-K2 with its automatic rows per thread (4 where they make the one fitting round of
+    workgroups on HBM-resident grids, stencil.hip fast_rows) and with 2 rows forced must give the same solve — same iteration count, fields to
+    round-off — and the field must satisfy its equation (independent residual through the bare operator)"""
     from pdegpu import heat, _lib
     kw = dict(Lx=1.0, Ly=1.0, Lz=0.01, nx=1024, ny=1024, nz=6, diffusivity=1.0, T_boundary=0.0, T_initial=0.0, dt=0.01, num_steps=1,
               source_type="constant", source_value=3.0, steady=True)
@@ -338,3 +340,40 @@ def test_wide_planes_take_four_rows_per_thread_in_k2_and_agree(lib, gpu_ctx):
     free = free.ravel()
     r = 3.0 * load[free] - y[free]
     assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(3.0 * load[free])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells", [(300, 260, 200), (700, 90, 150), (384, 200, 130)])
+def test_marching_kernels_on_hbm_resident_odd_grids_match_the_class_table_kernels(lib, gpu_ctx, cells):
+    """HBM-resident grids away from 512^3 take the fitted z-chunk policy (many dispatcher-scheduled chunks or a fitting round) and the row-major
+    workgroup order with ragged last workgroups (3 and 6 tiles per row here): the CG iterates of the marching kernels must be those of the
+    class-table kernels, which share nothing with them but the weights"""
+    from pdegpu import _lib
+    grid = _lib.make_grid(3, cells, (1.0, 0.9, 0.7))
+    nodes = (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+    assert nodes * 8 > (64 << 20)
+    out = []
+    for fast in (1, 0):
+        h = _lib.Heat()
+        h.kappa, h.dt, h.steady, h.source = 1.0, 1.0, 1, 1.0
+        h.bc_mode, h.fast_path = _lib.BC_UNIFORM, fast
+        h.bc_present[0] = 1
+        s = C.c_void_p()
+        _lib.check(gpu_ctx, lib.pdegpu_session_create(gpu_ctx, grid, h, 0, cells[2] + 1, C.byref(s)))
+        try:
+            _lib.check(gpu_ctx, lib.pdegpu_session_begin(s, 0.0))
+            _lib.check(gpu_ctx, lib.pdegpu_session_residual(s))
+            _lib.check(gpu_ctx, lib.pdegpu_session_reduce_local(s, 1, 1))
+            st = _lib.Stats()
+            _lib.check(gpu_ctx, lib.pdegpu_session_iterate(s, 6, 1, st))
+            rr = C.c_double()
+            _lib.check(gpu_ctx, lib.pdegpu_session_rr(s, C.byref(rr)))
+            _lib.check(gpu_ctx, lib.pdegpu_session_flush(s))
+            x = np.empty(nodes)
+            _lib.check(gpu_ctx, lib.pdegpu_session_get_x(s, _lib.dptr(x)))
+            assert st.path == fast
+            out.append((rr.value, x))
+        finally:
+            lib.pdegpu_session_destroy(s)
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-10)
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-11 * np.abs(out[1][1]).max()
