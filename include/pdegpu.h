@@ -135,7 +135,8 @@ const char* pdegpu_version(void);
  * "plane2d" / "plane2d_ry" (2-D grids: CG kernels as one-round tiles), "persist2d" (1 = 2-D grids up to 1024 cells wide and 8 rows per
  * CU run their whole CG loop in ONE cooperative launch with the state in registers; 2 / 3 = other grid-barrier forms), "persist2d_sr" (1 = that
  * launch uses the single-reduction CG recurrences: one grid barrier + one neighbour hand-off per iteration), "tile3d_max_nodes" (3-D grids up to this many
- * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "fast_linear" (1 = a workgroup of a marching kernel takes four consecutive tiles of the row-major
+ * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "place_tune" (1 = an HBM-resident marching session times K1 once with each of its six still
+ * interchangeable vectors as the solution vector and keeps the fastest: ~18 launches at creation; K1's time depends on the physical placement of that stream), "fast_linear" (1 = a workgroup of a marching kernel takes four consecutive tiles of the row-major
  * tile order, so tile-edge values are handed through LDS at any tile count per row; 0 = wxt x wyt blocks), "fast_occ_plain|res|k1|k2" (2 | 3 | 4: at most this many workgroups of that marching kernel resident per CU,
  * enforced by a dynamic LDS request the kernel never touches; 0 = off, measured without gain), "fast_cfg_plain|res|k1|k2" (per-mode
  * word ry + 16 wg + 256 ex + 512 pf, -1 = global tunables), "el_fast_xface" (1 = x-face rows inside the elasticity marching kernel),
@@ -310,6 +311,10 @@ int  pdegpu_session_time_apply(pdegpu_session* s, int reps, double* avg_ms_out);
 /* in-run memory calibration over the session's own vectors (padded slab, nk*PP doubles each):
  * which = 0 copy (1R+1W), 1 read-only (1R), 2 write-only (1W), 3 triad (2R+1W), 4 in-place update (2R+1W). */
 int  pdegpu_session_membench(pdegpu_session* s, int which, int reps, double* avg_ms_out);
+/* Diagnostic: average milliseconds of `reps` launches of the fused CG kernel K1 with its four vectors (x, r, p_old, p_new) taken from the session's
+ * six vectors {x, r, p0, p1, q, b} in the order roles4 gives (distinct indices 0..5).  K1's time depends on where its vectors sit in physical
+ * memory (profiles/r02_k1_bimodal_between_processes.log); single-slab marching sessions only; the session must be begun again afterwards. */
+int         pdegpu_session_debug_time_k1(pdegpu_session* s, const int32_t* roles4, int reps, double* avg_ms_out);
 int  pdegpu_session_get_x(pdegpu_session* s, double* x_out /* host [nk][plane nodes] */);
 int  pdegpu_session_sync(pdegpu_session* s);
 

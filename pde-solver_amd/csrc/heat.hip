@@ -29,6 +29,8 @@ struct pdegpu_session {
     int npt = 15;
     double hA[27 * 27];
     DevVec x, r, p[2], q, b;
+    double place_ms_default = 0.0, place_ms_best = 0.0;      // tune_x_placement: K1 with the default buffer as x / with the chosen one
+    int place_choice = 0;          // which of the six allocations became x (0 = the default)
     DevVec xprev;                  // u^{n-1} of a transient solve (allocated on first use)
     int pcur = 0;
     double* d_scal = nullptr;
@@ -454,7 +456,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_nt_in", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear", "fast_occ_plain", "fast_occ_res", "fast_occ_k1", "fast_occ_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_xt", "el_fast_npl", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_nt_in", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear", "place_tune", "fast_occ_plain", "fast_occ_res", "fast_occ_k1", "fast_occ_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_xt", "el_fast_npl", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -476,6 +478,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_cfg_k1")) return &ctx->fast_cfg[APPLY_CG_K1];
     if (!strcmp(key, "fast_cfg_k2")) return &ctx->fast_cfg[APPLY_CG_K2];
     if (!strcmp(key, "fast_linear")) return &ctx->fast_linear;
+    if (!strcmp(key, "place_tune")) return &ctx->place_tune;
     if (!strcmp(key, "fast_occ_plain")) return &ctx->fast_occ[APPLY_PLAIN];
     if (!strcmp(key, "fast_occ_res")) return &ctx->fast_occ[APPLY_RESIDUAL];
     if (!strcmp(key, "fast_occ_k1")) return &ctx->fast_occ[APPLY_CG_K1];
@@ -567,6 +570,88 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     delete s;
 }
 
+namespace {
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+// average ms of `reps` launches (after one untimed) of the marching K1 (64 B/DoF form) with the roles x, r, p_old, p_new played by the
+// session's vectors {x, r, p0, p1, q, b}[roles4[.]]
+int time_k1_roles(pdegpu_session* s, const int32_t* roles4, int reps, double* avg_ms_out) {
+    pdegpu_ctx* ctx = s->ctx;
+    double* bufs[6] = {s->x.v, s->r.v, s->p[0].v, s->p[1].v, s->q.v, s->b.v};
+    StencilArgs a{};
+    a.g = s->gk;
+    a.x = bufs[roles4[0]];
+    a.in = bufs[roles4[1]];
+    a.p_old = bufs[roles4[2]];
+    a.p_new = bufs[roles4[3]];
+    a.out = nullptr;
+    a.scal = s->d_scal;
+    a.partials = s->d_part;
+    a.counter = s->d_counter;
+    a.dot_which = -1;
+    a.mask_dirichlet = 1;
+    fast_weights(s->hA, a.w, s->gk.flat2d != 0);
+    a.npt = s->npt;
+    EventPair ev;
+    PG_HIP(ctx, hipEventCreate(&ev.a));
+    PG_HIP(ctx, hipEventCreate(&ev.b));
+    PG_TRY(stencil_fast(ctx, a, APPLY_CG_K1, nullptr));
+    PG_HIP(ctx, hipEventRecord(ev.a, ctx->stream));
+    for (int i = 0; i < reps; ++i) PG_TRY(stencil_fast(ctx, a, APPLY_CG_K1, nullptr));
+    PG_HIP(ctx, hipEventRecord(ev.b, ctx->stream));
+    PG_HIP(ctx, hipEventSynchronize(ev.b));
+    float ms = 0;
+    PG_HIP(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
+    *avg_ms_out = ms / reps;
+    return PDEGPU_OK;
+}
+
+// Placement of the solution vector (tunable place_tune, HBM-resident single-operator marching sessions).  K1 streams four vectors — r and p_old
+// read, p_new written, x read AND written — and its time depends on where they sit in PHYSICAL memory: the same launch takes 0.85 or 0.91-0.93 ms
+// at 512^3 from one set of allocations to the next (profiles/r02_k1_bimodal_between_processes.log).  The six vectors of a session are
+// interchangeable before the first begin(), and which of them carries the read-modify-write stream decides most of it
+// (profiles/r02_k1_role_probe.log: with the right one 0.845 ms whatever the others do, with any other 0.89-0.92), so: time K1 once with each
+// buffer as x, and if one is clearly the best let it be x.  6 x 3 launches on zero-filled vectors (they stay zero: alpha = beta = 1), ~20 ms.
+int tune_x_placement(pdegpu_session* s) {
+    pdegpu_ctx* ctx = s->ctx;
+    const bool hbm = (long long)s->g.nkl * s->g.PP * 8 > (64LL << 20);
+    if (!ctx->place_tune || !hbm || !s->fast || s->hybrid || s->tile3d || s->plane2d || s->weighted || s->g.dim != 3) return PDEGPU_OK;
+    const double one[SC_COUNT] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    static_assert(SC_COUNT <= 8, "scalar block");
+    PG_HIP(ctx, hipMemcpyAsync(s->d_scal, one, SC_COUNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double t[6];
+    for (int c = 0; c < 6; ++c) {
+        int32_t roles[4] = {c, 0, 0, 0};
+        int k = 1;
+        for (int i = 0; i < 6 && k < 4; ++i)
+            if (i != c) roles[k++] = i;
+        PG_TRY(time_k1_roles(s, roles, 2, &t[c]));
+    }
+    PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
+    int best = 0;
+    for (int c = 1; c < 6; ++c)
+        if (t[c] < t[best]) best = c;
+    s->place_ms_default = t[0];
+    s->place_ms_best = t[best];
+    s->place_choice = 0;
+    if (best != 0 && t[best] < 0.98 * t[0]) {           // (a clear win only: 2 % is the noise of two launches)
+        DevVec* vecs[6] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
+        std::swap(*vecs[0], *vecs[best]);
+        s->place_choice = best;
+    }
+    if (getenv("PDEGPU_DEBUG_GEOM"))
+        fprintf(stderr, "[pdegpu placement] K1 with each buffer as x: %.4f %.4f %.4f %.4f %.4f %.4f ms -> x takes buffer %d\n", t[0], t[1], t[2], t[3], t[4], t[5],
+                s->place_choice);
+    return PDEGPU_OK;
+}
+}  // namespace
+
 extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0,
                                      int64_t nk, pdegpu_session** out) {
     if (!ctx) return PDEGPU_EINVAL;
@@ -623,6 +708,7 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     if (rc == PDEGPU_OK && hipHostMalloc(&s->h_pin, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipHostMalloc");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset scal");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_part, 0, npart * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset partials");
+    if (rc == PDEGPU_OK) rc = tune_x_placement(s);
     if (rc != PDEGPU_OK) { pdegpu_session_destroy(s); return rc; }
     *out = s;
     return PDEGPU_OK;
@@ -1002,16 +1088,6 @@ extern "C" int pdegpu_session_rr(pdegpu_session* s, double* rr_out) {
     return PDEGPU_OK;
 }
 
-namespace {
-struct EventPair {
-    hipEvent_t a = nullptr, b = nullptr;
-    ~EventPair() {
-        if (a) (void)hipEventDestroy(a);
-        if (b) (void)hipEventDestroy(b);
-    }
-};
-}  // namespace
-
 extern "C" int pdegpu_session_time_apply(pdegpu_session* s, int reps, double* avg_ms_out) {
     if (!s || reps < 1 || !avg_ms_out) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;
@@ -1029,6 +1105,19 @@ extern "C" int pdegpu_session_time_apply(pdegpu_session* s, int reps, double* av
     PG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     *avg_ms_out = ms / reps;
     return PDEGPU_OK;
+}
+
+// Diagnostic (tools/role_probe.py): K1 timed with the roles (x, r, p_old, p_new) played by the session's six vectors in the order given by
+// roles4 (distinct indices into {x, r, p0, p1, q, b}).  Leaves the vectors in an undefined state: begin() again.
+extern "C" int pdegpu_session_debug_time_k1(pdegpu_session* s, const int32_t* roles4, int reps, double* avg_ms_out) {
+    if (!s || !roles4 || reps < 1 || !avg_ms_out || !s->fast || s->hybrid || s->tile3d || s->plane2d) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    for (int i = 0; i < 4; ++i) {
+        if (roles4[i] < 0 || roles4[i] > 5) return PDEGPU_EINVAL;
+        for (int j = 0; j < i; ++j)
+            if (roles4[j] == roles4[i]) return PDEGPU_EINVAL;
+    }
+    return time_k1_roles(s, roles4, reps, avg_ms_out);
 }
 
 // in-run memory calibration: average ms of `reps` launches of a streaming kernel over one slab vector set

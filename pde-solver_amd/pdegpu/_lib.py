@@ -128,6 +128,7 @@ SYMBOLS = {
     "pdegpu_session_rr": (C.c_int, [_vp, _dp]),
     "pdegpu_session_time_apply": (C.c_int, [_vp, C.c_int, _dp]),
     "pdegpu_session_membench": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "pdegpu_session_debug_time_k1": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int, _dp]),
     "pdegpu_session_get_x": (C.c_int, [_vp, _dp]),
     "pdegpu_session_sync": (C.c_int, [_vp]),
     "pdegpu_grid_num_nodes": (C.c_int64, [C.POINTER(Grid)]),

@@ -690,7 +690,7 @@ def test_opt_in_dot_and_graph_variants_give_the_same_bits(lib, gpu_ctx, knob, ca
                                      dict(extrapolate=0), dict(hybrid_bc=0), dict(hybrid_fx=0), dict(hybrid_k2=0), dict(fast_minlen=4), dict(fast_small_mult=4),
                                      dict(cg_variant=0), dict(cg_variant=2), dict(cg_variant=0, fast_ex=0, fast_ry=4), dict(fast_ex_all=1), dict(fast_pf=1), dict(fast_pf=0),
                                      dict(fast_ex_all=1, fast_pf=1, fast_ry=4), dict(fast_zlen=3), dict(tile3d_max_nodes=0),
-                                     dict(fast_occ_plain=2, fast_occ_res=2, fast_occ_k1=2, fast_occ_k2=3), dict(fast_linear=0),
+                                     dict(fast_occ_plain=2, fast_occ_res=2, fast_occ_k1=2, fast_occ_k2=3), dict(fast_linear=0), dict(place_tune=0),
                                      # per-mode configuration words: ry + 16 wg + 256 ex + 512 pf
                                      dict(fast_cfg_plain=4 + 16 * 2 + 512, fast_cfg_res=2 + 256 + 512, fast_cfg_k1=4 + 16 * 3 + 256, fast_cfg_k2=1 + 16 + 512)])
 def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kernel_form):
@@ -699,7 +699,7 @@ def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kerne
     from pdegpu import heat, _lib
     defaults = dict(fast_ry=0, fast_nt=-1, fast_ex=1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, extrapolate=1,
                     hybrid_bc=1, hybrid_fx=1, hybrid_k2=1, fast_minlen=1, fast_small_mult=1, cg_variant=1, fast_ex_all=0, fast_pf=-1, fast_zlen=0, tile3d_max_nodes=3000000,
-                    fast_cfg_plain=-1, fast_cfg_res=-1, fast_cfg_k1=-1, fast_cfg_k2=-1, fast_occ_plain=0, fast_occ_res=0, fast_occ_k1=0, fast_occ_k2=0, fast_linear=1)
+                    fast_cfg_plain=-1, fast_cfg_res=-1, fast_cfg_k1=-1, fast_cfg_k2=-1, fast_occ_plain=0, fast_occ_res=0, fast_occ_k1=0, fast_occ_k2=0, fast_linear=1, place_tune=1)
     def runs():
         a = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 140, 13, 11, 0.9, 1.5, 20.0, 0.003, 1, steady=True, source_type="constant", source_value=2.0, rtol=1e-12)
         b = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 30, 17, 12, 0.9, 1.5, 20.0, 0.003, 3, rtol=1e-12)
