@@ -621,7 +621,7 @@ int time_k1_roles(pdegpu_session* s, const int32_t* roles4, int reps, double* av
 int tune_x_placement(pdegpu_session* s) {
     pdegpu_ctx* ctx = s->ctx;
     const bool hbm = (long long)s->g.nkl * s->g.PP * 8 > (64LL << 20);
-    if (!ctx->place_tune || !hbm || !s->fast || s->hybrid || s->tile3d || s->plane2d || s->weighted || s->g.dim != 3) return PDEGPU_OK;
+    if (!ctx->place_tune || !hbm || !s->fast || s->tile3d || s->plane2d || s->weighted || s->g.dim != 3) return PDEGPU_OK;
     const double one[SC_COUNT] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     static_assert(SC_COUNT <= 8, "scalar block");
     PG_HIP(ctx, hipMemcpyAsync(s->d_scal, one, SC_COUNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
