@@ -135,7 +135,7 @@ const char* pdegpu_version(void);
  * "plane2d" / "plane2d_ry" (2-D grids: CG kernels as one-round tiles), "persist2d" (1 = 2-D grids up to 1024 cells wide and 8 rows per
  * CU run their whole CG loop in ONE cooperative launch with the state in registers; 2 / 3 = other grid-barrier forms), "persist2d_sr" (1 = that
  * launch uses the single-reduction CG recurrences: one grid barrier + one neighbour hand-off per iteration), "tile3d_max_nodes" (3-D grids up to this many
- * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "place_tune" (1 = an HBM-resident marching session times K1 once with each of its six still
+ * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "vec_contig" (experiment, 0: 1 = session vectors from hipExtMallocWithFlags(hipDeviceMallocContiguous)), "place_tune" (1 = an HBM-resident marching session times K1 once with each of its six still
  * interchangeable vectors as the solution vector and keeps the fastest: ~18 launches at creation; K1's time depends on the physical placement of that stream), "fast_linear" (1 = a workgroup of a marching kernel takes four consecutive tiles of the row-major
  * tile order, so tile-edge values are handed through LDS at any tile count per row; 0 = wxt x wyt blocks), "fast_occ_plain|res|k1|k2" (2 | 3 | 4: at most this many workgroups of that marching kernel resident per CU,
  * enforced by a dynamic LDS request the kernel never touches; 0 = off, measured without gain), "fast_cfg_plain|res|k1|k2" (per-mode

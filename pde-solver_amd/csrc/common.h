@@ -30,6 +30,7 @@ struct pdegpu_ctx {
     int fast_cfg[4] = {-1, -1, -1, -1};
     int fast_occ[4] = {0, 0, 0, 0};   // per mode: at most this many workgroups of a marching kernel resident per CU (2 | 3 | 4; enforced by a dynamic
                                 // LDS request of 60 / 48 / 36 KB per workgroup that the kernel never touches); 0 = whatever the registers allow
+    int vec_contig = 0;         // experiment: 1 = session vectors from hipExtMallocWithFlags(hipDeviceMallocContiguous) (physically contiguous), falling back to hipMalloc
     int place_tune = 1;         // HBM-resident marching sessions: 1 = at creation K1 is timed with each of the six (still interchangeable) vectors as x and the
                                 // fastest becomes x (K1's time depends on the physical placement of its read-modify-write stream), ~20 ms
     int fast_linear = 1;        // marching kernels: 1 = a workgroup takes four consecutive tiles of the row-major tile order (LDS edge hand-off at any tile count per row)

@@ -456,7 +456,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_nt_in", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear", "place_tune", "fast_occ_plain", "fast_occ_res", "fast_occ_k1", "fast_occ_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_xt", "el_fast_npl", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_nt_in", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear", "place_tune", "vec_contig", "fast_occ_plain", "fast_occ_res", "fast_occ_k1", "fast_occ_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_xt", "el_fast_npl", "el_fast_ry", "el_fast_waves"}) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -479,6 +479,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_cfg_k2")) return &ctx->fast_cfg[APPLY_CG_K2];
     if (!strcmp(key, "fast_linear")) return &ctx->fast_linear;
     if (!strcmp(key, "place_tune")) return &ctx->place_tune;
+    if (!strcmp(key, "vec_contig")) return &ctx->vec_contig;
     if (!strcmp(key, "fast_occ_plain")) return &ctx->fast_occ[APPLY_PLAIN];
     if (!strcmp(key, "fast_occ_res")) return &ctx->fast_occ[APPLY_RESIDUAL];
     if (!strcmp(key, "fast_occ_k1")) return &ctx->fast_occ[APPLY_CG_K1];

@@ -5,6 +5,8 @@
 // per lane -> __shfl_down across the 64-lane wavefront -> LDS across waves -> one partial per workgroup,
 // summed in fixed order by k_reduce (bitwise reproducible, no atomics, alpha/beta never leave the device).
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 #include "dot_finish.h"
 #include <cstdarg>
 
@@ -179,7 +181,14 @@ inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
 
 int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v) {
     v->total = vec_total(g);
-    PG_HIP(ctx, hipMalloc(&v->base, v->total * sizeof(double)));
+    v->base = nullptr;
+    if (ctx->vec_contig) {
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, v->total * sizeof(double), hipDeviceMallocContiguous) == hipSuccess) v->base = static_cast<double*>(p);
+        else (void)hipGetLastError();
+        if (getenv("PDEGPU_DEBUG_GEOM")) fprintf(stderr, "[pdegpu alloc] contiguous %zu MiB: %s\n", v->total * 8 >> 20, v->base ? "ok" : "refused");
+    }
+    if (!v->base) PG_HIP(ctx, hipMalloc(&v->base, v->total * sizeof(double)));
     PG_HIP(ctx, hipMemsetAsync(v->base, 0, v->total * sizeof(double), ctx->stream));
     v->v = v->base + vec_front(g);
     return PDEGPU_OK;
