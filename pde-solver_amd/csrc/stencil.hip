@@ -957,7 +957,7 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
         //    exact count — where the registers allow exactly 2 workgroups per CU (bare apply with 4 rows and the deeper prefetch) the
         //    rounds are real and W just below a multiple of 512 is best;
         //  * what the old rule (as few chunks as give every CU 2 workgroups, then 1/8 slack) got wrong is everything in between: 768^3 ran
-        //    ONE chunk of 576 workgroups (0.56 of the peak; now 8 chunks, 0.72), 700^3 525 (0.49 -> 0.68), 448^3 3 x 224 (0.58 -> 0.70).
+        //    ONE chunk of 576 workgroups (0.56 of the peak; now 12 chunks, 0.72), 700^3 525 (0.49 -> 0.68), 448^3 3 x 224 (0.58 -> 0.70).
         // Every chunk marches a two-plane prologue (useful = planes / (c * (zlen + 2))).
         const double S1 = 2.0 * ctx->num_cu;
         const bool k2 = (mode == APPLY_CG_K2);
