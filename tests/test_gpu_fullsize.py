@@ -377,3 +377,19 @@ def test_marching_kernels_on_hbm_resident_odd_grids_match_the_class_table_kernel
             lib.pdegpu_session_destroy(s)
     assert out[0][0] == pytest.approx(out[1][0], rel=1e-10)
     assert np.abs(out[0][1] - out[1][1]).max() <= 1e-11 * np.abs(out[1][1]).max()
+
+
+@pytest.mark.parametrize("cells", [(3000, 3000), (4096, 2200)])
+def test_flat_view_of_hbm_resident_2d_grids_matches_the_class_table_kernel(lib, gpu_ctx, cells):
+    """2-D grids beyond 64 MiB per vector take the flat view of the marching kernels under the fitted chunk policy (one 'row tile' per plane): the
+    bare operator on the free nodes must be the class-table kernel's"""
+    from pdegpu import _lib
+    g = _lib.make_grid(2, cells, (1.0, 0.7))
+    N = (cells[0] + 1) * (cells[1] + 1)
+    x = np.random.default_rng(1).standard_normal(N)
+    out = []
+    for fast in (1, 0):
+        y, load = np.empty(N), np.empty(N)
+        _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, g, 0.3, 1.0, _lib.dptr(x), _lib.dptr(y), _lib.dptr(load), fast))
+        out.append(y.reshape(cells[1] + 1, cells[0] + 1)[1:-1, 1:-1])
+    assert np.abs(out[0] - out[1]).max() <= 1e-13 * np.abs(out[1]).max()
