@@ -393,3 +393,40 @@ def test_flat_view_of_hbm_resident_2d_grids_matches_the_class_table_kernel(lib, 
         _lib.check(gpu_ctx, lib.pdegpu_heat_apply(gpu_ctx, g, 0.3, 1.0, _lib.dptr(x), _lib.dptr(y), _lib.dptr(load), fast))
         out.append(y.reshape(cells[1] + 1, cells[0] + 1)[1:-1, 1:-1])
     assert np.abs(out[0] - out[1]).max() <= 1e-13 * np.abs(out[1]).max()
+
+
+@pytest.mark.parametrize("bcs", [(1, 1, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)])
+def test_natural_face_sessions_on_an_hbm_resident_grid_match_the_class_table_kernels(lib, gpu_ctx, bcs):
+    """257 x 201 x 171 nodes (70 MB per vector; 257 = 2 * 128 + 1 nodes per row, so the column x = NX-1 is outside the tiles): the hybrid path —
+    marching kernel with the x-face rows, class-table pass for the rest, the Dirichlet column left out of the CG passes, placement tuner on — against
+    the class-table kernels everywhere, for T_left + T_right, T_left only, T_right only and T_side only"""
+    from pdegpu import _lib
+    cells = (256, 200, 170)
+    grid = _lib.make_grid(3, cells, (1.0, 0.8, 0.7))
+    nodes = (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+    out = []
+    for fast in (1, 0):
+        h = _lib.Heat()
+        h.kappa, h.dt, h.steady, h.source = 1.0, 1.0, 1, 1.0
+        h.bc_mode, h.fast_path = _lib.BC_DIRECTIONAL, fast
+        for f in range(3):
+            h.bc_present[f], h.bc_value[f] = bcs[f], 2.0 + f
+        s = C.c_void_p()
+        _lib.check(gpu_ctx, lib.pdegpu_session_create(gpu_ctx, grid, h, 0, cells[2] + 1, C.byref(s)))
+        try:
+            _lib.check(gpu_ctx, lib.pdegpu_session_begin(s, 0.0))
+            _lib.check(gpu_ctx, lib.pdegpu_session_residual(s))
+            _lib.check(gpu_ctx, lib.pdegpu_session_reduce_local(s, 1, 1))
+            st = _lib.Stats()
+            _lib.check(gpu_ctx, lib.pdegpu_session_iterate(s, 8, 1, st))
+            rr = C.c_double()
+            _lib.check(gpu_ctx, lib.pdegpu_session_rr(s, C.byref(rr)))
+            _lib.check(gpu_ctx, lib.pdegpu_session_flush(s))
+            x = np.empty(nodes)
+            _lib.check(gpu_ctx, lib.pdegpu_session_get_x(s, _lib.dptr(x)))
+            assert st.path == (3 if fast else 0)
+            out.append((rr.value, x))
+        finally:
+            lib.pdegpu_session_destroy(s)
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-10)
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-11 * np.abs(out[1][1]).max()
