@@ -44,7 +44,9 @@ extern "C" {
 #define PDEGPU_BC_UNIFORM     0    /* every boundary node = bc_value[0]            (:373-376, :626-628) */
 #define PDEGPU_BC_DIRECTIONAL 1    /* x==0 -> bc_value[0], x==Lx -> bc_value[1], other boundary nodes
                                       with 0<x<Lx -> bc_value[2]; bc_present[i]==0 leaves that part
-                                      natural (:233-241 for 1-D, :606-623 for the 3-D box) */
+                                      natural (:233-241 for 1-D, :606-623 for the 3-D box).  DirichletBC marks
+                                      facets, so with n[0] <= 2 cells bc_value[2] constrains nothing (every
+                                      side facet touches x = 0 or x = Lx; see make_grid_dev) */
 
 #define PDEGPU_QUANTITY_STRESS 0
 #define PDEGPU_QUANTITY_STRAIN 1
@@ -320,6 +322,9 @@ int  pdegpu_session_sync(pdegpu_session* s);
 
 /* ---- CPU-visible helpers that need no GPU (used by `-m "not gpu"` tests) ---------------------- */
 int64_t pdegpu_grid_num_nodes(const pdegpu_grid* grid);
+/* the Dirichlet set (mask_out [N] 0/1, value_out [N] nullable) the kernels use for `grid` with the boundary arguments of `heat`
+ * (bc_mode, bc_present, bc_value) — the DirichletBC predicates of :233-241, :373-376, :606-628 with the facet rule above */
+int     pdegpu_dirichlet_set_host(const pdegpu_grid* grid, const pdegpu_heat* heat, uint8_t* mask_out, double* value_out);
 int     pdegpu_slab_partition(int64_t n_planes, int n_ranks, int rank, int64_t* k0, int64_t* nk);
 
 #ifdef __cplusplus

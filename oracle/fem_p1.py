@@ -270,7 +270,13 @@ def solve_heat_2d(Lx, Ly, nx, ny, diffusivity, T_boundary, T_initial, dt, num_st
 def box_dirichlet(nx, ny, nz, T_boundary=0.0, T_left=None, T_right=None, T_side=None):
     """Dirichlet set of the box branch, fenics_mcp_server.py:576-628, with exact index tests in place
     of near().  Directional mode: left = x==0, right = x==Lx, side = boundary nodes with 0<x<Lx;
-    faces whose value is None stay natural.  bcs are applied in list order (left, right, side)."""
+    faces whose value is None stay natural.  bcs are applied in list order (left, right, side).
+    [3P] DirichletBC's default method "topological" marks FACETS — a boundary facet is taken when the predicate
+    holds at all of its vertices and at its midpoint — and constrains the dofs of the taken facets.  left_face /
+    right_face / `boundary` take whole faces (= their node sets).  `other_faces` (:614-617) takes a side facet
+    only if no vertex of it lies on x = 0 or x = Lx: impossible for nx <= 2 (T_side then constrains nothing);
+    for nx >= 3 every side node with 0 < ix < nx is a vertex of such a facet, so the node set below is exact
+    (enumerated against the facet rule in tests/test_oracle_known_answers.py)."""
     n = (nx + 1) * (ny + 1) * (nz + 1)
     idx = np.arange(n)
     ix = idx % (nx + 1)
@@ -291,7 +297,7 @@ def box_dirichlet(nx, ny, nz, T_boundary=0.0, T_left=None, T_right=None, T_side=
         s = ix == nx
         mask |= s
         vals[s] = T_right
-    if T_side is not None:
+    if T_side is not None and nx >= 3:
         s = onb & (ix != 0) & (ix != nx)
         mask |= s
         vals[s] = T_side

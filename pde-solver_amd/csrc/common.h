@@ -122,7 +122,19 @@ struct DevVec {
     double* base = nullptr;    // allocation
     double* v = nullptr;       // origin: node (0,0,lk=0)
     size_t total = 0;          // doubles allocated
+    bool borrowed = false;     // base points into a session arena (vec_free leaves it alone)
 };
+
+// One block of device memory that a session carves its six CG vectors from (placement experiments, tunable vec_contig >= 2):
+// kind 1 = one hipMalloc, kind 2 = one hipMemCreate handle mapped into one reserved address range.
+struct DevArena {
+    int kind = 0;
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipMemGenericAllocationHandle_t handle{};
+};
+int arena_create(pdegpu_ctx* ctx, int mode, size_t bytes_per_vec, int nvec, DevArena* a, size_t* stride_out);
+void arena_free(DevArena* a);
 
 inline size_t vec_front(const GridDev& g) { return (size_t)g.PX + kGuard + (size_t)g.PP; }
 inline size_t vec_total(const GridDev& g) { return 2 * ((size_t)g.PX + kGuard) + (size_t)(g.nkl + 2) * g.PP; }

@@ -29,6 +29,7 @@ struct pdegpu_session {
     int npt = 15;
     double hA[27 * 27];
     DevVec x, r, p[2], q, b;
+    DevArena arena;                // vec_contig >= 2: the six vectors above are carved from this one block
     double place_ms_default = 0.0, place_ms_best = 0.0;      // tune_x_placement: K1 with the default buffer as x / with the chosen one
     int place_choice = 0;          // which of the six allocations became x (0 = the default)
     DevVec xprev;                  // u^{n-1} of a transient solve (allocated on first use)
@@ -92,6 +93,26 @@ extern "C" int pdegpu_heat_num_snapshots(const pdegpu_heat* h) {
     return n;
 }
 
+// Host-only (no GPU): the Dirichlet set the kernels use for this grid and these boundary arguments, node order x fastest — lets the CPU
+// test-suite compare it with the oracle's restatement of the reference predicates (fenics_mcp_server.py:233-241, 373-376, 606-628).
+extern "C" int pdegpu_dirichlet_set_host(const pdegpu_grid* grid, const pdegpu_heat* heat, uint8_t* mask_out, double* value_out) {
+    if (!grid || !heat || !mask_out || grid->dim < 1 || grid->dim > 3) return PDEGPU_EINVAL;
+    for (int r = 0; r < grid->dim; ++r)
+        if (grid->n[r] < 1) return PDEGPU_EINVAL;
+    const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
+    const GridDev g = make_grid_dev(grid, heat, 0, nslow);
+    size_t e = 0;
+    for (int k = 0; k < g.NZ; ++k)
+        for (int j = 0; j < g.NY; ++j)
+            for (int i = 0; i < g.NX; ++i, ++e) {
+                double v = 0.0;
+                const bool d = pg_dirichlet(g, i, j, k, &v);
+                mask_out[e] = d ? 1 : 0;
+                if (value_out) value_out[e] = d ? v : 0.0;
+            }
+    return PDEGPU_OK;
+}
+
 int validate_grid(pdegpu_ctx* ctx, const pdegpu_grid* grid) {
     if (!grid) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "grid is null");
     if (grid->dim < 1 || grid->dim > 3) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "dim must be 1, 2 or 3 (got %d)", grid->dim);
@@ -121,6 +142,13 @@ GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t 
             g.bc_present[r] = heat->bc_present[r];
             g.bc_value[r] = heat->bc_value[r];
         }
+        // DirichletBC marks FACETS (DOLFIN's default method "topological": a boundary facet is taken when the predicate holds at all of
+        // its vertices and at its midpoint; every dof of a taken facet is constrained).  For `other_faces` (fenics_mcp_server.py:614-617,
+        // "on the boundary and 0 < x < Lx") a side facet qualifies only if none of its vertices lies on x = 0 or x = Lx: with nx <= 2 cells
+        // every side facet touches one of the two, so T_side constrains NOTHING there; from nx = 3 on every side node with 0 < x < Lx is a
+        // vertex of a qualifying facet and the per-node test of pg_dirichlet is exact.  left_face / right_face / the uniform predicate mark
+        // whole faces and agree with their node sets at any size.
+        if (g.bc_mode == PDEGPU_BC_DIRECTIONAL && grid->dim >= 2 && grid->n[0] <= 2) g.bc_present[2] = 0;
     } else {
         g.bc_mode = PDEGPU_BC_DIRECTIONAL;   // nothing constrained
     }
@@ -554,6 +582,7 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     vec_free(&s->x); vec_free(&s->r); vec_free(&s->p[0]); vec_free(&s->p[1]); vec_free(&s->q); vec_free(&s->b);
+    arena_free(&s->arena);
     tables_free(&s->tabs);
     if (s->d_scal) (void)hipFree(s->d_scal);
     if (s->d_part) (void)hipFree(s->d_part);
@@ -697,8 +726,27 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     s->tile3d = s->fast && !s->hybrid && s->g.dim == 3 && s->g.k0 == 0 && s->g.nkl == s->g.NZ && ctx->tile3d_max_nodes > 0 &&
                 (long long)s->g.NX * s->g.NY * s->g.NZ <= ctx->tile3d_max_nodes && stencil_tile3d_grid(s->g) <= 0x3fffffffLL;
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
-    for (DevVec* v : vecs)
-        if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);
+    if (ctx->vec_contig >= 2 && ctx->vec_contig <= 5 && rc == PDEGPU_OK) {
+        size_t stride = 0;
+        const size_t total = vec_total(s->g);
+        rc = arena_create(ctx, ctx->vec_contig, total * sizeof(double), 6, &s->arena, &stride);
+        for (int i = 0; i < 6 && rc == PDEGPU_OK; ++i) {
+            DevVec* v = vecs[i];
+            char* b0 = static_cast<char*>(s->arena.ptr);
+            if (s->arena.kind == 1) {                    // hipMalloc arena: first vector at the alignment the stride stands for
+                const size_t al = ctx->vec_contig == 4 ? (2ull << 20) : (1024ull << 20);
+                b0 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(b0) + al - 1) / al * al);
+            }
+            v->base = reinterpret_cast<double*>(b0 + (size_t)i * stride);
+            v->total = total;
+            v->borrowed = true;
+            v->v = v->base + vec_front(s->g);
+            if (hipMemsetAsync(v->base, 0, total * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset arena vector");
+        }
+    } else {
+        for (DevVec* v : vecs)
+            if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);
+    }
     int npart = stencil_max_partials(ctx);
     if (s->tile3d && stencil_tile3d_grid(s->g) > npart) npart = (int)stencil_tile3d_grid(s->g);
     if (rc == PDEGPU_OK && hipMalloc(&s->d_scal, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc scal");

@@ -182,7 +182,7 @@ inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
 int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v) {
     v->total = vec_total(g);
     v->base = nullptr;
-    if (ctx->vec_contig) {
+    if (ctx->vec_contig == 1) {
         void* p = nullptr;
         if (hipExtMallocWithFlags(&p, v->total * sizeof(double), hipDeviceMallocContiguous) == hipSuccess) v->base = static_cast<double*>(p);
         else (void)hipGetLastError();
@@ -194,8 +194,57 @@ int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v) {
     return PDEGPU_OK;
 }
 
+// Session arena (placement experiments, profiles/r03_placement_*.log): mode 2 / 3 = ONE hipMemCreate handle of the minimum / recommended
+// granularity mapped into one reserved range; mode 4 / 5 = one hipMalloc carved at 2 MiB / 1 GiB strides.
+int arena_create(pdegpu_ctx* ctx, int mode, size_t bytes_per_vec, int nvec, DevArena* a, size_t* stride_out) {
+    const size_t MiB = 1ull << 20;
+    if (mode == 4 || mode == 5) {
+        const size_t al = mode == 4 ? 2 * MiB : 1024 * MiB;
+        const size_t stride = (bytes_per_vec + al - 1) / al * al;
+        a->bytes = stride * nvec + al;
+        PG_HIP(ctx, hipMalloc(&a->ptr, a->bytes));
+        a->kind = 1;
+        *stride_out = stride;
+        return PDEGPU_OK;
+    }
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    size_t gran = 0;
+    PG_HIP(ctx, hipMemGetAllocationGranularity(&gran, &prop, mode == 2 ? hipMemAllocationGranularityMinimum : hipMemAllocationGranularityRecommended));
+    if (gran < 2 * MiB) gran = 2 * MiB;
+    const size_t stride = (bytes_per_vec + gran - 1) / gran * gran;
+    a->bytes = stride * nvec;
+    PG_HIP(ctx, hipMemAddressReserve(&a->ptr, a->bytes, gran, nullptr, 0));
+    if (hipMemCreate(&a->handle, a->bytes, &prop, 0) != hipSuccess) {
+        (void)hipMemAddressFree(a->ptr, a->bytes);
+        a->ptr = nullptr;
+        return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMemCreate(%zu MiB) failed", a->bytes >> 20);
+    }
+    a->kind = 2;
+    PG_HIP(ctx, hipMemMap(a->ptr, a->bytes, 0, a->handle, 0));
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    PG_HIP(ctx, hipMemSetAccess(a->ptr, a->bytes, &acc, 1));
+    if (getenv("PDEGPU_DEBUG_GEOM")) fprintf(stderr, "[pdegpu alloc] VMM arena %zu MiB, granularity %zu KiB\n", a->bytes >> 20, gran >> 10);
+    *stride_out = stride;
+    return PDEGPU_OK;
+}
+void arena_free(DevArena* a) {
+    if (a->kind == 1 && a->ptr) (void)hipFree(a->ptr);
+    if (a->kind == 2 && a->ptr) {
+        (void)hipMemUnmap(a->ptr, a->bytes);
+        (void)hipMemRelease(a->handle);
+        (void)hipMemAddressFree(a->ptr, a->bytes);
+    }
+    *a = DevArena();
+}
+
 void vec_free(DevVec* v) {
-    if (v->base) (void)hipFree(v->base);
+    if (v->base && !v->borrowed) (void)hipFree(v->base);
+    v->borrowed = false;
     v->base = v->v = nullptr;
     v->total = 0;
 }

@@ -132,6 +132,7 @@ SYMBOLS = {
     "pdegpu_session_get_x": (C.c_int, [_vp, _dp]),
     "pdegpu_session_sync": (C.c_int, [_vp]),
     "pdegpu_grid_num_nodes": (C.c_int64, [C.POINTER(Grid)]),
+    "pdegpu_dirichlet_set_host": (C.c_int, [C.POINTER(Grid), C.POINTER(Heat), C.POINTER(C.c_uint8), _dp]),
     "pdegpu_slab_partition": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
@@ -190,6 +191,15 @@ def context(device: int | None = None):
             ctx = h
             _ctx_cache[device] = ctx
     return ctx
+
+
+def close_contexts() -> None:
+    """Destroy every cached context (its stream included).  Long-lived servers never need this; scripts that run under a
+    profiler call it before the interpreter exits so that no HIP handle of this library outlives the tool's finalisation."""
+    lib = load_library()
+    with _lock:
+        for dev in list(_ctx_cache):
+            lib.pdegpu_destroy(_ctx_cache.pop(dev))
 
 
 def check(ctx, rc: int, allow=()):

@@ -61,7 +61,8 @@ def solve_heat_3D(Lx: float = 1.0, Ly: float = 1.0, Lz: float = 1.0, nx: int = 1
                   initial_wavenumber: float = 1.0, geometry_type: str = "box", cylinder_radius: Optional[float] = None,
                   T_left: Optional[float] = None, T_right: Optional[float] = None, T_side: Optional[float] = None,
                   core_radius: Optional[float] = None, core_diffusivity: Optional[float] = None) -> SolveResult:
-    """fenics_mcp_server.py:2122-2213 (box geometry; cylinder / composite core raise NotImplementedError)"""
+    """fenics_mcp_server.py:2122-2213: the box, its composite core (:537-572) and the BoxMesh fallback the reference runs for
+    geometry_type="cylinder" (:523-529); only a true mshr cylinder mesh is not offered"""
     field = _heat._solve_heat_3d_raw(Lx=Lx, Ly=Ly, Lz=Lz, nx=nx, ny=ny, nz=nz, diffusivity=diffusivity,
                                      T_boundary=T_boundary, T_initial=T_initial, dt=dt, num_steps=num_steps,
                                      steady=steady, source_type=source_type, source_value=source_value,

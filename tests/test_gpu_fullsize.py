@@ -9,11 +9,12 @@ pytestmark = pytest.mark.gpu
 N1 = 513
 
 
-def _apply(lib, ctx, cM, cK, x):
+def _apply(lib, ctx, cM, cK, x, fast=1):
+    """fast = 1: the fused z-marching kernels (Dirichlet rows give 0); fast = 0: the class-table kernel, full operator on every node"""
     from pdegpu import _lib
     g = _lib.make_grid(3, (512, 512, 512), (1.0, 1.0, 1.0))
     y = np.empty_like(x)
-    _lib.check(ctx, lib.pdegpu_heat_apply(ctx, g, cM, cK, _lib.dptr(x), _lib.dptr(y), None, 1))
+    _lib.check(ctx, lib.pdegpu_heat_apply(ctx, g, cM, cK, _lib.dptr(x), _lib.dptr(y), None, fast))
     return y
 
 
@@ -56,14 +57,15 @@ def test_operator_properties_at_512_cubed(lib, gpu_ctx):
 
 def test_steady_solve_at_512_cubed_satisfies_its_equation(lib, gpu_ctx):
     """config 3(ii): steady kappa K u = f m, f = 1, T_b = 0, rtol 1e-8; the returned field is checked by an
-    independent application of the operator (||b - A u|| <= 2e-8 ||b||), by the maximum principle, by the
+    independent application of the operator — the class-table kernel (fast_path = 0), NOT the marching family that produced the
+    solution — (||b - A u|| <= 2e-8 ||b||), by the maximum principle, by the
     symmetry of the solution and against the known maximum of the continuous problem"""
     from pdegpu import heat
     f = heat._solve_heat_3d_raw(1.0, 1.0, 1.0, 512, 512, 512, 1.0, 0.0, 0.0, 0.1, 1, steady=True,
                                 source_type="constant", source_value=1.0, rtol=1e-8)
     u = f.values[0]
     assert f.meta["solver_path"] == "fast" and f.values.shape == (1, N1 ** 3)
-    Au = _apply(lib, gpu_ctx, 0.0, 1.0, u)
+    Au = _apply(lib, gpu_ctx, 0.0, 1.0, u, fast=0)
     h = 1.0 / 512
     U = u.reshape(N1, N1, N1)
     r = (h ** 3 - Au.reshape(N1, N1, N1))[1:-1, 1:-1, 1:-1]

@@ -345,3 +345,29 @@ def test_marching_geometry_away_from_512_uses_many_chunks_or_a_fitting_round(lib
     assert g["ry"] == 2 and g["wg_per_chunk"] * g["chunks"] > 2048, g
     with pytest.raises(Exception):
         assert lib.pdegpu_marching_geometry(0, 10, 10, 10, 2, 2, (C.c_int32 * 4)()) == 0
+
+
+def test_dirichlet_set_of_the_library_is_the_oracles(lib):
+    """the index predicate the kernels use (pg_dirichlet + the facet rule of make_grid_dev) against oracle.box_dirichlet — itself pinned to
+    the facet rule by enumeration in test_oracle_known_answers.py — for every boundary-argument combination of the box branch"""
+    from pdegpu import _lib
+    for nx, ny, nz in ((1, 1, 1), (2, 2, 2), (2, 3, 4), (3, 2, 2), (4, 3, 2), (5, 4, 3)):
+        n = (nx + 1) * (ny + 1) * (nz + 1)
+        grid = _lib.make_grid(3, (nx, ny, nz), (1.0, 1.0, 1.0))
+        combos = [(None, None, None)] + [(a, b, c) for a in (None, 1.0) for b in (None, 2.0) for c in (None, 3.0) if (a, b, c) != (None, None, None)]
+        for T_left, T_right, T_side in combos:
+            h = _lib.Heat()
+            if (T_left, T_right, T_side) == (None, None, None):
+                h.bc_mode = _lib.BC_UNIFORM
+                h.bc_present[0], h.bc_value[0] = 1, 7.0
+                ref_m, ref_v = o.box_dirichlet(nx, ny, nz, T_boundary=7.0)
+            else:
+                h.bc_mode = _lib.BC_DIRECTIONAL
+                for r, v in enumerate((T_left, T_right, T_side)):
+                    h.bc_present[r], h.bc_value[r] = (0, 0.0) if v is None else (1, v)
+                ref_m, ref_v = o.box_dirichlet(nx, ny, nz, T_left=T_left, T_right=T_right, T_side=T_side)
+            mask = np.zeros(n, np.uint8)
+            vals = np.zeros(n)
+            assert lib.pdegpu_dirichlet_set_host(grid, h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), _lib.dptr(vals)) == 0
+            assert (mask.astype(bool) == ref_m).all(), (nx, ny, nz, T_left, T_right, T_side)
+            assert np.array_equal(vals[ref_m], ref_v[ref_m])

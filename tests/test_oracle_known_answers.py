@@ -221,3 +221,49 @@ def test_projected_sine_initial_condition():
     d = np.abs(f.values[0][1:-1] - 2.0 * np.sin(x[1:-1])).max()
     assert 1e-6 < d < 5e-3
     assert f.values[0][0] == 0.0 and f.values[0][-1] == 0.0           # bc.apply after project
+
+
+# ---- DirichletBC marks facets (DOLFIN's default method "topological", [3P]) ----------------------------------------------
+def _facet_rule_set(nx, ny, nz, T_left, T_right, T_side):
+    """The constrained node set by the facet rule itself: boundary facets of the mesh (triangles that belong to ONE
+    tetrahedron), a facet is taken when the predicate of fenics_mcp_server.py:606-617 holds at its three vertices and at its
+    midpoint, every vertex of a taken facet is constrained; bcs applied in list order (left, right, side)."""
+    Lx, Ly, Lz = 1.0, 0.7, 1.3
+    coords, cells = o.box_mesh(Lx, Ly, Lz, nx, ny, nz)
+    faces = np.concatenate([cells[:, [a, b, c]] for a, b, c in ((0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3))])
+    faces = np.sort(faces, axis=1)
+    uniq, cnt = np.unique(faces, axis=0, return_counts=True)
+    bnd = uniq[cnt == 1]
+    near = lambda a, b: np.abs(a - b) < 3e-16 * 16             # noqa: E731  (DOLFIN_EPS)
+    preds = {"left": lambda x: near(x[..., 0], 0.0), "right": lambda x: near(x[..., 0], Lx),
+             "side": lambda x: ~(near(x[..., 0], 0.0) | near(x[..., 0], Lx))}
+    n = coords.shape[0]
+    mask, vals = np.zeros(n, bool), np.zeros(n)
+    for name, T in (("left", T_left), ("right", T_right), ("side", T_side)):
+        if T is None:
+            continue
+        P = coords[bnd]                                          # [nf, 3, 3]
+        ok = preds[name](P).all(axis=1) & preds[name](P.mean(axis=1))
+        nodes = np.unique(bnd[ok])
+        mask[nodes] = True
+        vals[nodes] = T
+    return mask, vals
+
+
+@pytest.mark.parametrize("nx", [1, 2, 3, 4, 5])
+def test_box_dirichlet_is_the_facet_rule(nx):
+    for ny, nz in ((1, 1), (2, 3), (3, 2)):
+        for T_left, T_right, T_side in ((1.0, None, None), (None, 2.0, None), (None, None, 3.0), (1.0, 2.0, 3.0), (1.0, None, 3.0)):
+            m0, v0 = _facet_rule_set(nx, ny, nz, T_left, T_right, T_side)
+            m1, v1 = o.box_dirichlet(nx, ny, nz, T_left=T_left, T_right=T_right, T_side=T_side)
+            assert (m0 == m1).all(), (nx, ny, nz, T_left, T_right, T_side)
+            assert np.array_equal(v0[m0], v1[m1])
+    if nx <= 2:                                                  # every side facet touches x = 0 or x = Lx: T_side constrains nothing
+        m, _ = o.box_dirichlet(nx, 3, 3, T_side=5.0)
+        assert not m.any()
+
+
+def test_side_value_on_a_two_cell_grid_leaves_the_transient_problem_unconstrained():
+    """nx = 2, T_side only: no Dirichlet node, so the backward-Euler steps conserve the mean of a constant initial field exactly"""
+    f = o.solve_heat_3d(1.0, 1.0, 1.0, 2, 3, 3, 1.0, 0.0, 20.0, 0.01, 3, T_side=5.0)
+    assert np.abs(f.values - 20.0).max() < 1e-10

@@ -2,8 +2,9 @@ import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "pde-solver_amd")]
-from pdegpu import heat, elasticity
+from pdegpu import heat, elasticity, _lib
 f = heat._solve_heat_2d_raw(1.0, 1.0, 1024, 1024, 1.0, 0.0, 20.0, 0.0025, 10)
 print("2d iters", f.meta["cg_iterations"])
 f = elasticity._solve_elasticity_3d_static(1.0, 0.25, 0.25, 256, 64, 64, 210e9, 0.3, 0.0, 0.0, -76518.0, "stress", rtol=1e-8)
 print("el iters", f.meta["cg_iterations"])
+_lib.close_contexts()          # nothing of this library is alive when the profiler's exit handlers run
