@@ -726,7 +726,7 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     s->tile3d = s->fast && !s->hybrid && s->g.dim == 3 && s->g.k0 == 0 && s->g.nkl == s->g.NZ && ctx->tile3d_max_nodes > 0 &&
                 (long long)s->g.NX * s->g.NY * s->g.NZ <= ctx->tile3d_max_nodes && stencil_tile3d_grid(s->g) <= 0x3fffffffLL;
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
-    if (ctx->vec_contig >= 2 && ctx->vec_contig <= 5 && rc == PDEGPU_OK) {
+    if (ctx->vec_contig >= 2 && ctx->vec_contig <= 6 && rc == PDEGPU_OK) {
         size_t stride = 0;
         const size_t total = vec_total(s->g);
         rc = arena_create(ctx, ctx->vec_contig, total * sizeof(double), 6, &s->arena, &stride);
@@ -734,7 +734,7 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
             DevVec* v = vecs[i];
             char* b0 = static_cast<char*>(s->arena.ptr);
             if (s->arena.kind == 1) {                    // hipMalloc arena: first vector at the alignment the stride stands for
-                const size_t al = ctx->vec_contig == 4 ? (2ull << 20) : (1024ull << 20);
+                const size_t al = ctx->vec_contig == 5 ? (1024ull << 20) : (2ull << 20);
                 b0 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(b0) + al - 1) / al * al);
             }
             v->base = reinterpret_cast<double*>(b0 + (size_t)i * stride);

@@ -198,11 +198,16 @@ int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v) {
 // granularity mapped into one reserved range; mode 4 / 5 = one hipMalloc carved at 2 MiB / 1 GiB strides.
 int arena_create(pdegpu_ctx* ctx, int mode, size_t bytes_per_vec, int nvec, DevArena* a, size_t* stride_out) {
     const size_t MiB = 1ull << 20;
-    if (mode == 4 || mode == 5) {
-        const size_t al = mode == 4 ? 2 * MiB : 1024 * MiB;
-        const size_t stride = (bytes_per_vec + al - 1) / al * al;
+    if (mode == 4 || mode == 5 || mode == 6) {
+        const size_t al = mode == 5 ? 1024 * MiB : 2 * MiB;
+        size_t stride = (bytes_per_vec + al - 1) / al * al;
+        if (mode == 6) {                                  // physically contiguous arena, vectors staggered by PDEGPU_VEC_STAGGER_KB
+            const char* e = getenv("PDEGPU_VEC_STAGGER_KB");
+            stride += (size_t)(e ? atol(e) : 0) * 1024;
+        }
         a->bytes = stride * nvec + al;
-        PG_HIP(ctx, hipMalloc(&a->ptr, a->bytes));
+        if (mode == 6) PG_HIP(ctx, hipExtMallocWithFlags(&a->ptr, a->bytes, hipDeviceMallocContiguous));
+        else PG_HIP(ctx, hipMalloc(&a->ptr, a->bytes));
         a->kind = 1;
         *stride_out = stride;
         return PDEGPU_OK;

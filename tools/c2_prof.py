@@ -8,3 +8,7 @@ print("2d iters", f.meta["cg_iterations"])
 f = elasticity._solve_elasticity_3d_static(1.0, 0.25, 0.25, 256, 64, 64, 210e9, 0.3, 0.0, 0.0, -76518.0, "stress", rtol=1e-8)
 print("el iters", f.meta["cg_iterations"])
 _lib.close_contexts()          # nothing of this library is alive when the profiler's exit handlers run
+import os
+if os.environ.get("PDEGPU_DUMP_MAPS"):          # which libraries own the frames of an exit-time fault (profiles/r03_rocprofv3_exit_abort.log)
+    with open(os.environ["PDEGPU_DUMP_MAPS"], "w") as fh:
+        fh.write("".join(l for l in open("/proc/self/maps") if "r-xp" in l))

@@ -34,6 +34,6 @@ for rep in range(3):
 ms = C.c_double()
 L.check(ctx, lib.pdegpu_session_time_apply(s, 20, C.byref(ms)))
 ptrs = [lib.pdegpu_session_plane_ptr(s, v, 0) for v in range(4)]
-print(f"mode {os.environ.get('PDEGPU_VEC_CONTIG', '0')}: K1 " + " ".join(f"{a:.4f}" for a in k1) + "  K2 " + " ".join(f"{b:.4f}" for b in k2) +
+print(f"mode {os.environ.get('PDEGPU_VEC_CONTIG', '0')} stagger {os.environ.get('PDEGPU_VEC_STAGGER_KB', '-')} tune {os.environ.get('PDEGPU_PLACE_TUNE')}: K1 " + " ".join(f"{a:.4f}" for a in k1) + "  K2 " + " ".join(f"{b:.4f}" for b in k2) +
       f"  spmv {ms.value:.4f}  x r p q at " + " ".join(hex(q or 0) for q in ptrs), flush=True)
 lib.pdegpu_session_destroy(s)
