@@ -25,6 +25,7 @@ assemble + sparse LU — on a small grid, both on this host's cores)."""
 from __future__ import annotations
 
 import argparse
+import copy
 import ctypes as C
 import json
 import os
@@ -99,7 +100,8 @@ def cpu_baseline(n_cells: int, budget_s: float = 12.0):
                       f"cgroup quota {effective_cpus()}); the reference's own algorithm "
                       f"(sparse LU per step, FEniCS 2019.1.0) is not installable offline: see reference_algorithm",
             "ms_per_step": secs / iters * 1e3, "achieved_GBps": 112.0 * nodes ** 3 * iters / secs / 1e9,
-            "bytes_per_dof_model": 112}
+            "bytes_per_dof_model": 112,
+            "achieved_GBps_note": "112 B per unknown and iteration is a traffic MODEL of the unfused loop (14 vector passes), not a counter reading"}
 
 
 def reference_algorithm_baseline(n: int = 32):
@@ -311,65 +313,7 @@ def main():
                                       "no reduce launches) — the same kernels without the stepwise driver"}
     out["roofline"] = rl
 
-    # ---- the other workloads, same process group, after the main measurement ----------------------------------------
-    printed = threading.Event()
-
-    def emit():
-        if rank == 0 and not printed.is_set():
-            printed.set()
-            print(json.dumps(out), flush=True)
-
-    if not args.no_extras:
-        def bail():
-            # an extra leg is stuck (a collective that never completes would otherwise hold the main line back for ever)
-            out.setdefault("extras", {})["aborted"] = f"extras did not finish within {args.extras_timeout:.0f} s"
-            emit()
-            os._exit(0)
-        wd = threading.Timer(args.extras_timeout, bail)
-        wd.daemon = True
-        wd.start()
-        extras = {}
-        todo = [("config3", "strong"), ("config3", "weak"), ("config4", "strong")]
-        for wl, sc in todo:
-            c2 = make_case(wl, sc, n, world)
-            if c2["workload"] == case["workload"] and c2["scaling"] == case["scaling"]:
-                continue
-            if world == 1 and wl == "config3":
-                continue                                    # weak == strong == the main line on one GPU
-            try:
-                r2 = R.run_case(c2, max(20, args.steps // 2), max(5, args.warmup // 2))
-                st2 = max(20, args.steps // 2)
-                extras[f"{wl}_{c2['scaling']}"] = {
-                    "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
-                    "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
-                    "k1_ms": r2["k1_ms"], "k2_ms": r2["k2_ms"], "planes_rank0": r2["planes_rank0"], "rr_after": r2["rr_after"]}
-            except Exception as e:                          # an extra must never void the main number
-                extras[f"{wl}_{sc}"] = {"failed": repr(e)}
-                break
-        if world == 1 and not extras.get("config4_strong", {}).get("failed"):
-            # what the collective calls themselves cost (no wire): the same 512^3 loop with its two 8-byte all-reduces per iteration going
-            # through a ONE-rank RCCL process group — torch.distributed's stream hand-over + RCCL's launch path, on this GPU
-            try:
-                import socket
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1", 0))
-                    port = sk.getsockname()[1]
-                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-                R.dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.torch.device(f"cuda:{R.local_rank}"))
-                c3 = dict(case)
-                c3["force_collectives"] = True
-                st3 = max(20, args.steps // 2)
-                r3 = R.run_case(c3, st3, max(5, args.warmup // 2))
-                extras["collective_calls_one_rank"] = {
-                    "what": "main workload with both scalar all-reduces of every iteration issued through a 1-rank RCCL group (no wire time)",
-                    "steps": st3, "ms_per_step": r3["elapsed"] / st3 * 1e3, "value": r3["unknowns"] * st3 / r3["elapsed"], "unit": "DoF/s",
-                    "ms_per_step_without": ms_per_step}
-                R.dist.destroy_process_group()
-            except Exception as e:
-                extras["collective_calls_one_rank"] = {"failed": repr(e)}
-        wd.cancel()
-        out["extras"] = extras
-
+    # ---- CPU baseline (rank 0's host cores, N = 1 only) BEFORE the extras, so that a watchdog abort below still carries it ---------
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(n)
@@ -379,9 +323,80 @@ def main():
             out["cpu_baseline"]["reference_algorithm"] = reference_algorithm_baseline(32)
         except Exception as e:
             out["cpu_baseline"]["reference_algorithm"] = {"value": None, "sample": f"failed: {e}"}
-    emit()
+
+    # ---- the other workloads, same process group, after the main measurement ----------------------------------------
+    if not args.no_extras:
+        out["extras"] = run_extras_guarded(R, args, case, out, ms_per_step)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         R.dist.destroy_process_group()
+
+
+EXTRAS_ABORT_RC = 3
+
+
+def run_extras_guarded(R, args, case, out, ms_per_step):
+    """The other workloads (strong / weak / config 4, and at N = 1 the cost of the collective calls), measured after the main one in the
+    same process group.  An extra that hangs (a collective that never completes, a stuck GPU) must neither hold the main line back
+    for ever nor look like a success: after --extras-timeout seconds EVERY rank leaves with exit code 3 and rank 0 first prints the
+    main line — from a snapshot taken before the extras started, so the timer thread never serialises a dict the main thread is
+    mutating — with extras = {"aborted": ...}.  The cause is then to be found in the run's logs."""
+    snapshot = copy.deepcopy(out)
+
+    def bail():
+        snapshot["extras"] = {"aborted": f"extras did not finish within {args.extras_timeout:.0f} s; the process group was abandoned "
+                                         f"and every rank exited with code {EXTRAS_ABORT_RC}"}
+        log(f"[bench] rank {R.rank}: extras watchdog fired after {args.extras_timeout:.0f} s")
+        if R.rank == 0:
+            print(json.dumps(snapshot), flush=True)
+        os._exit(EXTRAS_ABORT_RC)
+
+    wd = threading.Timer(args.extras_timeout, bail)
+    wd.daemon = True
+    wd.start()
+    world, n = R.world, args.cells
+    extras = {}
+    todo = [("config3", "strong"), ("config3", "weak"), ("config4", "strong")]
+    for wl, sc in todo:
+        c2 = make_case(wl, sc, n, world)
+        if c2["workload"] == case["workload"] and c2["scaling"] == case["scaling"]:
+            continue
+        if world == 1 and wl == "config3":
+            continue                                    # weak == strong == the main line on one GPU
+        try:
+            r2 = R.run_case(c2, max(20, args.steps // 2), max(5, args.warmup // 2))
+            st2 = max(20, args.steps // 2)
+            extras[f"{wl}_{c2['scaling']}"] = {
+                "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
+                "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
+                "k1_ms": r2["k1_ms"], "k2_ms": r2["k2_ms"], "planes_rank0": r2["planes_rank0"], "rr_after": r2["rr_after"]}
+        except Exception as e:                          # an extra must never void the main number
+            extras[f"{wl}_{sc}"] = {"failed": repr(e)}
+            break
+    if world == 1 and not extras.get("config4_strong", {}).get("failed"):
+        # what the collective calls themselves cost (no wire): the same 512^3 loop with its scalar all-reduce(s) of every iteration going
+        # through a ONE-rank RCCL process group — torch.distributed's stream hand-over + RCCL's launch path, on this GPU
+        try:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            R.dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.torch.device(f"cuda:{R.local_rank}"))
+            c3 = dict(case)
+            c3["force_collectives"] = True
+            st3 = max(20, args.steps // 2)
+            r3 = R.run_case(c3, st3, max(5, args.warmup // 2))
+            extras["collective_calls_one_rank"] = {
+                "what": "main workload with the scalar all-reduce(s) of every iteration issued through a 1-rank RCCL group (no wire time)",
+                "steps": st3, "ms_per_step": r3["elapsed"] / st3 * 1e3, "value": r3["unknowns"] * st3 / r3["elapsed"], "unit": "DoF/s",
+                "ms_per_step_without": ms_per_step}
+            R.dist.destroy_process_group()
+        except Exception as e:
+            extras["collective_calls_one_rank"] = {"failed": repr(e)}
+    wd.cancel()
+    return extras
 
 
 if __name__ == "__main__":

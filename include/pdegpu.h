@@ -120,34 +120,58 @@ void        pdegpu_destroy(pdegpu_ctx* ctx);
 const char* pdegpu_last_error(const pdegpu_ctx* ctx);
 int         pdegpu_device_name(const pdegpu_ctx* ctx, char* buf, size_t buflen);
 const char* pdegpu_version(void);
-/* performance tunables of a context (also read from PDEGPU_<KEY> at pdegpu_create): "fast_ry" rows per thread of
- * the z-marching kernels (2|4|8), "fast_nt" non-temporal hint bits, "fast_ex" (1 = LDS hand-off of tile-edge values in the CG kernels), "fast_ex_all" (1 = also in the bare apply / residual pass), "fast_pf" (deeper prefetch, plane k+2 requested before plane k is computed: -1 = bare apply / residual pass, 1 = every one-vector mode, 0 = off), "fast_wg_per_cu" (0 = occupancy API),
- * "grid_mult" / "k2_grid_mult" workgroups per CU of the flat kernels / K2, "cg_variant"
- * (1 = K2 recomputes q with the marching stencil, 64 B/DoF per iteration, for the 7-point operator; 2 = for the 15-point operator of transient
- * runs as well (measured within 1 % of the stored-q form); 0 = K1 stores q, 72 B/DoF), "use_graph"
- * (1 = replay the CG inner loop from a captured hipGraph; opt-in, no measured gain, and NOT profilable: rocprofv3 7.2 aborted on
- * graph launches in round 1), "inlaunch_dot" (1 = finish dot products inside the producing
- * launch instead of a separate one-workgroup reduce launch; measured slower), "lazy_dot" (1 = the next
- * kernel's prologue sums the previous launch's partials, no reduce launches inside a single-slab CG chunk; same bits),
- * "direct_1d" (1 = 1-D grids use the Thomas recurrence inside one launch, 0 = CG), "el_fast" (1 = 3-D elasticity
- * z-marching block stencil), "el_fast_ry" (1|2 rows per column), "el_fast_waves" (wavefront target of the marching part; 0 = 4096, 8192 on HBM-resident grids),
- * "el_fast_yx" (1 = y-halo rows handed between the workgroup's waves through LDS), "hybrid_bc" (1 = 3-D grids with natural faces: marching kernel on the interior + class-table
- * kernel on the boundary nodes), "extrapolate" (1 = transient solves start CG from 2 u^n - u^{n-1}), "fast_minlen" /
- * "fast_small_mult" (z-chunk policy of the marching kernels on grids too small to fill the device), "fast_wg_per_cu_k2",
- * "plane2d" / "plane2d_ry" (2-D grids: CG kernels as one-round tiles), "persist2d" (1 = 2-D grids up to 1024 cells wide and 8 rows per
- * CU run their whole CG loop in ONE cooperative launch with the state in registers; 2 / 3 = other grid-barrier forms), "persist2d_sr" (1 = that
- * launch uses the single-reduction CG recurrences: one grid barrier + one neighbour hand-off per iteration), "tile3d_max_nodes" (3-D grids up to this many
- * nodes: CG kernels as one-round tiles; 0 = always march), "fast_zlen" (forced z-chunk length), "vec_contig" (experiment, 0: 1 = session vectors from hipExtMallocWithFlags(hipDeviceMallocContiguous)), "place_tune" (1 = an HBM-resident marching session times K1 once with each of its six still
- * interchangeable vectors as the solution vector and keeps the fastest: ~18 launches at creation; K1's time depends on the physical placement of that stream), "fast_linear" (1 = a workgroup of a marching kernel takes four consecutive tiles of the row-major
- * tile order, so tile-edge values are handed through LDS at any tile count per row; 0 = wxt x wyt blocks), "fast_occ_plain|res|k1|k2" (2 | 3 | 4: at most this many workgroups of that marching kernel resident per CU,
- * enforced by a dynamic LDS request the kernel never touches; 0 = off, measured without gain), "fast_cfg_plain|res|k1|k2" (per-mode
- * word ry + 16 wg + 256 ex + 512 pf, -1 = global tunables), "el_fast_xface" (1 = x-face rows inside the elasticity marching kernel),
- * "el_fast_yzface" (bit 0: its y-face rows, bit 1: the planes 0 / NZ-1 as well — the class-table pass then keeps the edges of the box), "el_fast_nt"
- * (non-temporal stores of that kernel's output: 1 | 0, -1 = where the vectors are HBM-resident), "el_fast_xt" (62 | 48 nodes per wave and row;
- * 48 = 128-byte aligned tiles, measured slower), "el_fast_npl" (1 | 2 nodes per lane; 2 = k_el_fast2 with 16-byte accesses, measured slower), "el_bnd_last" (1 = its boundary workgroups take the last block indices), "el_debug_part" (timing aid, 0;
- * 1 / 2 launch only the marching / boundary workgroups: WRONG results), "hybrid_fx" (1 = natural x-face rows inside the heat marching kernel),
- * "hybrid_k2" (1 = steady natural-face sessions on one slab use the 64 B/DoF form: K2 applies the operator again, marching + boundary launch).
- * Results do not depend on them beyond the solver tolerance. */
+/* Performance tunables of a context: pdegpu_set_tunable(ctx, key, value), or PDEGPU_<KEY> in the environment at pdegpu_create.
+ * Results do not depend on them beyond the solver tolerance; every non-default value is a parity-tested alternative or a tuning aid.
+ * Measured negatives are not kept as switches (round 3 removed hipGraph replay, in-launch dot completion, residency caps,
+ * non-temporal input loads, the 48-node / two-nodes-per-lane elasticity tiles and the allocation modes: DESIGN.md §4b, profiles/).
+ *
+ * key                | default | meaning
+ * -------------------+---------+----------------------------------------------------------------------------------------------
+ * heat, z-marching kernels (3-D; 2-D through the flat view)
+ * fast_ry            | 0       | rows per thread (1|2|4|8); 0 = 4 for the bare apply / residual pass, 2 for the CG kernels
+ * fast_nt            | -1      | non-temporal hints: bit 0 stores, bit 1 loads of x; -1 = both where a slab vector exceeds 64 MiB
+ * fast_ex            | 1       | CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
+ * fast_pf            | -1      | deeper prefetch (plane k+2 requested before plane k is computed): -1 = bare apply / residual pass,
+ *                    |         | 1 = every one-vector mode, 0 = off
+ * fast_linear        | 1       | a workgroup takes four consecutive tiles of the row-major tile order (0 = wxt x wyt blocks)
+ * fast_wg_per_cu     | 0       | workgroups per CU the z-chunking aims for; 0 = 2 on HBM-resident grids, occupancy API otherwise
+ * fast_wg_per_cu_k2  | 0       | the same for the stencil K2 alone (0 = follow fast_wg_per_cu)
+ * fast_zlen          | 0       | forced planes per z-chunk (0 = fitted chunk policy)
+ * fast_minlen        | 1       | shortest z-chunk on grids too small to fill the device
+ * fast_small_mult    | 1       | resident rounds of workgroups such grids may launch
+ * fast_cfg_plain|res|k1|k2 | -1 | per-mode word ry + 16 wg_per_cu + 256 ex + 512 pf; -1 = the global tunables
+ * cg_variant         | 1       | 1 = K2 applies the marching stencil to the stored p again (64 B/DoF, 7-point operator); 2 = also for
+ *                    |         | the 15-point operator of transient runs; 0 = K1 stores q, flat K2 (72 B/DoF)
+ * lazy_dot           | 1       | single-slab loops: the next kernel's prologue sums the previous launch's partials (no reduce launches)
+ * place_tune         | 1       | HBM-resident marching sessions time K1 once with each of their six interchangeable vectors as the
+ *                    |         | solution vector and keep the fastest (~18 launches at creation; profiles/r03_placement_*.log)
+ * grid_mult          | 8       | flat kernels: workgroups per CU
+ * k2_grid_mult       | 2       | flat K2: workgroups per CU
+ * extrapolate        | 1       | transient solves start CG from 2 u^n - u^(n-1)
+ * heat, other kernel forms
+ * tile3d_max_nodes   | 3000000 | 3-D grids up to this many nodes run K1 / K2 as one-round tiles (0 = always march)
+ * tile3d_plain       | 1       | ... and the bare masked apply too
+ * plane2d            | 1       | 2-D grids: K1 / K2 as one-round tiles (0 = flat view of the marching kernels)
+ * plane2d_ry         | 4       | rows per wavefront tile of that form (2|4|8)
+ * persist2d          | 1       | 2-D grids up to 1024 cells wide: the whole CG loop in ONE cooperative launch, state in registers
+ *                    |         | (2 / 3 = other grid-barrier forms).  Traced by rocprofv3, whose exit handler then faults inside
+ *                    |         | libhsa-runtime64 AFTER the stats files are written (profiles/r03_rocprofv3_exit_abort.log)
+ * persist2d_sr       | 1       | that launch uses the single-reduction recurrences (one grid barrier + one neighbour hand-off)
+ * hybrid_bc          | 1       | natural faces: marching kernel on the interior + class-table kernel on the boundary nodes
+ * hybrid_fx          | 1       | ... with the natural x-face rows inside the marching kernel
+ * hybrid_k2          | 1       | ... steady sessions on one slab use the 64 B/DoF form
+ * direct_1d          | 1       | 1-D grids: Thomas recurrence inside one launch (0 = CG, diagnostic)
+ * elasticity
+ * el_fast            | 1       | 3-D: z-marching block stencil (0 = thread-per-node class-table kernel)
+ * el_fast_ry         | 2       | rows per wavefront column (1|2)
+ * el_fast_yx         | 1       | y-halo rows handed between the workgroup's waves through LDS
+ * el_fast_xface      | 1       | x-face nodes inside the marching kernel
+ * el_fast_yzface     | 3       | bit 0: y-face rows, bit 1: the planes 0 / NZ-1 as well (the class-table pass keeps the box edges)
+ * el_fast_nt         | -1      | non-temporal stores of the output: 1|0, -1 = where the vectors are HBM-resident
+ * el_fast_waves      | 0       | wavefront target of the marching part; 0 = 4096, 8192 on HBM-resident grids
+ * el_bnd_last        | 0       | boundary workgroups take the last block indices
+ * el_grid_mult       | 4       | flat / class-table kernels: workgroups per CU
+ */
 int         pdegpu_set_tunable(pdegpu_ctx* ctx, const char* key, int value);
 /* Host-only diagnostic (needs no GPU): launch geometry of the 7-point z-marching kernels for a single-slab 3-D grid of nx x ny x nz NODES on
  * a device with num_cu compute units and resident_wg_per_cu resident workgroups of that kernel per CU (gfx950 build: PLAIN 2, K1 3, K2 4),

@@ -22,15 +22,10 @@ struct pdegpu_ctx {
                                 // (3 when one slab vector exceeds 64 MiB, i.e. nothing stays cache-resident)
     int fast_ex = 1;            // 1: CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
                                 // instead of 2-lane global loads (measured: 1.65 -> 1.52 ms per 512^3 CG iteration)
-    int fast_nt_in = 0;         // one-vector marching modes on HBM-resident grids: non-temporal loads of the input (1 inner rows, 2 all rows)
-    int fast_ex_all = 0;        // 1: the bare apply / residual pass use the LDS edge hand-off too (default: CG kernels only)
     int fast_pf = -1;           // deeper prefetch (plane k+2 requested before plane k is computed): -1 = bare apply / residual pass only, 1 = every one-vector mode, 0 = off
     // per-mode overrides of the marching kernels, index = ApplyMode (PLAIN, RESIDUAL, CG_K1, CG_K2); -1 = follow the global tunables.
     // value = ry + 16 * wg_per_cu + 256 * ex + 512 * pf  (ry in {1, 2, 4, 8}, wg_per_cu 0 = occupancy API)
     int fast_cfg[4] = {-1, -1, -1, -1};
-    int fast_occ[4] = {0, 0, 0, 0};   // per mode: at most this many workgroups of a marching kernel resident per CU (2 | 3 | 4; enforced by a dynamic
-                                // LDS request of 60 / 48 / 36 KB per workgroup that the kernel never touches); 0 = whatever the registers allow
-    int vec_contig = 0;         // experiment: 1 = session vectors from hipExtMallocWithFlags(hipDeviceMallocContiguous) (physically contiguous), falling back to hipMalloc
     int place_tune = 1;         // HBM-resident marching sessions: 1 = at creation K1 is timed with each of the six (still interchangeable) vectors as x and the
                                 // fastest becomes x (K1's time depends on the physical placement of its read-modify-write stream), ~20 ms
     int fast_linear = 1;        // marching kernels: 1 = a workgroup takes four consecutive tiles of the row-major tile order (LDS edge hand-off at any tile count per row)
@@ -43,21 +38,14 @@ struct pdegpu_ctx {
                                 // K2 0.62 -> 0.55 ms against the occupancy limit of 5-8) — and the occupancy API on cache-resident grids
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
-    int inlaunch_dot = 0;       // opt-in: finish dot products inside the producing launch (dot_finish.h).  Measured slower:
-                                // the per-workgroup agent-scope release writes back the XCD's dirty L2 in streaming kernels
-    int use_graph = 0;          // opt-in: replay the CG inner loop from a captured hipGraph.  Measured: no gain (the small
-                                // configs are bound by kernel time, not launches) and rocprofv3 7.2 crashes on graph launches
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
     int el_fast = 1;            // 3-D elasticity: 1 = z-marching block stencil (k_el_fast); 0 = thread-per-node class-table kernel
     int el_fast_yx = 1;         // k_el_fast: 1 = the 4 waves of a workgroup are y-neighbours and hand their y-halo rows through LDS
     int el_fast_xface = 1;      // k_el_fast: 1 = the x-face nodes (interior in y, z) are computed by the marching part (edge lanes carry the
                                 // face-class weights); 0 = by the class-table boundary pass (45 uncoalesced loads per node)
     int el_fast_yzface = 3;     // k_el_fast also computes: bit 0 the y-face nodes, bit 1 (with bit 0) the nodes of the planes 0 / NZ-1
-    int el_fast_npl = 1;        // k_el_fast: nodes per lane, 1 | 2 (2 = k_el_fast2: 16-byte accesses, 124-node tiles)
-    int el_fast_xt = 62;        // k_el_fast: nodes per wave and row, 62 | 48 (48: 128-byte aligned tiles, whole-line stores, a quarter of the lanes idle)
-    int el_fast_nt = -1;        // k_el_fast / k_el_fast2: non-temporal stores of the output: 1 | 0; -1 = where the vectors are HBM-resident
+    int el_fast_nt = -1;        // k_el_fast: non-temporal stores of the output: 1 | 0; -1 = where the vectors are HBM-resident
     int el_bnd_last = 0;        // k_el_fast: 1 = the boundary workgroups take the last block indices instead of the first
-    int el_debug_part = 0;      // timing aid for tools/: 1 = k_el_fast launches its marching part only, 2 = its boundary workgroups only (wrong results)
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
     int el_fast_waves = 0;      // wavefronts the marching part aims for (sets the z-chunk length); 0 = 4096, 8192 on HBM-resident grids
     int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never
@@ -122,19 +110,8 @@ struct DevVec {
     double* base = nullptr;    // allocation
     double* v = nullptr;       // origin: node (0,0,lk=0)
     size_t total = 0;          // doubles allocated
-    bool borrowed = false;     // base points into a session arena (vec_free leaves it alone)
 };
 
-// One block of device memory that a session carves its six CG vectors from (placement experiments, tunable vec_contig >= 2):
-// kind 1 = one hipMalloc, kind 2 = one hipMemCreate handle mapped into one reserved address range.
-struct DevArena {
-    int kind = 0;
-    void* ptr = nullptr;
-    size_t bytes = 0;
-    hipMemGenericAllocationHandle_t handle{};
-};
-int arena_create(pdegpu_ctx* ctx, int mode, size_t bytes_per_vec, int nvec, DevArena* a, size_t* stride_out);
-void arena_free(DevArena* a);
 
 inline size_t vec_front(const GridDev& g) { return (size_t)g.PX + kGuard + (size_t)g.PP; }
 inline size_t vec_total(const GridDev& g) { return 2 * ((size_t)g.PX + kGuard) + (size_t)(g.nkl + 2) * g.PP; }
@@ -221,12 +198,10 @@ struct StencilArgs {
     const double* p_old;      // CG_K1
     double* p_new;            // CG_K1
     double* x;                // CG_K1 (updated in place)
-    double* scal;             // device scalars (SC_*): read by K1 / K2, updated by dot_finish
+    double* scal;             // device scalars (SC_*): read by K1 / K2
     double* partials;         // per-workgroup partial dot products
     int mask_dirichlet;       // 1: Dirichlet rows give 0 (P applied to the output)
     int npt;                  // 7 or 15 (fast path)
-    unsigned* counter;        // dot_finish ticket counter (device word)
-    int dot_which;            // 0: p.q, 1: r.r (the kernel completes the dot product itself), -1: partials only
     DotIn di;                 // CG_K1 / CG_K2: how the previous launch's dot product arrives
     // hybrid path (3-D grids with natural faces): the marching kernel does the interior nodes, the class-table kernel the
     // boundary nodes of the slab, enumerated analytically: bnd_n > 0 -> one thread per boundary node instead of per index
@@ -235,7 +210,6 @@ struct StencilArgs {
     int bnd_lkb = 0;          // first local plane that is interior in z
     int bnd_ring = 0;         // boundary nodes of such a plane: 2 NX + 2 (NY - 2)
     int bnd_xcover = 0;       // columns [0, bnd_xcover) of interior rows get p / x from the marching kernel (128-node tiles)
-    int nt_in = 0;            // marching kernel, one-vector modes: 1 = non-temporal loads of the rows no other workgroup reads, 2 = of every row
     int fx_hi = 0;            // free_x == 2: the tiles reach the node NX-1 (no extra tile is spent on it: a fifth, one-node tile column
                               // per 513-node row was measured 27 % SLOWER than leaving that column to the class-table pass)
     int bnd_xcols = 2;        // boundary pass: x-face columns of the interior rows it still owns (2 both, 1 only x = NX-1, 0 none)
@@ -248,31 +222,6 @@ struct StencilArgs {
 };
 
 struct LaunchInfo { int grid = 0; int block = 256; };
-
-// hipGraph of an even number of CG iterations (the p ping-pong returns to its starting buffer), replayed from
-// the context stream.  `key` = the tunables the captured launches depend on.
-struct CgGraph {
-    hipGraphExec_t exec = nullptr;
-    hipGraph_t graph = nullptr;
-    int iters = 0;
-    int pcur = -1;
-    long long key = -1;
-    void reset() {
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        exec = nullptr;
-        graph = nullptr;
-        iters = 0;
-        pcur = -1;
-        key = -1;
-    }
-};
-inline long long tunable_key(const pdegpu_ctx* c) {
-    return (((((((long long)c->fast_ry * 8 + (c->fast_nt & 7)) * 32 + c->fast_wg_per_cu) * 128 + c->grid_mult) * 128 + c->k2_grid_mult) * 4 +
-            c->cg_variant) * 8 + c->fast_ex * 4 + c->fast_ex_all * 2 + (c->fast_pf != 0)) * 1024 + (c->fast_pf < 0 ? 512 : 0) + c->fast_zlen +
-           (((long long)c->fast_cfg[0] * 1031 + c->fast_cfg[1]) * 1031 + c->fast_cfg[2]) * 1031 + c->fast_cfg[3] +
-           (((long long)c->fast_occ[0] * 7 + c->fast_occ[1]) * 7 + c->fast_occ[2]) * 7 + c->fast_occ[3] + 3001LL * c->fast_linear;
-}
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 bool stencil_fast_supported(const GridDev& g, int element_mode);
@@ -292,8 +241,8 @@ int vec_zero(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
 int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const double* nodal_dense, int only_bc);
 int vec_extrapolate(pdegpu_ctx* ctx, const GridDev& g, double* x, double* xprev, int first);   // x <- 2x - xprev; xprev <- x
 int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal);
-int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, unsigned* counter,
-           LaunchInfo* li, const DotIn& di = DotIn());
+int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, LaunchInfo* li,
+           const DotIn& di = DotIn());
 // which: 0 p.q -> SC_PQ(_LOCAL); 1 r.r -> SC_RR_PREV <- SC_RR, SC_RR(_LOCAL); 2 r.r -> SC_RR(_LOCAL) only (SC_RR_PREV
 // already holds the previous value: end of a lazy chunk whose current slot is SC_RR_PREV)
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
@@ -302,7 +251,7 @@ int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partia
 int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, const double* lengths, double cM,
                       double cK, double* ellA, double* ellM, double* dinv, long long stride);
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
-              double* partials, unsigned* counter, int use_alpha, LaunchInfo* li);
+              double* partials, int use_alpha, LaunchInfo* li);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense

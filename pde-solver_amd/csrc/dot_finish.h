@@ -1,23 +1,12 @@
-// dot_finish.h — in-launch completion of a grid-wide dot product (gfx950).
+// dot_finish.h — how the CG kernels hand dot products from one launch to the next (gfx950).
 //
-// Every workgroup stores its partial sum, publishes it with an agent-scope release and takes a ticket from a
-// device-scope counter; the workgroup that draws the last ticket acquires (invalidates its CU's L1) and sums
-// ALL partials in a fixed order — the result is bitwise independent of which workgroup happens to be last —
-// then updates the CG scalars and re-arms the counter.  This replaces a separate one-workgroup reduce launch
-// after every dot-producing kernel (2 launches per CG iteration).
-// Protocol per /opt/skills/guides/cdna_hip_programming.md §6 Guideline 16: producer = plain store ->
-// __threadfence() (buffer_wbl2 sc1 + buffer_inv sc1) -> explicit s_waitcnt vmcnt(0) (the compiler may drop the
-// wait after the write-back) -> atomic ticket; consumer = ticket -> agent acquire fence -> barrier -> plain loads.
-// No dispatch-order / placement assumption: the last ticket can only be drawn after every workgroup has arrived.
+// Every dot-producing kernel stores ONE partial per workgroup (dot_finish).  The consumer is either a one-workgroup reduce launch
+// (k_reduce: the multi-GPU loop, whose all-reduce needs the scalar in memory) or — single-slab loops — the prologue of the next
+// kernel, where every workgroup sums all partials in the same fixed order (dot_in_sum) and so holds the bitwise identical scalar.
+// (Round 1 also finished the sum inside the producing launch with a last-workgroup ticket; it was measured slower — every workgroup's
+// agent-scope release writes back its XCD's dirty L2 lines in a streaming kernel — and was removed in round 3.)
 #pragma once
 #include "common.h"
-
-struct DotSink {
-    double* partials;       // [gridDim.x]
-    unsigned* counter;      // device word, zero between launches
-    double* scal;           // CG scalar block (SC_*)
-    int which;              // 0: p.q -> SC_PQ_LOCAL / SC_PQ;  1: r.r -> SC_RR_PREV <- SC_RR, SC_RR_LOCAL / SC_RR;  < 0: no scalar update
-};
 
 __device__ __forceinline__ double df_wave_sum(double v) {
 #pragma unroll
@@ -71,42 +60,7 @@ __device__ __forceinline__ double cg_alpha_in(const DotIn& di, double* scal, dou
     return (pq > 0.0) ? rr / pq : 0.0;
 }
 
-// block_total is valid in thread 0.  sRed: >= 4 doubles of LDS.  All 256 threads must call.
-__device__ __forceinline__ void dot_finish(double block_total, const DotSink& d, double* sRed) {
-    __shared__ int sLast;
-    if (threadIdx.x == 0) {
-        d.partials[blockIdx.x] = block_total;
-        int last = 0;
-        if (d.which >= 0) {
-            __threadfence();                                         // agent-scope release of the partial
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned ticket = atomicAdd(d.counter, 1u);
-            last = (ticket == gridDim.x - 1);
-        }
-        sLast = last;
-    }
-    __syncthreads();
-    if (sLast) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // this CU's L1 may not hold other CUs' partials
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        double acc = 0.0;
-        const int n = (int)gridDim.x;
-        for (int e = threadIdx.x; e < n; e += 256) acc += d.partials[e];     // same order as the former k_reduce
-        acc = df_wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const double tot = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
-            if (d.which == 0) {
-                d.scal[SC_PQ_LOCAL] = tot;
-                d.scal[SC_PQ] = tot;
-            } else {
-                d.scal[SC_RR_PREV] = d.scal[SC_RR];
-                d.scal[SC_RR_LOCAL] = tot;
-                d.scal[SC_RR] = tot;
-            }
-            *d.counter = 0u;                                         // re-armed for the next launch (kernel boundary orders it)
-        }
-    }
+// block_total is valid in thread 0: one partial per workgroup.
+__device__ __forceinline__ void dot_finish(double block_total, double* partials) {
+    if (threadIdx.x == 0) partials[blockIdx.x] = block_total;
 }

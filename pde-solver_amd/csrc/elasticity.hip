@@ -254,6 +254,7 @@ __device__ __forceinline__ ElW36 el_expand_weights(const ElW18& k) {
     w.faces = k.faces;
     return w;
 }
+constexpr int kElXt = 62;      // nodes a wave owns per row (lanes 1 .. 62; lanes 0 and 63 carry the x-halo)
 struct ElFastGeom {
     int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
     int nyg;                   // groups of 4 y-tiles (one workgroup each) of the y-hand-off variant
@@ -261,8 +262,6 @@ struct ElFastGeom {
     int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
     int nb_bnd;                // boundary workgroups
     int bnd_last;              // 1: they take the LAST block indices
-    int npl;                   // nodes per lane: 1 (k_el_fast) | 2 (k_el_fast2)
-    int xt;                    // nodes a wave owns per row: 62 (lanes 1 .. 62), or 48: tiles then start on 128-byte boundaries and store whole lines
     int full_lo, full_hi;      // 1: this slab owns the global plane 0 / NZ-1 (all of its nodes are boundary nodes)
     int ring;                  // boundary nodes of an interior plane: 2 NX + 2 (NY - 2)
     long long nbnd;            // boundary nodes of the slab
@@ -486,7 +485,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
         }
         const bool ghost_wave = YX && yt >= fg.nty;           // beyond the last row tile: takes part in the barriers only
         if (ghost_wave) yt = fg.nty - 1;                      // (loads stay inside the grid; nothing is stored)
-        const int i = xt * fg.xt + lane;                         // lanes 0 and 63: x-halo only (lane 0 of the first tile: the face x = 0)
+        const int i = xt * kElXt + lane;                         // lanes 0 and 63: x-halo only (lane 0 of the first tile: the face x = 0)
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
         const int lk0 = fg.lkb + zc * fg.zlen;
         const int lk1 = min(lk0 + fg.zlen, fg.lke);
@@ -498,9 +497,9 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             // x-faces: lane 0 of the first tile is the node i = 0 (clamped: its row is 0 when Dirichlet rows are masked), the node
             // i = NX-1 (traction-free) sits on one of the lanes 1 .. 62 of the last tile
             const bool face_lo = (w.faces & 1) && i == 0, face_hi = (w.faces & 1) && i == g.NX - 1;
-            const bool wave_has_face = (w.faces & 1) && (xt == 0 || (xt + 1) * fg.xt >= g.NX - 1);      // wave-uniform
+            const bool wave_has_face = (w.faces & 1) && (xt == 0 || (xt + 1) * kElXt >= g.NX - 1);      // wave-uniform
             const double kup = face_hi ? 0.0 : 1.0, klo = face_lo ? 0.0 : 1.0;      // no coupling across the face (the lanes beyond hold finite pad values)
-            const bool out_x = (lane >= 1 && lane <= fg.xt && i <= g.NX - ((w.faces & 1) ? 1 : 2)) || face_lo;
+            const bool out_x = (lane >= 1 && lane <= kElXt && i <= g.NX - ((w.faces & 1) ? 1 : 2)) || face_lo;
             const int rows_out = ghost_wave ? 0 : min(RY, g.NY - 1 - j0);      // owned rows inside the grid (wave-uniform)
             // lanes beyond the padded row (the last 62-node tile overshoots: 558 columns for a 513-node row) read the row's last pad
             // entry instead of the next row's data: same cache line as real data, no traffic of their own (9 % of the loads at
@@ -571,7 +570,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             const bool ylo_wave = yz && !ghost_wave && yt == 0;                       // row 0 = the halo row below the first row tile
             const int r_hi = (yz && !ghost_wave && yt == fg.nty - 1) ? g.NY - j0 : 0;       // held-row index of the row NY-1 (2 .. RY+1)
             const bool zlo_chunk = zf && fg.full_lo && zc == 0, zhi_chunk = zf && fg.full_hi && lk1 == fg.lke;
-            const bool out_f = lane >= 1 && lane <= fg.xt && i >= 1 && i <= g.NX - 2;      // face nodes proper (the x-ends are edges of the box)
+            const bool out_f = lane >= 1 && lane <= kElXt && i >= 1 && i <= g.NX - 2;      // face nodes proper (the x-ends are edges of the box)
             auto face_finish = [&](long long o, const double* c0, double* y, const double* U, const double* Lw) __attribute__((always_inline)) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
@@ -717,310 +716,6 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                 load_plane(lkf, PA);
                 load_plane(lkf - 1, PB);
                 zface_hi(lkf, PA, PB);
-            }
-        }
-    }
-    const double tot = block_sum_256(acc, sRed);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The same marching scheme with TWO adjacent nodes per lane (16-byte loads and stores).  tools/marchbw.hip moves the bare access pattern of
-// the one-node kernel (8 B per lane, 512-B segments, 62-node tiles) at 3.8 TB/s — what k_el_fast reaches — and the two-node pattern with
-// non-temporal 16-byte stores at 5.6-5.9 TB/s.  A lane holds the nodes a = i, b = i + 1 (i even: 16-byte aligned) of every held row as
-// double2; lanes 0 and 63 are x-halo lanes, a wave owns 124 columns.  x-shifts: node a takes U from b of the same lane and Lw from b of the
-// lane below; node b takes U from a of the lane above and Lw from a of the same lane: 6 DPP pairs per two nodes.  Everything else — plane
-// rotation by name, y hand-off through LDS, faces, weights — is k_el_fast's, per node.  x-faces must be folded in (faces bit 0).
-struct ElV3 { double v[3]; };
-__device__ __forceinline__ ElV3 el_node(const double2 (*P)[3], int r, int n) {
-    ElV3 o;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o.v[c] = n ? P[r][c].y : P[r][c].x;
-    return o;
-}
-__device__ __forceinline__ ElV3 el_add(const ElV3& p, const ElV3& q) { return ElV3{{p.v[0] + q.v[0], p.v[1] + q.v[1], p.v[2] + q.v[2]}}; }
-__device__ __forceinline__ ElV3 el_sub(const ElV3& p, const ElV3& q) { return ElV3{{p.v[0] - q.v[0], p.v[1] - q.v[1], p.v[2] - q.v[2]}}; }
-
-// PF: a fourth plane buffer receives plane k+2 while plane k is computed (k_el_fast's scheme); without it three buffers rotate, a wave
-// requests plane k+2 into the buffer of plane k-1 as soon as that one is dead and waits for it at once — other waves cover the latency —
-// and the registers of one plane (36 with two nodes per lane and RY = 1) are free
-template <int RY, bool YX, bool ZF, bool PF, bool NTS>
-__global__ __launch_bounds__(256, 2) void k_el_fast2(ElArgs a, ElW18 wk, ElFastGeom fg) {
-    typedef double el_d2 __attribute__((ext_vector_type(2)));
-    const ElW36 w = el_expand_weights(wk);
-    __shared__ double sTab[2 * 4 * 2 * 3 * 128 + 32];         // boundary role: the class table (3645); marching: y hand-off block + face numbers
-    __shared__ unsigned sMask[27];
-    __shared__ double sRed[8];
-    constexpr int RH = RY + 2;
-    constexpr int GOFF = 2 * 4 * 2 * 3 * 128;
-    const GridDev& g = a.g;
-    double acc = 0.0;
-    const int bidx = fg.bnd_last ? ((int)blockIdx.x >= fg.nb_fast ? (int)blockIdx.x - fg.nb_fast : -1) : ((int)blockIdx.x < fg.nb_bnd ? (int)blockIdx.x : -1);
-    if (bidx >= 0) {
-        acc = el_boundary_role(a, w.faces, fg, bidx, sTab, sMask);
-    } else {
-        const int lane = threadIdx.x & 63;
-        int bm = fg.bnd_last ? (int)blockIdx.x : (int)blockIdx.x - fg.nb_bnd;
-        if ((fg.nb_fast & 7) == 0) bm = (bm & 7) * (fg.nb_fast >> 3) + (bm >> 3);
-        if (threadIdx.x < 27) sTab[GOFF + threadIdx.x] = fg.gf[threadIdx.x];
-        __syncthreads();
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        int xt, yt, zc;
-        if (YX) {
-            xt = bm % fg.ntx;
-            yt = ((bm / fg.ntx) % fg.nyg) * 4 + wv;
-            zc = fg.nzc - 1 - bm / (fg.ntx * fg.nyg);
-        } else {
-            const int wid = bm * 4 + wv;
-            xt = wid % fg.ntx;
-            yt = (wid / fg.ntx) % fg.nty;
-            zc = fg.nzc - 1 - wid / (fg.ntx * fg.nty);
-        }
-        const bool ghost_wave = YX && yt >= fg.nty;
-        if (ghost_wave) yt = fg.nty - 1;
-        const int ia = xt * 124 + 2 * lane - 2;               // node a of this lane (b = ia + 1); lanes 0 and 63: x-halo only
-        const int j0 = 1 + yt * RY;
-        const int lk0 = fg.lkb + zc * fg.zlen;
-        const int lk1 = min(lk0 + fg.zlen, fg.lke);
-        if (zc >= 0 && lk0 < lk1) {
-            const bool inner = lane >= 1 && lane <= 62;
-            const int in_[2] = {ia, ia + 1};
-            // per-lane node flags in ONE register (as separate masks and factors they cost 8 VGPRs + 8 SGPR pairs that this kernel does not have):
-            // bit n: node n is stored by interior rows; 2 + n: by face rows / planes (the x-ends are edges of the box); 4 + n: node n is the face
-            // x = 0; 6 + n: the face x = NX-1
-            int nflags = 0;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                if (inner && in_[n] >= 0 && in_[n] <= g.NX - 1) nflags |= 1 << n;
-                if (inner && in_[n] >= 1 && in_[n] <= g.NX - 2) nflags |= 4 << n;
-                if (in_[n] == 0) nflags |= 16 << n;
-                if (in_[n] == g.NX - 1) nflags |= 64 << n;
-            }
-            const bool wave_has_face = xt == 0 || (xt + 1) * 124 > g.NX - 1;       // wave-uniform
-            const int rows_out = ghost_wave ? 0 : min(RY, g.NY - 1 - j0);
-            // addresses: rows are contiguous, so ia = -2 (first tile, lane 0) reads the pad of the row before — finite, never used; beyond
-            // the padded row the pair is clamped to the row's last pad pair
-            const long long col = (long long)(j0 - 1) * g.PX + (ia + 1 < g.PX ? ia : g.PX - 2);
-            double2 PA[RH][3], PB[RH][3], PC[RH][3], PD[PF ? RH : 1][3];
-            auto ld2 = [&](const double* p) __attribute__((always_inline)) { return *reinterpret_cast<const double2*>(p); };
-            auto load_plane = [&](int lk, double2 (*P)[3]) __attribute__((always_inline)) {
-                const long long base = (long long)lk * g.PP + col;
-#pragma unroll
-                for (int r = 0; r < RH; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) P[r][c] = ld2(a.in + c * a.stride + base + (long long)r * g.PX);
-            };
-            const bool lo_global = !YX || wv == 0;
-            const bool hi_global = !YX || wv == 3 || (yt + 1 >= fg.nty);
-            auto load_own = [&](int lk, double2 (*P)[3]) __attribute__((always_inline)) {
-                const long long base = (long long)lk * g.PP + col;
-#pragma unroll
-                for (int r = 1; r <= RY; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) P[r][c] = ld2(a.in + c * a.stride + base + (long long)r * g.PX);
-                if (lo_global) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) P[0][c] = ld2(a.in + c * a.stride + base);
-                }
-                if (hi_global) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) P[RH - 1][c] = ld2(a.in + c * a.stride + base + (long long)(RH - 1) * g.PX);
-                }
-            };
-            double2* sY = reinterpret_cast<double2*>(sTab);   // [2][4 waves][first | last own row][3][64] pairs
-            auto face_g = [&](int ax) __attribute__((always_inline)) {
-                int off = GOFF + 9 * ax;
-                asm volatile("" : "+v"(off));
-                return reinterpret_cast<const double (*)[3]>(sTab + off);
-            };
-            auto y_exchange = [&](int ybuf, double2 (*P)[3]) __attribute__((always_inline)) {
-                double2* mine = sY + ((ybuf * 4 + wv) * 2) * 192;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    mine[c * 64 + lane] = P[1][c];
-                    mine[192 + c * 64 + lane] = P[RY][c];
-                }
-                __syncthreads();
-                if (!lo_global) {
-                    const double2* below = sY + ((ybuf * 4 + wv - 1) * 2 + 1) * 192;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) P[0][c] = below[c * 64 + lane];
-                }
-                if (!hi_global) {
-                    const double2* above = sY + ((ybuf * 4 + wv + 1) * 2) * 192;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) P[RH - 1][c] = above[c * 64 + lane];
-                }
-            };
-            const bool yz = (w.faces & 2) != 0, zf = ZF && (w.faces & 4) != 0;
-            const bool ylo_wave = yz && !ghost_wave && yt == 0;
-            const int r_hi = (yz && !ghost_wave && yt == fg.nty - 1) ? g.NY - j0 : 0;
-            const bool zlo_chunk = zf && fg.full_lo && zc == 0, zhi_chunk = zf && fg.full_hi && lk1 == fg.lke;
-            // x-shifts of the two accumulated 3-vectors, then the stores (o = offset of node a; mask = which of the two nodes are stored)
-            auto finish = [&](long long o, const ElV3* c0, ElV3* y, const ElV3* U, const ElV3* Lw, int mshift, bool xfaces,
-                              const ElV3* corr) __attribute__((always_inline)) {
-                const bool m0 = (nflags >> mshift) & 1, m1 = (nflags >> (mshift + 1)) & 1;
-                double kup[2] = {1.0, 1.0}, klo[2] = {1.0, 1.0};
-                if (xfaces) {
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        klo[n] = (nflags & (16 << n)) ? 0.0 : 1.0;
-                        kup[n] = (nflags & (64 << n)) ? 0.0 : 1.0;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double up_a = U[1].v[c], lo_a = el_dpp_lower(Lw[1].v[c]);
-                    const double up_b = el_dpp_upper(U[0].v[c]), lo_b = Lw[0].v[c];
-                    if (xfaces) {
-                        // face nodes: in-face part halved + the antisymmetric remainder, no coupling across the face (factors, not selects:
-                        // the shifts must run with every lane active)
-                        const double fa = 0.5 * (kup[0] + klo[0]), ga = klo[0] - kup[0], fb = 0.5 * (kup[1] + klo[1]), gb = klo[1] - kup[1];
-                        y[0].v[c] = fa * y[0].v[c] + (kup[0] * up_a + klo[0] * lo_a) + ga * corr[0].v[c];
-                        y[1].v[c] = fb * y[1].v[c] + (kup[1] * up_b + klo[1] * lo_b) + gb * corr[1].v[c];
-                        if (a.mask_dirichlet) {
-                            if (nflags & 16) y[0].v[c] = 0.0;
-                            if (nflags & 32) y[1].v[c] = 0.0;
-                        }
-                    } else {
-                        y[0].v[c] += up_a + lo_a;
-                        y[1].v[c] += up_b + lo_b;
-                    }
-                }
-                if (m0 && m1) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const el_d2 t = {y[0].v[c], y[1].v[c]};
-                        if constexpr (NTS) __builtin_nontemporal_store(t, reinterpret_cast<el_d2*>(a.out + c * a.stride + o));      // not read again by this launch
-                        else *reinterpret_cast<el_d2*>(a.out + c * a.stride + o) = t;
-                        acc += c0[0].v[c] * y[0].v[c] + c0[1].v[c] * y[1].v[c];
-                    }
-                } else if (m0 || m1) {
-                    const int n = m0 ? 0 : 1;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        a.out[c * a.stride + o + n] = n ? y[1].v[c] : y[0].v[c];
-                        acc += (n ? c0[1].v[c] * y[1].v[c] : c0[0].v[c] * y[0].v[c]);
-                    }
-                }
-            };
-            auto zface = [&](auto high, int lk, double2 (*P0)[3], double2 (*Pin)[3]) __attribute__((always_inline)) {
-                constexpr bool HIGH = decltype(high)::value;
-                const long long obase = (long long)lk * g.PP + col;
-#pragma unroll
-                for (int r = 1; r <= RY; ++r) {
-                    ElV3 y[2], U[2], Lw[2], c0[2];
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        c0[n] = el_node(P0, r, n);
-                        const ElV3 e1p = el_node(P0, r + 1, n), e1m = el_node(P0, r - 1, n), n0 = el_node(Pin, r, n), n1 = el_node(Pin, HIGH ? r - 1 : r + 1, n);
-                        el_face_node<2, HIGH>(w, face_g(2), c0[n].v, e1p.v, e1m.v, n0.v, n1.v, y[n].v, U[n].v, Lw[n].v);
-                    }
-                    if (r <= rows_out) finish(obase + (long long)r * g.PX, c0, y, U, Lw, 2, false, nullptr);
-                }
-            };
-            auto step = [&](int lk, double2 (*Pm)[3], double2 (*P0)[3], double2 (*Pp)[3], double2 (*Pn)[3]) __attribute__((always_inline)) {
-                if (YX) {
-                    if (PF) load_own(min(lk + 2, lk1), Pn);
-                    if (lk > lk0) y_exchange((lk - lk0) & 1, Pp);
-                } else if (PF) {
-                    load_plane(min(lk + 2, lk1), Pn);
-                }
-                const long long obase = (long long)lk * g.PP + col;
-#pragma unroll
-                for (int r = 1; r <= RY; ++r) {
-                    // the shifted parts of both nodes first, then the unshifted part node by node: fewer 3-vectors alive at once (two nodes per
-                    // lane leave little room next to the four plane buffers)
-                    ElV3 y[2], U[2], Lw[2], c0[2], corr[2];
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        c0[n] = el_node(P0, r, n);
-                        U[n] = ElV3{{0.0, 0.0, 0.0}};
-                        el_sym6(w.ax[0], c0[n].v, U[n].v);
-                        Lw[n] = U[n];
-                        el_off3(w.dg[0], el_node(P0, r + 1, n).v, U[n].v);
-                        el_off3(w.dg[1], el_node(Pp, r, n).v, U[n].v);
-                        el_off3(w.dg[3], el_node(Pp, r + 1, n).v, U[n].v);
-                        el_off3(w.dg[0], el_node(P0, r - 1, n).v, Lw[n].v);
-                        el_off3(w.dg[1], el_node(Pm, r, n).v, Lw[n].v);
-                        el_off3(w.dg[3], el_node(Pm, r - 1, n).v, Lw[n].v);
-                    }
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        y[n] = ElV3{{0.0, 0.0, 0.0}};
-                        el_sym6(w.c, c0[n].v, y[n].v);
-                        el_sym6(w.ax[1], el_add(el_node(P0, r + 1, n), el_node(P0, r - 1, n)).v, y[n].v);
-                        el_sym6(w.ax[2], el_add(el_node(Pp, r, n), el_node(Pm, r, n)).v, y[n].v);
-                        el_off3(w.dg[2], el_add(el_node(Pp, r + 1, n), el_node(Pm, r - 1, n)).v, y[n].v);
-                        if (wave_has_face) {
-                            const double (*G0)[3] = face_g(0);
-                            corr[n] = ElV3{{0.0, 0.0, 0.0}};
-                            el_rem<0>(G0[0], 1.0, el_sub(el_node(P0, r + 1, n), el_node(P0, r - 1, n)).v, corr[n].v);
-                            el_rem<0>(G0[1], 1.0, el_sub(el_node(Pp, r, n), el_node(Pm, r, n)).v, corr[n].v);
-                            el_rem<0>(G0[2], 1.0, el_sub(el_node(Pp, r + 1, n), el_node(Pm, r - 1, n)).v, corr[n].v);
-                        }
-                    }
-                    if (r <= rows_out) finish(obase + (long long)r * g.PX, c0, y, U, Lw, 0, wave_has_face, corr);
-                }
-                if (ylo_wave) {
-                    ElV3 y[2], U[2], Lw[2], c0[2];
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        c0[n] = el_node(P0, 0, n);
-                        el_face_node<1, false>(w, face_g(1), c0[n].v, el_node(Pp, 0, n).v, el_node(Pm, 0, n).v, el_node(P0, 1, n).v, el_node(Pp, 1, n).v,
-                                               y[n].v, U[n].v, Lw[n].v);
-                    }
-                    finish(obase, c0, y, U, Lw, 2, false, nullptr);
-                }
-                if (r_hi > 0) {
-#pragma unroll
-                    for (int r = 2; r < RH; ++r)
-                        if (r == r_hi) {
-                            ElV3 y[2], U[2], Lw[2], c0[2];
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) {
-                                c0[n] = el_node(P0, r, n);
-                                el_face_node<1, true>(w, face_g(1), c0[n].v, el_node(Pp, r, n).v, el_node(Pm, r, n).v, el_node(P0, r - 1, n).v,
-                                                      el_node(Pm, r - 1, n).v, y[n].v, U[n].v, Lw[n].v);
-                            }
-                            finish(obase + (long long)r * g.PX, c0, y, U, Lw, 2, false, nullptr);
-                        }
-                }
-                if (!PF && lk + 1 < lk1) {                    // plane lk-1 is dead: its buffer takes plane lk+2
-                    if (YX) load_own(lk + 2, Pm);
-                    else load_plane(lk + 2, Pm);
-                }
-            };
-            load_plane(lk0 - 1, PA);
-            load_plane(lk0, PB);
-            load_plane(lk0 + 1, PC);
-            if constexpr (ZF)
-                if (zlo_chunk) zface(std::false_type{}, lk0 - 1, PA, PB);
-            if constexpr (PF) {
-                for (int lk = lk0; lk < lk1; lk += 4) {
-                    step(lk, PA, PB, PC, PD);
-                    if (lk + 1 >= lk1) break;
-                    step(lk + 1, PB, PC, PD, PA);
-                    if (lk + 2 >= lk1) break;
-                    step(lk + 2, PC, PD, PA, PB);
-                    if (lk + 3 >= lk1) break;
-                    step(lk + 3, PD, PA, PB, PC);
-                }
-            } else {
-                for (int lk = lk0; lk < lk1; lk += 3) {
-                    step(lk, PA, PB, PC, PD);
-                    if (lk + 1 >= lk1) break;
-                    step(lk + 1, PB, PC, PA, PD);
-                    if (lk + 2 >= lk1) break;
-                    step(lk + 2, PC, PA, PB, PD);
-                }
-            }
-            if constexpr (ZF) if (zhi_chunk) {
-                int lkf = lk1;
-                asm volatile("" : "+s"(lkf));
-                load_plane(lkf, PA);
-                load_plane(lkf - 1, PB);
-                zface(std::true_type{}, lkf, PA, PB);
             }
         }
     }
@@ -1649,10 +1344,7 @@ void el_fast_geometry(ElSession* s) {
     fg.lke = g.nkl - fg.full_hi;
     const int planes = std::max(0, fg.lke - fg.lkb);
     const bool xface = s->w36.faces != 0;
-    fg.xt = s->ctx->el_fast_xt == 48 ? 48 : 62;
-    fg.ntx = (g.NX - (xface ? 1 : 2) + fg.xt - 1) / fg.xt;
-    fg.npl = (s->ctx->el_fast_npl == 2 && xface) ? 2 : 1;       // two nodes per lane: 124 owned columns per wave, the x-faces inside
-    if (fg.npl == 2) fg.ntx = (g.NX + 123) / 124;
+    fg.ntx = (g.NX - (xface ? 1 : 2) + kElXt - 1) / kElXt;
     fg.nty = (g.NY - 2 + RY - 1) / RY;
     fg.nyg = (fg.nty + 3) / 4;
     const bool yx = s->ctx->el_fast_yx != 0;
@@ -1675,9 +1367,6 @@ void el_fast_geometry(ElSession* s) {
     }
     fg.nb_bnd = (int)std::min<long long>((fg.nbnd + 255) / 256, 2LL * s->ctx->num_cu);      // grid-stride: the 29 KB table is loaded per workgroup
     fg.bnd_last = s->ctx->el_bnd_last != 0 ? 1 : 0;
-    // timing aid (results are wrong with it): 1 = marching part only, 2 = boundary pass only
-    if (s->ctx->el_debug_part == 1) { fg.nb_bnd = 0; fg.nbnd = 0; }
-    if (s->ctx->el_debug_part == 2) { fg.nb_fast = 0; fg.nzc = 0; }
     fg.mask = s->d_mask;
     fg.gf = reinterpret_cast<const double*>(s->d_mask + 32);
 }
@@ -1701,16 +1390,7 @@ int el_apply(ElSession* s, const ElArgs& a, int mode) {
         const bool nts = el_vec_nt(s);
         const int ry = s->fast_ry >= 2 ? 2 : 1;
         const int key = (ry == 2 ? 8 : 0) | (yx ? 4 : 0) | (zf ? 2 : 0) | (nts ? 1 : 0);
-        if (fg.npl == 2) {
-            switch (key) {
-#define EL_CASE2(K, RYv, YXv, ZFv, NTv) case K: launch(k_el_fast2<RYv, YXv, ZFv, false, NTv>); break;
-                EL_CASE2(0, 1, false, false, false) EL_CASE2(1, 1, false, false, true) EL_CASE2(2, 1, false, true, false) EL_CASE2(3, 1, false, true, true)
-                EL_CASE2(4, 1, true, false, false) EL_CASE2(5, 1, true, false, true) EL_CASE2(6, 1, true, true, false) EL_CASE2(7, 1, true, true, true)
-                EL_CASE2(8, 2, false, false, false) EL_CASE2(9, 2, false, false, true) EL_CASE2(10, 2, false, true, false) EL_CASE2(11, 2, false, true, true)
-                EL_CASE2(12, 2, true, false, false) EL_CASE2(13, 2, true, false, true) EL_CASE2(14, 2, true, true, false) EL_CASE2(15, 2, true, true, true)
-#undef EL_CASE2
-            }
-        } else {
+        {
             switch (key) {
 #define EL_CASE1(K, RYv, YXv, ZFv, NTv) case K: launch(k_el_fast<RYv, YXv, ZFv, NTv>); break;
                 EL_CASE1(0, 1, false, false, false) EL_CASE1(1, 1, false, false, true) EL_CASE1(2, 1, false, true, false) EL_CASE1(3, 1, false, true, true)
@@ -2193,11 +1873,14 @@ extern "C" int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* 
     a.in = s.x;
     a.out = s.q;
     a.mask_dirichlet = 0;
-    hipEvent_t e0, e1;
-    PG_HIP(ctx, hipEventCreate(&e0));
-    PG_HIP(ctx, hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (d_Ke) (void)hipFree(d_Ke);
+        return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipEventCreate failed");
+    }
     int rc = PDEGPU_OK;
-    for (int i = -1; i < reps && rc == PDEGPU_OK; ++i) {
+    for (int i = -1; i < reps && rc == PDEGPU_OK; ++i) {          // (reps >= 1 is checked above: e0 is always recorded)
         if (i == 0) (void)hipEventRecord(e0, ctx->stream);
         rc = use_mfma ? el_apply_mfma(&s, s.x, s.q, d_Ke) : el_apply(&s, a, APPLY_PLAIN);
     }

@@ -29,7 +29,6 @@ struct pdegpu_session {
     int npt = 15;
     double hA[27 * 27];
     DevVec x, r, p[2], q, b;
-    DevArena arena;                // vec_contig >= 2: the six vectors above are carved from this one block
     double place_ms_default = 0.0, place_ms_best = 0.0;      // tune_x_placement: K1 with the default buffer as x / with the chosen one
     int place_choice = 0;          // which of the six allocations became x (0 = the default)
     DevVec xprev;                  // u^{n-1} of a transient solve (allocated on first use)
@@ -37,13 +36,10 @@ struct pdegpu_session {
     double* d_scal = nullptr;
     double* d_part = nullptr;       // [2][npart]: per-workgroup partials; the second half takes K2's in the lazy loop
     int npart = 0;
-    unsigned* d_counter = nullptr;  // dot_finish ticket counter
     double* d_dense = nullptr;
     double* h_pin = nullptr;       // pinned host scalars
     std::vector<hipEvent_t> events;
-    CgGraph cg_graph;
     int last_iters = 0;            // CG iterations of the previous linear solve of this session (first poll of the next one)
-    long long eager_iters = 0;     // iterations launched eagerly so far (occupancy queries etc. are done)
     // per-call kernel timing of the stepwise protocol (pdegpu_session_set_timing): event pairs around every k1 part / k2 launch
     bool timing = false;
     std::vector<hipEvent_t> tev;   // pairs: [2 i] start, [2 i + 1] stop
@@ -232,7 +228,6 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     if (a.bnd_n > 0x7fffffffLL) return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "hybrid path: more than 2^31 boundary nodes");
     const int n1 = li_fast ? li_fast->grid : 0;
     a.partials = a.partials + n1;                 // appended to the marching launch's (K2: wherever the caller keeps its r.r partials)
-    a.dot_which = -1;
     LaunchInfo l2;
     PG_TRY(stencil_general(s->ctx, a, mode, &l2));
     if (li_fast) li_fast->grid = n1 + l2.grid;
@@ -247,9 +242,7 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     a.in_shift = shift;
     a.out = out;
     a.partials = s->d_part;
-    a.counter = s->d_counter;
     a.scal = s->d_scal;
-    a.dot_which = -1;
     a.mask_dirichlet = mask;
     const double* htab = which == 0 ? s->hA : s->tabs.h_tabM;
     a.tabA = which == 0 ? s->tabs.d_tabA : s->tabs.d_tabM;
@@ -277,10 +270,6 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     return stencil_general(s->ctx, a, APPLY_PLAIN, nullptr);
 }
 
-// the in-launch dot completion (tunable inlaunch_dot) applies to sessions whose dot-producing step is ONE launch; hybrid and
-// 2-D tile sessions append a second launch's partials, so they always use the reduce launch / the prologue sum
-bool use_inlaunch(const pdegpu_session* s) { return s->ctx->inlaunch_dot != 0 && !s->hybrid && !s->plane2d && !s->tile3d; }
-
 // out = P (rhs - A in), partials of out.out
 int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* out, LaunchInfo* li) {
     StencilArgs a{};
@@ -289,9 +278,7 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     a.rhs = rhs;
     a.out = out;
     a.partials = s->d_part;
-    a.counter = s->d_counter;
     a.scal = s->d_scal;
-    a.dot_which = (s->weighted || !use_inlaunch(s)) ? -1 : 1;   // PCG forms rho = r.z in the follow-up k_k2_pc pass
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     a.off_mask = table_mask(s->hA);
@@ -305,7 +292,6 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
         a.npt = s->npt;
         a.free_x = s->hybrid ? (s->ctx->hybrid_fx ? 2 : 1) : 0;
         a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
-        if (s->hybrid) a.dot_which = -1;
         PG_TRY(stencil_fast(s->ctx, a, APPLY_RESIDUAL, li));
         return s->hybrid ? hybrid_boundary(s, a, APPLY_RESIDUAL, li) : PDEGPU_OK;
     }
@@ -341,8 +327,6 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
     a.out = k2_is_stencil(s) ? nullptr : s->q.v;     // 64-B variant: q is recomputed by K2
     a.scal = s->d_scal;
     a.partials = s->d_part + part_off;
-    a.counter = s->d_counter;
-    a.dot_which = use_inlaunch(s) ? 0 : -1;
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     a.off_mask = table_mask(s->hA);
@@ -350,19 +334,16 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
     if (part) {
         a.lk_lo = lk_lo;
         a.lk_hi = lk_hi;
-        a.dot_which = -1;
     }
     int rc;
     if (s->plane2d) {
         a.g = s->g;
         plane2d_weights(s->hA, a.w);
-        a.dot_which = -1;
         rc = stencil_plane2d(s->ctx, a, APPLY_CG_K1, li);
     } else if (s->tile3d) {
         a.g = s->g;
         fast_weights(s->hA, a.w, false);
         a.npt = s->npt;
-        a.dot_which = -1;
         rc = stencil_tile3d(s->ctx, a, APPLY_CG_K1, li);
     } else if (s->fast) {
         a.g = s->gk;
@@ -370,7 +351,6 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
         a.npt = s->npt;
         a.free_x = s->hybrid ? (s->ctx->hybrid_fx ? 2 : 1) : 0;
         a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
-        if (s->hybrid) a.dot_which = -1;
         rc = stencil_fast(s->ctx, a, APPLY_CG_K1, li);
         if (rc == PDEGPU_OK && s->hybrid) rc = hybrid_boundary(s, a, APPLY_CG_K1, li);
     } else {
@@ -393,20 +373,16 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         a.out = s->r.v;
         a.scal = s->d_scal;
         a.partials = part_out;
-        a.counter = s->d_counter;
-        a.dot_which = use_inlaunch(s) ? 1 : -1;
         a.mask_dirichlet = 1;
         if (s->plane2d) {
             a.g = s->g;
             plane2d_weights(s->hA, a.w);
-            a.dot_which = -1;
             return stencil_plane2d(s->ctx, a, APPLY_CG_K2, li);
         }
         if (s->tile3d) {
             a.g = s->g;
             fast_weights(s->hA, a.w, false);
             a.npt = s->npt;
-            a.dot_which = -1;
             return stencil_tile3d(s->ctx, a, APPLY_CG_K2, li);
         }
         a.g = s->gk;
@@ -415,7 +391,6 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         if (!s->hybrid) return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
         a.free_x = s->ctx->hybrid_fx ? 2 : 1;
         a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
-        a.dot_which = -1;
         a.tabA = s->tabs.d_tabA;
         a.off_mask = table_mask(s->hA);
         LaunchInfo lf;
@@ -424,25 +399,18 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         if (li) *li = lf;
         return PDEGPU_OK;
     }
-    // nullptr: partials only, reduced by k_reduce (always so when K1's dot has a second launch to wait for: hybrid / 2-D tile sessions)
-    unsigned* cnt = use_inlaunch(s) ? s->d_counter : nullptr;
-    if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, cnt, 1, li);
-    return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, part_out, cnt, li, di);
+    if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 1, li);
+    return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, part_out, li, di);
 }
 
 // after a RESIDUAL pass: PCG needs z = D^-1 r and rho = r.z in place of r.r
-// completes the dot product of the launch described by li: by default a one-workgroup fixed-order reduce launch
-// (k_reduce); with the inlaunch_dot tunable the producing kernel has already done it (dot_finish.h) unless its grid
-// was empty (a slab without free planes), in which case the sum 0 still has to be recorded
+// completes the dot product of the launch described by li: a one-workgroup fixed-order reduce launch (k_reduce); an empty grid
+// (a slab without free planes) records the sum 0
 int empty_dot(pdegpu_session* s, const LaunchInfo& li, int which) {
-    if (use_inlaunch(s) && li.grid > 0) return PDEGPU_OK;
     return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, which, 1);
 }
 int residual_finish(pdegpu_session* s, LaunchInfo* li) {
-    if (s->weighted) {
-        unsigned* cnt = use_inlaunch(s) ? s->d_counter : nullptr;
-        PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, cnt, 0, li));
-    }
+    if (s->weighted) PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 0, li));
     return empty_dot(s, *li, 1);
 }
 
@@ -464,6 +432,14 @@ int set_bc_ext(pdegpu_session* s, double* x, double fill, const double* nodal_de
 // ---------------------------------------------------------------------------------------------
 extern "C" const char* pdegpu_version(void) { return "pdegpu 0.1 (gfx950)"; }
 
+// every tunable of a context: PDEGPU_<KEY> in the environment at pdegpu_create, pdegpu_set_tunable afterwards (table in include/pdegpu.h)
+static const char* const kTunableKeys[] = {
+    "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
+    "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
+    "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
+    "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
+    "el_fast_waves"};
+
 extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
     if (!out) return PDEGPU_EINVAL;
     *out = nullptr;
@@ -484,7 +460,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDEGPU_EHIP; }
         ctx->own_stream = true;
     }
-    for (const char* key : {"fast_ry", "fast_nt", "fast_ex", "fast_ex_all", "fast_nt_in", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear", "place_tune", "vec_contig", "fast_occ_plain", "fast_occ_res", "fast_occ_k1", "fast_occ_k2", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "use_graph", "el_grid_mult", "inlaunch_dot", "direct_1d", "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes", "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_debug_part", "el_bnd_last", "el_fast_nt", "el_fast_xt", "el_fast_npl", "el_fast_ry", "el_fast_waves"}) {
+    for (const char* key : kTunableKeys) {
         std::string env = std::string("PDEGPU_") + key;
         for (auto& ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char* v = getenv(env.c_str())) (void)pdegpu_set_tunable(ctx, key, atoi(v));
@@ -498,7 +474,6 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_ry")) return &ctx->fast_ry;
     if (!strcmp(key, "fast_nt")) return &ctx->fast_nt;
     if (!strcmp(key, "fast_ex")) return &ctx->fast_ex;
-    if (!strcmp(key, "fast_ex_all")) return &ctx->fast_ex_all;
     if (!strcmp(key, "fast_pf")) return &ctx->fast_pf;
     if (!strcmp(key, "fast_zlen")) return &ctx->fast_zlen;
     if (!strcmp(key, "fast_cfg_plain")) return &ctx->fast_cfg[APPLY_PLAIN];
@@ -507,19 +482,12 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "fast_cfg_k2")) return &ctx->fast_cfg[APPLY_CG_K2];
     if (!strcmp(key, "fast_linear")) return &ctx->fast_linear;
     if (!strcmp(key, "place_tune")) return &ctx->place_tune;
-    if (!strcmp(key, "vec_contig")) return &ctx->vec_contig;
-    if (!strcmp(key, "fast_occ_plain")) return &ctx->fast_occ[APPLY_PLAIN];
-    if (!strcmp(key, "fast_occ_res")) return &ctx->fast_occ[APPLY_RESIDUAL];
-    if (!strcmp(key, "fast_occ_k1")) return &ctx->fast_occ[APPLY_CG_K1];
-    if (!strcmp(key, "fast_occ_k2")) return &ctx->fast_occ[APPLY_CG_K2];
     if (!strcmp(key, "tile3d_plain")) return &ctx->tile3d_plain;
     if (!strcmp(key, "fast_wg_per_cu")) return &ctx->fast_wg_per_cu;
     if (!strcmp(key, "fast_wg_per_cu_k2")) return &ctx->fast_wg_per_cu_k2;
     if (!strcmp(key, "grid_mult")) return &ctx->grid_mult;
     if (!strcmp(key, "k2_grid_mult")) return &ctx->k2_grid_mult;
     if (!strcmp(key, "cg_variant")) return &ctx->cg_variant;
-    if (!strcmp(key, "use_graph")) return &ctx->use_graph;
-    if (!strcmp(key, "inlaunch_dot")) return &ctx->inlaunch_dot;
     if (!strcmp(key, "el_grid_mult")) return &ctx->el_grid_mult;
     if (!strcmp(key, "direct_1d")) return &ctx->direct_1d;
     if (!strcmp(key, "lazy_dot")) return &ctx->lazy_dot;
@@ -527,7 +495,6 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "hybrid_bc")) return &ctx->hybrid_bc;
     if (!strcmp(key, "hybrid_fx")) return &ctx->hybrid_fx;
     if (!strcmp(key, "hybrid_k2")) return &ctx->hybrid_k2;
-    if (!strcmp(key, "fast_nt_in")) return &ctx->fast_nt_in;
     if (!strcmp(key, "plane2d")) return &ctx->plane2d;
     if (!strcmp(key, "persist2d")) return &ctx->persist2d;
     if (!strcmp(key, "persist2d_sr")) return &ctx->persist2d_sr;
@@ -539,12 +506,9 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "el_fast_ry")) return &ctx->el_fast_ry;
     if (!strcmp(key, "el_fast_yx")) return &ctx->el_fast_yx;
     if (!strcmp(key, "el_fast_xface")) return &ctx->el_fast_xface;
-    if (!strcmp(key, "el_debug_part")) return &ctx->el_debug_part;
     if (!strcmp(key, "el_bnd_last")) return &ctx->el_bnd_last;
     if (!strcmp(key, "el_fast_yzface")) return &ctx->el_fast_yzface;
     if (!strcmp(key, "el_fast_nt")) return &ctx->el_fast_nt;
-    if (!strcmp(key, "el_fast_xt")) return &ctx->el_fast_xt;
-    if (!strcmp(key, "el_fast_npl")) return &ctx->el_fast_npl;
     if (!strcmp(key, "el_fast_waves")) return &ctx->el_fast_waves;
     return nullptr;
 }
@@ -582,17 +546,14 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     vec_free(&s->x); vec_free(&s->r); vec_free(&s->p[0]); vec_free(&s->p[1]); vec_free(&s->q); vec_free(&s->b);
-    arena_free(&s->arena);
     tables_free(&s->tabs);
     if (s->d_scal) (void)hipFree(s->d_scal);
     if (s->d_part) (void)hipFree(s->d_part);
-    if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_dense) (void)hipFree(s->d_dense);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->tev) (void)hipEventDestroy(e);
     persist2d_free(s->p2d);
-    s->cg_graph.reset();
     for (double* b0 : s->ell_base)
         if (b0) (void)hipFree(b0);
     vec_free(&s->z);
@@ -623,8 +584,6 @@ int time_k1_roles(pdegpu_session* s, const int32_t* roles4, int reps, double* av
     a.out = nullptr;
     a.scal = s->d_scal;
     a.partials = s->d_part;
-    a.counter = s->d_counter;
-    a.dot_which = -1;
     a.mask_dirichlet = 1;
     fast_weights(s->hA, a.w, s->gk.flat2d != 0);
     a.npt = s->npt;
@@ -726,34 +685,13 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     s->tile3d = s->fast && !s->hybrid && s->g.dim == 3 && s->g.k0 == 0 && s->g.nkl == s->g.NZ && ctx->tile3d_max_nodes > 0 &&
                 (long long)s->g.NX * s->g.NY * s->g.NZ <= ctx->tile3d_max_nodes && stencil_tile3d_grid(s->g) <= 0x3fffffffLL;
     DevVec* vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
-    if (ctx->vec_contig >= 2 && ctx->vec_contig <= 6 && rc == PDEGPU_OK) {
-        size_t stride = 0;
-        const size_t total = vec_total(s->g);
-        rc = arena_create(ctx, ctx->vec_contig, total * sizeof(double), 6, &s->arena, &stride);
-        for (int i = 0; i < 6 && rc == PDEGPU_OK; ++i) {
-            DevVec* v = vecs[i];
-            char* b0 = static_cast<char*>(s->arena.ptr);
-            if (s->arena.kind == 1) {                    // hipMalloc arena: first vector at the alignment the stride stands for
-                const size_t al = ctx->vec_contig == 5 ? (1024ull << 20) : (2ull << 20);
-                b0 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(b0) + al - 1) / al * al);
-            }
-            v->base = reinterpret_cast<double*>(b0 + (size_t)i * stride);
-            v->total = total;
-            v->borrowed = true;
-            v->v = v->base + vec_front(s->g);
-            if (hipMemsetAsync(v->base, 0, total * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset arena vector");
-        }
-    } else {
-        for (DevVec* v : vecs)
-            if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);
-    }
+    for (DevVec* v : vecs)
+        if (rc == PDEGPU_OK) rc = vec_alloc(ctx, s->g, v);
     int npart = stencil_max_partials(ctx);
     if (s->tile3d && stencil_tile3d_grid(s->g) > npart) npart = (int)stencil_tile3d_grid(s->g);
     if (rc == PDEGPU_OK && hipMalloc(&s->d_scal, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc scal");
     s->npart = npart;
     if (rc == PDEGPU_OK && hipMalloc(&s->d_part, 2 * (size_t)npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
-    if (rc == PDEGPU_OK && (hipMalloc(&s->d_counter, 64) != hipSuccess || hipMemsetAsync(s->d_counter, 0, 64, ctx->stream) != hipSuccess))
-        rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc counter");
     if (rc == PDEGPU_OK && hipHostMalloc(&s->h_pin, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipHostMalloc");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset scal");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_part, 0, npart * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset partials");
@@ -969,42 +907,6 @@ extern "C" int pdegpu_session_flush(pdegpu_session* s) {
 }
 
 namespace {
-constexpr int kGraphIters = 8;     // iterations per captured graph (even)
-
-int cg_one_iteration(pdegpu_session* s, LaunchInfo* l1, LaunchInfo* l2) {
-    PG_TRY(op_k1(s, l1));
-    PG_TRY(empty_dot(s, *l1, 0));
-    PG_TRY(op_k2(s, l2));
-    return empty_dot(s, *l2, 1);
-}
-
-// capture kGraphIters iterations on the context stream (nothing executes; host-side pcur ends where it started)
-int cg_graph_prepare(pdegpu_session* s) {
-    pdegpu_ctx* ctx = s->ctx;
-    CgGraph& g = s->cg_graph;
-    const long long key = tunable_key(ctx);
-    if (g.exec && g.key == key && g.pcur == s->pcur) return PDEGPU_OK;
-    g.reset();
-    PG_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    int rc = PDEGPU_OK;
-    LaunchInfo l1, l2;
-    for (int it = 0; it < kGraphIters && rc == PDEGPU_OK; ++it) rc = cg_one_iteration(s, &l1, &l2);
-    hipGraph_t graph = nullptr;
-    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-    if (rc != PDEGPU_OK || e != hipSuccess || !graph) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc != PDEGPU_OK ? rc : pdegpu_set_err(ctx, PDEGPU_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    }
-    g.graph = graph;
-    PG_HIP(ctx, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-    g.iters = kGraphIters;
-    g.pcur = s->pcur;
-    g.key = key;
-    return PDEGPU_OK;
-}
-}  // namespace
-
-namespace {
 // 2-D sessions whose CG loop runs as one cooperative launch (persist2d.hip)
 bool use_persist2d(pdegpu_session* s) {
     return s->plane2d && !s->weighted && s->ctx->persist2d != 0 && s->g.dim == 2 && persist2d_supported(s->ctx, s->g);
@@ -1040,28 +942,13 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
     }
     LaunchInfo l1, l2;
     int done = 0;
-    // launch-bound grids: replay the inner loop from a captured hipGraph (after two eager iterations, which
-    // also run the one-time occupancy queries).  Timed runs stay eager: every launch is bracketed by events.
-    if (!time_kernels && ctx->use_graph && ctx->stream != nullptr) {
-        while (s->eager_iters < 2 && done < iters) {
-            PG_TRY(cg_one_iteration(s, &l1, &l2));
-            ++done;
-            ++s->eager_iters;
-        }
-        if (iters - done >= kGraphIters && cg_graph_prepare(s) == PDEGPU_OK) {
-            while (iters - done >= kGraphIters) {
-                PG_HIP(ctx, hipGraphLaunch(s->cg_graph.exec, ctx->stream));
-                done += kGraphIters;
-            }
-        }
-    }
     // lazy dot products (default): no reduce launches inside the chunk — K2's prologue sums K1's p.q partials, the next
     // K1's prologue sums K2's r.r partials (same summation order as k_reduce: bitwise the same scalars); the two r.r
     // slots alternate so that no launch overwrites a scalar its own workgroups still read, and one reduce launch at the
     // end of the chunk leaves the canonical layout (SC_RR current, SC_RR_PREV previous) for the host and for flush.
     const int64_t nslow = s->grid.dim == 3 ? (int64_t)s->grid.n[2] + 1 : 1;
     // (every workgroup of the consuming launch sums ALL partials: only sensible while they are a few thousand)
-    const bool lazy = ctx->lazy_dot && !use_inlaunch(s) && !s->weighted && s->g.k0 == 0 && s->g.nkl == nslow &&
+    const bool lazy = ctx->lazy_dot && !s->weighted && s->g.k0 == 0 && s->g.nkl == nslow &&
                       done < iters && !(s->tile3d && stencil_tile3d_grid(s->g) > stencil_max_partials(ctx));
     if (lazy) {
         int cur = SC_RR;
@@ -1088,7 +975,6 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
             if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
             if (l2.grid < 1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "lazy CG loop: empty K2 grid");
             pend = true;
-            ++s->eager_iters;
         }
         PG_TRY(vec_reduce(ctx, s->d_part + s->npart, l2.grid, s->d_scal, cur == SC_RR ? 1 : 2, 1));
         done = iters;
@@ -1102,7 +988,6 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
         PG_TRY(op_k2(s, &l2));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
         PG_TRY(empty_dot(s, l2, 1));
-        ++s->eager_iters;
     }
     if (stats) {
         stats->cg_iterations += iters;
@@ -1259,15 +1144,25 @@ int cg_solve(pdegpu_session* s, double bnorm2, double rr, double rtol, int max_i
     hipEvent_t e0 = ev.a, e1 = ev.b;
     PG_HIP(ctx, hipEventRecord(e0, ctx->stream));
     const bool persistent = use_persist2d(s);
+    bool classic_only = false;      // persistent 2-D loop: the single-reduction form broke down, stay with the classic recurrences
     while (rr > target && it < max_iter && std::isfinite(rr)) {
         if (persistent) {
             // one cooperative launch runs until r.r <= target (every workgroup holds the same r.r): no polling, no overshoot;
             // launches are cut at 8192 iterations only to keep a single launch short
             int done = 0;
-            PG_TRY(persist2d_iterate(s, std::min(8192, max_iter - it), target, &done, /*fresh=*/it == 0 ? 1 : 0));
+            const int req = std::min(8192, max_iter - it);
+            const int fresh = (it == 0 && !classic_only) ? 1 : 0;
+            PG_TRY(persist2d_iterate(s, req, target, &done, fresh));
             it += done;
             PG_TRY(pdegpu_session_rr(s, &rr));
-            if (done == 0) break;
+            if (done < req && rr > target) {
+                // The launch left its loop without converging: a breakdown of its recurrences (alpha = 0).  The single-reduction form
+                // (Chronopoulos-Gear) loses positivity of its predicted p.Ap earlier than the classic one near tight tolerances, so a
+                // fresh single-reduction launch gets ONE retry with the classic recurrences (which restart with beta = 0) before the
+                // solve is given up; once iterations have been made the next launch is classic anyway.
+                if (fresh) { classic_only = true; continue; }
+                if (done == 0) break;
+            }
             continue;
         }
         const int n = std::min(chunk, max_iter - it);

@@ -179,8 +179,7 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
         }
     }
     const double tot = block_sum_256(acc, sRed);
-    __syncthreads();
-    dot_finish(tot, DotSink{a.partials, a.counter, a.scal, a.dot_which}, sRed);
+    dot_finish(tot, a.partials);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,16 +320,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 val.y = rr.y + beta * po.y;
                 if (po_out) *po_out = po;
             } else {
-                // (rows 2 .. RY-1 of a tile are read by no other workgroup; rows 1 / RY are the y-neighbour's halo, 0 / RY+1 its own rows)
-                const int rr = j - j0 + 1;
-                const bool nt = a.nt_in == 2 || (a.nt_in == 1 && rr >= 2 && rr <= RY - 1);      // kernel- / unroll-uniform
-                double2 v;
-                if (nt) {
-                    const dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(a.in + off));
-                    v = make_double2(t.x, t.y);
-                } else {
-                    v = load_pair(a.in, off);
-                }
+                // (non-temporal loads here were measured slower, profiles/r02_exp14_nontemporal_input_loads.log: the y-neighbours' halo rows are L2 hits)
+                const double2 v = load_pair(a.in, off);
                 val.x = v.x + shift;
                 val.y = v.y + shift;
             }
@@ -621,8 +612,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
         if (K1 && lk1 == fg.lke && lk1 == g.nkl && g.k0 + g.nkl < g.NZ) ghost_store(lk1, C);
     }
     const double tot = block_sum_256(acc, sRed);
-    __syncthreads();
-    dot_finish(tot, DotSink{a.partials, a.counter, a.scal, a.dot_which}, sRed);
+    dot_finish(tot, a.partials);
 }
 
 
@@ -1009,7 +999,7 @@ ModeCfg mode_cfg(const pdegpu_ctx* ctx, int mode) {
     ModeCfg c;
     c.ry = ctx->fast_ry > 0 ? ctx->fast_ry : ((mode == APPLY_PLAIN || mode == APPLY_RESIDUAL) ? 4 : 2);
     c.wg = (mode == APPLY_CG_K2 && ctx->fast_wg_per_cu_k2 >= 1) ? ctx->fast_wg_per_cu_k2 : ctx->fast_wg_per_cu;
-    c.ex = ctx->fast_ex && (mode == APPLY_CG_K1 || mode == APPLY_CG_K2 || ctx->fast_ex_all);
+    c.ex = ctx->fast_ex && (mode == APPLY_CG_K1 || mode == APPLY_CG_K2);
     // deeper prefetch: on by default in the bare apply / residual pass (fast_pf = -1; 512^3 SpMV 0.382 -> 0.376 ms, 400^3 0.208 -> 0.195, 640^3
     // 0.955 -> 0.910), 1 = also in the stencil-K2, 0 = nowhere
     c.pf = ctx->fast_pf < 0 ? (mode == APPLY_PLAIN || mode == APPLY_RESIDUAL) : (ctx->fast_pf != 0 && mode != APPLY_CG_K1);
@@ -1041,19 +1031,7 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     }
     int wg_per_cu = occ[mode];
     const ModeCfg mc = mode_cfg(ctx, mode);
-    // residency cap (fast_occ_*): more resident workgroups than ~2 per CU mean more concurrent HBM streams, not more bandwidth (512^3 K1:
-    // 3 per CU 0.64 of the peak against 0.74 with 2, profiles/r02_exp16_chunk_count_sweep.log).  A dynamic LDS request the kernel never
-    // touches makes the hardware hold the rest back, so a launch of many short z-chunks is dispatched 2 (3, 4) per CU as slots free up.
-    int res_occ = occ[mode];
-    size_t dyn_lds = 0;
-    {
-        const int cap = ctx->fast_occ[mode & 3];
-        if (cap >= 2 && cap <= 4 && cap < res_occ) {
-            static const size_t kb[3] = {60, 48, 36};      // 160 KB of LDS per CU: floor(160 / 60) = 2, floor(160 / 48) = 3, floor(160 / 36) = 4
-            dyn_lds = kb[cap - 2] * 1024 - 1024;           // (the static arrays of the kernel stay below 1 KB)
-            res_occ = cap;
-        }
-    }
+    const int res_occ = occ[mode];
     // HBM-resident vectors (the same threshold as the non-temporal hints): two workgroups per CU, i.e. as few and as long z-chunks
     // as fill the device; fast_geom adds 1/8 of slack so that e.g. 3 x 192 tiles count as one round
     const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
@@ -1077,10 +1055,10 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     }
     if (G == 0) return PDEGPU_OK;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
-        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
-        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>), dim3(G), dim3(256), dyn_lds, ctx->stream, a, fg); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -1247,8 +1225,6 @@ static int fast_rows(const pdegpu_ctx* ctx, const GridDev& g, int npt, int mode)
 
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo* li) {
     StencilArgs a = a_in;
-    const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
-    a.nt_in = (mode != APPLY_CG_K1 && hbm) ? ctx->fast_nt_in : 0;
     if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
     const int ry = fast_rows(ctx, a.g, a.npt, mode);
     if (a.npt == 7) {

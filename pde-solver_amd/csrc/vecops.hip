@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_set_bc(GridDev g, double* __restrict__ 
 typedef double vk_d2 __attribute__((ext_vector_type(2)));
 template <bool NT>
 __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const double2* __restrict__ q, long long n2,
-                                             double* scal, double* __restrict__ partials, unsigned* counter, DotIn di) {
+                                             double* scal, double* __restrict__ partials, DotIn di) {
     __shared__ double sRed[4];
     const double alpha = cg_alpha_in(di, scal, sRed);
     double acc = 0.0;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_k2(double2* __restrict__ r, const doubl
     }
     const double tot = block_sum_256(acc, sRed);
     __syncthreads();
-    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
+    dot_finish(tot, partials);
 }
 
 // streaming ceilings of the device for 16-B-per-lane accesses: ONE element per thread, as many workgroups as elements / 256 (no
@@ -182,74 +182,14 @@ inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
 int vec_alloc(pdegpu_ctx* ctx, const GridDev& g, DevVec* v) {
     v->total = vec_total(g);
     v->base = nullptr;
-    if (ctx->vec_contig == 1) {
-        void* p = nullptr;
-        if (hipExtMallocWithFlags(&p, v->total * sizeof(double), hipDeviceMallocContiguous) == hipSuccess) v->base = static_cast<double*>(p);
-        else (void)hipGetLastError();
-        if (getenv("PDEGPU_DEBUG_GEOM")) fprintf(stderr, "[pdegpu alloc] contiguous %zu MiB: %s\n", v->total * 8 >> 20, v->base ? "ok" : "refused");
-    }
-    if (!v->base) PG_HIP(ctx, hipMalloc(&v->base, v->total * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&v->base, v->total * sizeof(double)));
     PG_HIP(ctx, hipMemsetAsync(v->base, 0, v->total * sizeof(double), ctx->stream));
     v->v = v->base + vec_front(g);
     return PDEGPU_OK;
 }
 
-// Session arena (placement experiments, profiles/r03_placement_*.log): mode 2 / 3 = ONE hipMemCreate handle of the minimum / recommended
-// granularity mapped into one reserved range; mode 4 / 5 = one hipMalloc carved at 2 MiB / 1 GiB strides.
-int arena_create(pdegpu_ctx* ctx, int mode, size_t bytes_per_vec, int nvec, DevArena* a, size_t* stride_out) {
-    const size_t MiB = 1ull << 20;
-    if (mode == 4 || mode == 5 || mode == 6) {
-        const size_t al = mode == 5 ? 1024 * MiB : 2 * MiB;
-        size_t stride = (bytes_per_vec + al - 1) / al * al;
-        if (mode == 6) {                                  // physically contiguous arena, vectors staggered by PDEGPU_VEC_STAGGER_KB
-            const char* e = getenv("PDEGPU_VEC_STAGGER_KB");
-            stride += (size_t)(e ? atol(e) : 0) * 1024;
-        }
-        a->bytes = stride * nvec + al;
-        if (mode == 6) PG_HIP(ctx, hipExtMallocWithFlags(&a->ptr, a->bytes, hipDeviceMallocContiguous));
-        else PG_HIP(ctx, hipMalloc(&a->ptr, a->bytes));
-        a->kind = 1;
-        *stride_out = stride;
-        return PDEGPU_OK;
-    }
-    hipMemAllocationProp prop{};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = ctx->device;
-    size_t gran = 0;
-    PG_HIP(ctx, hipMemGetAllocationGranularity(&gran, &prop, mode == 2 ? hipMemAllocationGranularityMinimum : hipMemAllocationGranularityRecommended));
-    if (gran < 2 * MiB) gran = 2 * MiB;
-    const size_t stride = (bytes_per_vec + gran - 1) / gran * gran;
-    a->bytes = stride * nvec;
-    PG_HIP(ctx, hipMemAddressReserve(&a->ptr, a->bytes, gran, nullptr, 0));
-    if (hipMemCreate(&a->handle, a->bytes, &prop, 0) != hipSuccess) {
-        (void)hipMemAddressFree(a->ptr, a->bytes);
-        a->ptr = nullptr;
-        return pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMemCreate(%zu MiB) failed", a->bytes >> 20);
-    }
-    a->kind = 2;
-    PG_HIP(ctx, hipMemMap(a->ptr, a->bytes, 0, a->handle, 0));
-    hipMemAccessDesc acc{};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    PG_HIP(ctx, hipMemSetAccess(a->ptr, a->bytes, &acc, 1));
-    if (getenv("PDEGPU_DEBUG_GEOM")) fprintf(stderr, "[pdegpu alloc] VMM arena %zu MiB, granularity %zu KiB\n", a->bytes >> 20, gran >> 10);
-    *stride_out = stride;
-    return PDEGPU_OK;
-}
-void arena_free(DevArena* a) {
-    if (a->kind == 1 && a->ptr) (void)hipFree(a->ptr);
-    if (a->kind == 2 && a->ptr) {
-        (void)hipMemUnmap(a->ptr, a->bytes);
-        (void)hipMemRelease(a->handle);
-        (void)hipMemAddressFree(a->ptr, a->bytes);
-    }
-    *a = DevArena();
-}
-
 void vec_free(DevVec* v) {
-    if (v->base && !v->borrowed) (void)hipFree(v->base);
-    v->borrowed = false;
+    if (v->base) (void)hipFree(v->base);
     v->base = v->v = nullptr;
     v->total = 0;
 }
@@ -267,8 +207,8 @@ int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const 
     return PDEGPU_OK;
 }
 
-int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, unsigned* counter,
-           LaunchInfo* li, const DotIn& di) {
+int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, LaunchInfo* li,
+           const DotIn& di) {
     const long long n2 = (long long)g.nkl * g.PP / 2;
     long long nbl = (n2 + 255) / 256;
     if (nbl > (long long)ctx->k2_grid_mult * ctx->num_cu) nbl = (long long)ctx->k2_grid_mult * ctx->num_cu;
@@ -276,9 +216,9 @@ int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double
     if (li) { li->grid = nb; li->block = 256; }
     const bool nt = ctx->fast_nt < 0 ? n2 * 16 > (64LL << 20) : (ctx->fast_nt & 3) == 3;      // the marching kernels' policy
     if (nt) hipLaunchKernelGGL(k_k2<true>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                               reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
+                               reinterpret_cast<const double2*>(q), n2, scal, partials, di);
     else hipLaunchKernelGGL(k_k2<false>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(r),
-                            reinterpret_cast<const double2*>(q), n2, scal, partials, counter, di);
+                            reinterpret_cast<const double2*>(q), n2, scal, partials, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

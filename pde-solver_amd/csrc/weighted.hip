@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom
 // r -= alpha q;  z = D^-1 r;  partial r.z    (use_alpha == 0: z and the sum only)
 __global__ __launch_bounds__(256) void k_k2_pc(double* __restrict__ r, const double* __restrict__ q, double* __restrict__ z,
                                                 const double* __restrict__ dinv, long long n, double* scal,
-                                                double* __restrict__ partials, unsigned* counter, int use_alpha) {
+                                                double* __restrict__ partials, int use_alpha) {
     __shared__ double sRed[4];
     double alpha = 0.0;
     if (use_alpha) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_k2_pc(double* __restrict__ r, const dou
     }
     const double tot = block_sum_256(acc, sRed);
     __syncthreads();
-    dot_finish(tot, DotSink{partials, counter, scal, counter ? 1 : -1}, sRed);
+    dot_finish(tot, partials);
 }
 
 inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
@@ -104,11 +104,11 @@ int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w,
 }
 
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
-              double* partials, unsigned* counter, int use_alpha, LaunchInfo* li) {
+              double* partials, int use_alpha, LaunchInfo* li) {
     const long long n = (long long)g.nkl * g.PP;
     const int nb = flat_grid(ctx, n);
     if (li) { li->grid = nb; li->block = 256; }
-    hipLaunchKernelGGL(k_k2_pc, dim3(nb), dim3(256), 0, ctx->stream, r, q, z, dinv, n, scal, partials, counter, use_alpha);
+    hipLaunchKernelGGL(k_k2_pc, dim3(nb), dim3(256), 0, ctx->stream, r, q, z, dinv, n, scal, partials, use_alpha);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

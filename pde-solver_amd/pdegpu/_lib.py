@@ -237,23 +237,20 @@ def element_mode_from_env() -> int:
 # ---- output-volume policy ------------------------------------------------------------------------------------------------
 # The reference stores EVERY step (fenics_mcp_server.py:300-315, 694-696, 711-713); at the grid sizes this build solves that is
 # hundreds of GB (config 3 at the dispatcher's defaults: 201 states x 1.08 GB = 217 GB).  Policy: the host array may take at most
-# PDEGPU_MAX_OUTPUT_GB (default: half of the physical memory, at most 64 GB).  A request beyond it is strided automatically to the
-# smallest stride that fits (first and last state always kept) and the stride actually used is recorded in meta; with
-# PDEGPU_OUTPUT_POLICY=error it raises instead, naming snapshot_stride.
+# PDEGPU_MAX_OUTPUT_GB, default 32 GB — a FIXED number, so that the same call returns arrays of the same shape on every machine.  A
+# request beyond it is strided to the smallest stride that fits (first and last state always kept) and the stride actually used is
+# recorded in meta; with PDEGPU_OUTPUT_POLICY=error it raises instead, naming snapshot_stride.
+DEFAULT_OUTPUT_BUDGET_GB = 32.0
+
+
 def output_budget_bytes() -> int:
     v = os.environ.get("PDEGPU_MAX_OUTPUT_GB")
-    if v:
-        return int(float(v) * 1e9)
-    try:
-        phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
-    except (ValueError, OSError):
-        phys = 16 << 30
-    return int(min(0.5 * phys, 64e9))
+    return int(float(v if v else DEFAULT_OUTPUT_BUDGET_GB) * 1e9)
 
 
 def count_snapshots(num_steps: int, stride: int) -> int:
-    """states stored for steps 0 .. num_steps with `stride` (the last step is always stored) — pdegpu_heat_num_snapshots"""
-    return sum(1 for s in range(num_steps + 1) if s % stride == 0 or s == num_steps)
+    """states stored for steps 0 .. num_steps with `stride` (the last step is always stored) — pdegpu_heat_num_snapshots in closed form"""
+    return num_steps // stride + 1 + (1 if num_steps % stride else 0)
 
 
 def snapshot_policy(num_steps: int, n_nodes: int, requested_stride: int, steady: bool):
@@ -272,8 +269,14 @@ def snapshot_policy(num_steps: int, n_nodes: int, requested_stride: int, steady:
         raise PdeGpuError(EINVAL, msg + "; pass snapshot_stride=k (or PDEGPU_SNAPSHOT_STRIDE) to keep every k-th state")
     if 2 * n_nodes * 8 > budget:
         raise PdeGpuError(EINVAL, msg + "; not even the first and the last state fit")
-    stride = req
-    while count_snapshots(num_steps, stride) * n_nodes * 8 > budget:
-        stride += 1
+    # the count never grows with the stride: bisect for the smallest stride in (req, num_steps] that fits (num_steps itself stores 2 states)
+    lo, hi = req, max(req + 1, num_steps)
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if count_snapshots(num_steps, mid) * n_nodes * 8 > budget:
+            lo = mid
+        else:
+            hi = mid
+    stride = hi
     return stride, {"snapshot_stride": stride, "snapshot_stride_requested": req,
                     "snapshot_policy": f"auto-strided: {msg}; every {stride}-th state (and the last) is kept"}

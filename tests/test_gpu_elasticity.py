@@ -63,57 +63,10 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
     finally:
         for k, v in (("el_fast", 1), ("el_fast_ry", 2), ("el_fast_waves", 0), ("el_fast_yx", 1)):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
-    # 48-node tiles (128-byte aligned, whole-line stores): same per-node arithmetic, different lanes
-    try:
-        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_fast_xt", 48))
-        for ry, yx in ((2, 1), (1, 0)):
-            for k, v in (("el_fast_ry", ry), ("el_fast_yx", yx)):
-                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
-            y = np.full_like(u, np.nan)
-            _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 0))
-            assert np.array_equal(y, outs[(1, ry, 2048, yx)]), (ry, yx)
-    finally:
-        for k, v in (("el_fast_xt", 62), ("el_fast_ry", 2), ("el_fast_yx", 1)):
-            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
     # z-chunking does not change a single bit (same per-node arithmetic)
     assert np.array_equal(outs[(1, 1, 2048, 1)], outs[(1, 1, 1, 1)])
     # neither does handing the y-halo rows through LDS instead of loading them
     assert np.array_equal(outs[(1, 1, 2048, 1)], outs[(1, 1, 2048, 0)]) and np.array_equal(outs[(1, 2, 2048, 1)], outs[(1, 2, 2048, 0)])
-
-
-@pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((122, 4, 5), (2.0, 0.3, 0.2)), ((123, 3, 3), (2.0, 0.3, 0.2)), ((124, 2, 9), (1.0, 0.2, 0.5)),
-                                  ((125, 5, 3), (1.0, 0.2, 0.1)), ((2, 2, 2), (1.0, 1.0, 1.0)), ((20, 11, 8), (1.0, 0.5, 0.4)), ((9, 23, 6), (0.5, 1.0, 0.3)),
-                                  ((250, 8, 12), (1.0, 0.2, 0.3))])
-def test_two_nodes_per_lane_apply_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
-    """k_el_fast2 (two adjacent nodes per lane, 16-byte accesses, 124-node tiles): rows per wave 1 | 2, y hand-off on / off, faces folded
-    in or left to the class-table pass, non-temporal stores on / off (both kernels), one plane per z-chunk to the whole column, x-tiles ending at 123 / 124 / 125 / 126 nodes — against
-    the assembled matrix and, to round-off, against the one-node kernel"""
-    from pdegpu import _lib
-    E, nu = 210e9, 0.3
-    lam, mu = o.lame(E, nu)
-    c, cells = o.box_mesh(*Ls, *n)
-    K = o.assemble_elasticity(c, cells, lam, mu)
-    u = np.random.default_rng(12).uniform(-1, 1, (c.shape[0], 3))
-    ref = (K @ u.ravel()).reshape(-1, 3)
-    el = _lib.Elasticity()
-    el.E, el.nu = E, nu
-    g = _lib.make_grid(3, n, Ls)
-    keys = ("el_fast_npl", "el_fast_ry", "el_fast_waves", "el_fast_yx", "el_fast_yzface", "el_fast_nt")
-    try:
-        base = None
-        for cfg in ((1, 2, 4096, 1, 3, 0), (1, 2, 4096, 1, 3, 1), (1, 1, 1, 0, 1, 1), (2, 1, 4096, 1, 3, 0), (2, 2, 4096, 1, 3, 1), (2, 1, 1, 1, 3, 1),
-                    (2, 2, 100000, 0, 3, 0), (2, 1, 4096, 0, 1, 1), (2, 2, 4096, 1, 0, 0)):
-            for k, v in zip(keys, cfg):
-                _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
-            y = np.full_like(u, np.nan)
-            _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 0))
-            assert rel_err(y, ref) < 1e-12, cfg
-            if base is None:
-                base = y
-            assert rel_err(y, base) < 1e-13, cfg
-    finally:
-        for k, v in zip(keys, (1, 2, 0, 1, 3, -1)):
-            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, k.encode(), v))
 
 
 @pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((37, 3, 2), (2.0, 0.3, 0.2)), ((16, 1, 1), (1.0, 0.1, 0.1))])
@@ -306,12 +259,12 @@ def test_row_and_kernel_variants_agree(lib, gpu_ctx):
         for cfg in (dict(el_fast=1, el_fast_ry=2, el_fast_yx=1), dict(el_fast=1, el_fast_ry=1, el_fast_yx=1), dict(el_fast=1, el_fast_ry=2, el_fast_yx=0),
                     dict(el_fast=0), dict(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=0), dict(el_grid_mult=1), dict(el_grid_mult=16, el_fast_waves=300),
                     dict(el_fast_ry=4, el_fast_yx=1), dict(el_fast_ry=4, el_fast_yx=0), dict(el_fast_xface=0), dict(el_fast_xface=0, el_fast_ry=1),
-                    dict(el_fast_nt=1), dict(el_fast_nt=1, el_fast_npl=2, el_fast_ry=1), dict(el_fast_yzface=1), dict(el_fast_yzface=0, el_fast_nt=0)):
+                    dict(el_fast_nt=1), dict(el_fast_nt=1, el_fast_ry=1), dict(el_fast_yzface=1), dict(el_fast_yzface=0, el_fast_nt=0)):
             tun(**cfg)
             outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress",
                                                                rtol=1e-12))
     finally:
-        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=0, el_fast_xface=1, el_fast_nt=-1, el_fast_npl=1, el_fast_yzface=3)
+        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=0, el_fast_xface=1, el_fast_nt=-1, el_fast_yzface=3)
     ref = o.solve_elasticity_3d(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress")
     for f in outs:
         assert rel_err(f.values, ref.values) < TOL

@@ -293,6 +293,15 @@ def test_snapshot_policy_auto_strides_config3_defaults(monkeypatch):
     assert L.count_snapshots(200, stride) * N * 8 <= 64e9 < L.count_snapshots(200, stride - 1) * N * 8
     assert meta["snapshot_stride"] == stride and meta["snapshot_stride_requested"] == 1 and "217" in meta["snapshot_policy"]
     assert L.count_snapshots(200, 1) == 201 and L.count_snapshots(10, 4) == 4            # 0, 4, 8, 10
+    # the DEFAULT budget is a fixed number (the same array shapes on every machine): config 3's defaults -> every 8th state
+    monkeypatch.delenv("PDEGPU_MAX_OUTPUT_GB")
+    assert L.output_budget_bytes() == 32_000_000_000
+    assert L.snapshot_policy(200, N, 1, False)[0] == 8 and L.count_snapshots(200, 8) == 26
+    # closed form == enumeration, and a long run is strided without walking its steps
+    for steps, st in ((0, 1), (1, 1), (10, 3), (200, 7), (201, 200), (5, 9)):
+        assert L.count_snapshots(steps, st) == sum(1 for q in range(steps + 1) if q % st == 0 or q == steps)
+    big, _ = L.snapshot_policy(10 ** 6, 10 ** 6, 1, False)
+    assert L.count_snapshots(10 ** 6, big) * 8e6 <= 32e9 < L.count_snapshots(10 ** 6, big - 1) * 8e6
 
 
 def test_snapshot_policy_error_mode_and_hopeless_requests(monkeypatch):
@@ -371,3 +380,32 @@ def test_dirichlet_set_of_the_library_is_the_oracles(lib):
             assert lib.pdegpu_dirichlet_set_host(grid, h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), _lib.dptr(vals)) == 0
             assert (mask.astype(bool) == ref_m).all(), (nx, ny, nz, T_left, T_right, T_side)
             assert np.array_equal(vals[ref_m], ref_v[ref_m])
+
+
+def test_bench_extras_watchdog_reports_a_hang_as_a_failure(tmp_path):
+    """bench.py's extras watchdog: an extra leg that never returns gives exit code 3 AND the main JSON line (from a snapshot, with
+    extras.aborted and the cpu_baseline block intact) — a hang must not read as 'status ok'"""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / "drive.py"
+    script.write_text(f"""
+import sys, time, types
+sys.path.insert(0, {str(ROOT)!r})
+import bench
+class FakeRunner:
+    world, rank, local_rank = 1, 0, 0
+    def run_case(self, case, steps, warmup, extras_n1=False):
+        time.sleep(30)                       # a collective that never completes
+args = types.SimpleNamespace(extras_timeout=1.0, cells=8, steps=4, warmup=1)
+out = {{"metric": "m", "value": 1.0, "cpu_baseline": {{"value": 2.0}}, "roofline": {{"frac": 0.5}}}}
+case = bench.make_case("config3", "weak", 8, 1)
+bench.run_extras_guarded(FakeRunner(), args, case, out, 1.0)
+print("NOT REACHED")
+""")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "NOT REACHED" not in r.stdout
+    line = json.loads(lines[0])
+    assert "aborted" in line["extras"] and line["cpu_baseline"] == {"value": 2.0} and line["roofline"] == {"frac": 0.5}
