@@ -5,7 +5,8 @@ one node (one process per GPU, slabs along the slowest axis, RCCL halo exchange 
 A "step" is ONE CG iteration (fused K1: x-update + p-update + 7-point SpMV + p.q; K2: r-update + r.r) of the steady system
 kappa K u = f m with f = 1, T_boundary = 0 on synthetic data.  value = free unknowns x K / wall time of the K timed iterations
 (max over ranks).  Every N — N = 1 included — is driven by the SAME loop: pdegpu.dist.SlabCG stepping the HIP session
-(exchange posted -> K1 on the planes away from the ghosts -> exchange done -> K1 edge planes -> all-reduce -> K2 -> all-reduce).
+(exchange posted -> K1 on the planes away from the ghosts -> exchange done -> K1 edge planes + one reduce launch -> ONE 24-byte
+all-reduce {p.Ap, r.r, Ap.Ap} -> K2; --cg-variant classic: 8-byte all-reduces after K1 and after K2).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -192,7 +193,7 @@ class Runner:
         res = {"unknowns": unknowns, "cells": [nx, ny, nz], "planes_rank0": nk}
         with torch.cuda.stream(self.stream):
             eng = GpuSlabEngine(grid, heat, k0, nk, self.local_rank, self.stream)
-            cg = SlabCG(eng, rank, world, overlap=not self.args.no_overlap)
+            cg = SlabCG(eng, rank, world, overlap=not self.args.no_overlap, variant=self.args.cg_variant)
             cg.force_collectives = bool(case.get("force_collectives"))
             if extras_n1:
                 # in-run streaming ceilings and the bare SpMV are measured FIRST (they use r, q, b as scratch, so they must precede
@@ -209,7 +210,9 @@ class Runner:
             cg.start(0.0)
             cg.iterate(warmup)
             self.fence()
-            eng.set_timing(True)
+            # HIP-event pairs inside the timed region (roofline contract): around every launch at N = 1; at N > 1 — thin slabs, thousands of
+            # iterations per second — around those of every 4th iteration, so that the records do not slow the loop they measure
+            eng.set_timing(1 if world == 1 else 4)
             t0 = time.perf_counter()
             cg.iterate(steps)
             self.fence()
@@ -217,7 +220,8 @@ class Runner:
             stats = L.Stats()
             eng.get_stats(stats)
             eng.set_timing(False)
-            res["rr_after"] = eng.rr()
+            res["rr_after"] = cg.rr()
+            res["cg_variant"] = "sr" if cg.sr else "classic"
             if world > 1:
                 t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,6 +235,9 @@ class Runner:
             res["split_k1"] = bool(eng.can_split_k1()) and not self.args.no_overlap
             if extras_n1:
                 # the native single-GPU loop of the product's one-shot solves (pdegpu_session_iterate: no reduce launches, C loop)
+                eng.set_variant(False)                 # the native loop runs the classic recurrences: restart the system in that form
+                eng.begin(0.0)
+                eng.residual()
                 eng.iterate_native(warmup, False)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -269,6 +276,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="do not measure the other workloads after the main one")
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="seconds the extra legs may take before the main line is printed without them")
     ap.add_argument("--no-overlap", action="store_true", help="exchange halos before K1 instead of overlapping them with its bulk")
+    ap.add_argument("--cg-variant", choices=("sr", "classic"), default="sr", help="sr: single-reduction recurrences, ONE 24-byte scalar all-reduce per "
+                    "iteration (default); classic: 8 bytes after K1 and 8 bytes after K2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general", action="store_true", help="force the class-table kernels (diagnostic)")
     args = ap.parse_args()
@@ -286,14 +295,16 @@ def main():
         "config": {"workload": case["label"], "global_cells": res["cells"], "unknowns": res["unknowns"], "element_mode": "p1split",
                    "parallelism": (f"z-slabs x{world}" + rehearsal) if world > 1 else "single GPU",
                    "driver": "pdegpu.dist.SlabCG over the stepwise C-ABI session (the same loop at every N)" +
-                             ("; K1 split: bulk overlaps the halo exchange" if res["split_k1"] else ""),
+                             ("; K1 split: bulk overlaps the halo exchange" if res["split_k1"] else "") +
+                             ("; single-reduction CG: one 24-byte scalar all-reduce per iteration" if res["cg_variant"] == "sr" else
+                              "; classic CG: two 8-byte scalar all-reduces per iteration"),
                    "kernel_path": "general" if args.general else "fused z-marching", "rr_after": res["rr_after"]},
     }
     rl = roofline_of(res, args.general)
     if world > 1:
         per_gpu = float(res["k1_per_dof"] + 24) * res["unknowns"] / world / (res["elapsed"] / args.steps) / 1e9
         rl["whole_iteration_per_gpu"] = {"achieved": per_gpu, "frac": per_gpu / HBM_PEAK_GBS,
-                                         "note": "K1 + K2 algorithmic bytes per GPU over the whole iteration incl. halo exchange and the two 8-byte all-reduces"}
+                                         "note": "K1 + K2 algorithmic bytes per GPU over the whole iteration incl. halo exchange and the scalar all-reduce(s)"}
     else:
         pmc = ROOT / "profiles" / "pmc_latest.json"
         if pmc.exists():

@@ -251,7 +251,8 @@ int pdegpu_elasticity_tables_host(const pdegpu_grid* grid, double lam, double mu
 
 /* ---- slab-resident elasticity PCG session (3-D): same protocol as the heat session below.  Vectors: 0 x, 1 r,
  *      2 p (current), 3 q; each has 3 component arrays (z = D^-1 r is never stored: the p-update forms it).  Before every k1 the
- *      host exchanges the first / last owned plane of r and p (3 components each) with the slab neighbours; after k1 it all-reduces scalars[0]
+ *      host exchanges the first / last owned plane of r (3 component planes, contiguous each: no pack kernel) with the slab neighbours —
+ *      p on the ghost planes is maintained by k1 itself (same formula, same global scalars as the neighbour); after k1 it all-reduces scalars[0]
  *      (p.q), after k2 scalars[1..2] (r.z, r.r) — in place, 8 / 16 bytes.  begin() needs no exchange (x = 0). */
 typedef struct pdegpu_el_session pdegpu_el_session;
 int     pdegpu_el_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, int64_t k0, int64_t nk,
@@ -266,11 +267,12 @@ int     pdegpu_el_session_scalars_host(pdegpu_el_session* s, double* out4);   /*
 int64_t pdegpu_el_session_plane_doubles(const pdegpu_el_session* s);
 void*   pdegpu_el_session_plane_ptr(pdegpu_el_session* s, int vec, int comp, int64_t which);
 int     pdegpu_el_session_get_u(pdegpu_el_session* s, double* u_out /* host [nk * plane nodes][3] */);
-/* the halo of one exchange as ONE contiguous message per neighbour: device buffers [r0 r1 r2 p0 p1 p2][plane_doubles] per side
- * (side 0 = lower neighbour, 1 = upper; which 0 = send, 1 = receive).  halo_pack(s, 0) copies the first / last owned plane of r
- * and p into the send buffers, halo_pack(s, 1) the receive buffers into the ghost planes (one launch each). */
-void*   pdegpu_el_session_halo_buffer(pdegpu_el_session* s, int which, int side);
-int     pdegpu_el_session_halo_pack(pdegpu_el_session* s, int unpack);
+/* k1 in two steps so that the halo exchange overlaps the part of it that reads no ghost plane (same protocol as pdegpu_session_k1_part):
+ * part 0 = p-update of the owned planes + the marching apply on the planes away from the ghosts (call it right after posting the exchange),
+ * part 1 = p-update of the ghost planes + the apply on the one or two edge planes (one launch) + the p.q sum.  can_split_k1 = 1 for 3-D
+ * marching sessions on slabs of at least 4 planes with a neighbour; other sessions do nothing in part 0 and the whole k1 in part 1. */
+int     pdegpu_el_session_can_split_k1(const pdegpu_el_session* s);
+int     pdegpu_el_session_k1_part(pdegpu_el_session* s, int part);
 /* von Mises + project() (:1840-1866) on one GPU from a displacement field gathered on the host, disp [N][dim] */
 int     pdegpu_elasticity_postprocess(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, const double* disp,
                                       double* field_out);
@@ -312,9 +314,21 @@ int  pdegpu_session_k2(pdegpu_session* s);                  /* r-=alpha*q; rr_lo
  * nothing in part 0 and the whole k1 in part 1, so a driver may always call part 0 then part 1. */
 int  pdegpu_session_can_split_k1(const pdegpu_session* s);
 int  pdegpu_session_k1_part(pdegpu_session* s, int part);
+/* The CG recurrences of the stepwise protocol.  variant 0 (default): classic CG — the host all-reduces pq_global after k1 and rr_global after
+ * k2 (two 8-byte messages per iteration).  variant 1: single-reduction form (one message per iteration): k1 additionally sums
+ * Ap.Ap, k2 leaves its r.r in per-workgroup partials, and k1 / k1_part(1) end with ONE reduce launch that fills scalars[2..4] =
+ * {p.Ap, r.r (of the residual k1 started from), Ap.Ap}; the host all-reduces these 24 bytes in place after k1 and nothing after k2.  alpha =
+ * r.r / p.Ap as before; beta is formed from the predicted |r_{n+1}|^2 = alpha^2 Ap.Ap - r.r (exact arithmetic: the same iterates; the true
+ * r.r of every residual still enters the next alpha).  Convergence polls: sr_poll sums the last k2's partials into scalars[6] (this slab's
+ * share: all-reduce that slot, 8 bytes), then pdegpu_session_rr reports it; on a slab without neighbours rr does this by itself.  Choose the
+ * variant before begin() / residual(); pdegpu_session_iterate (the native single-slab loop) runs the classic form only. */
+int  pdegpu_session_set_cg_variant(pdegpu_session* s, int variant);
+int  pdegpu_session_cg_variant(const pdegpu_session* s);
+int  pdegpu_session_sr_poll(pdegpu_session* s);
 /* kernel timing of the stepwise protocol: set_timing(s, 1) starts a fresh measurement (hipEvent pairs around every k1 / k1_part
  * / k2 launch on the context stream), get_stats synchronises and ADDS kernel_ms[0] (k1), kernel_ms[1] (k2), launch counts and
- * algorithmic bytes since then to *stats. */
+ * algorithmic bytes since then to *stats.  set_timing(s, k), k > 1: only every k-th iteration is bracketed (an event record costs
+ * stream time of its own — at the 5000 iterations per second of a thin slab the pairs of EVERY launch add ~5 % to the loop). */
 int  pdegpu_session_set_timing(pdegpu_session* s, int on);
 int  pdegpu_session_get_stats(pdegpu_session* s, pdegpu_stats* stats);
 /* transient steps on a slab — the time loop of _solve_heat_3d_raw (:702-716) distributed over slabs.  Per step the host

@@ -172,7 +172,11 @@ void tables_free(HeatTables* t);
 enum ApplyMode { APPLY_PLAIN = 0, APPLY_RESIDUAL = 1, APPLY_CG_K1 = 2, APPLY_CG_K2 = 3 };
 
 // device scalar block used by the CG kernels
-enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_BNORM = 5 /* reference norm of a solve, host-read only */, SC_COUNT = 8 };
+// Single-reduction form (pdegpu_session_set_cg_variant 1): the block {SC_PQ, SC_RR, SC_QQ} = {p_n.Ap_n, r_n.r_n, Ap_n.Ap_n} is ONE 24-byte
+// all-reduce message per iteration; SC_QQ takes the slot the classic form uses for r_{n-1}.r_{n-1}, SC_RR_POLL receives r.r of the
+// residual the last K2 left (convergence polls only).
+enum { SC_PQ_LOCAL = 0, SC_RR_LOCAL = 1, SC_PQ = 2, SC_RR = 3, SC_RR_PREV = 4, SC_QQ = 4, SC_BNORM = 5 /* reference norm of a solve, host-read only */,
+       SC_RR_POLL = 6, SC_COUNT = 8 };
 
 // where a CG kernel finds the dot product of the launch before it.  part == nullptr: already reduced, rr_n in
 // scal[s_rr], rr_{n-1} in scal[s_rr_old], p.q in scal[SC_PQ] (the eager protocol of the multi-GPU driver: SC_RR /
@@ -183,6 +187,11 @@ struct DotIn {
     int n = 0;
     int s_rr = SC_RR;
     int s_rr_old = SC_RR_PREV;
+    // single-reduction form: the scalars are the all-reduced block {SC_PQ, SC_RR, SC_QQ} of the PREVIOUS iteration (K1) / of this one (K2):
+    //   alpha = r.r / p.Ap;   K1: beta = (alpha^2 Ap.Ap - r.r) / r.r  — the recurrence |r_{n+1}|^2 = alpha^2 |Ap|^2 - |r_n|^2 predicts the
+    //   next r.r for beta only; the TRUE r.r of K2's residual joins the next message and forms the next alpha (part / n unused)
+    int sr = 0;
+    int skip_x = 0;           // sr: the pending x += alpha p has been applied by flush
 };
 
 struct StencilArgs {
@@ -200,6 +209,7 @@ struct StencilArgs {
     double* x;                // CG_K1 (updated in place)
     double* scal;             // device scalars (SC_*): read by K1 / K2
     double* partials;         // per-workgroup partial dot products
+    double* partials2 = nullptr;   // CG_K1, single-reduction form: per-workgroup partials of (A p).(A p), same indexing
     int mask_dirichlet;       // 1: Dirichlet rows give 0 (P applied to the output)
     int npt;                  // 7 or 15 (fast path)
     DotIn di;                 // CG_K1 / CG_K2: how the previous launch's dot product arrives
@@ -217,11 +227,12 @@ struct StencilArgs {
                               // x-face nodes of interior rows are computed by the marching kernel itself (edge lanes, halved in-face terms)
     int lk_lo = 0, lk_hi = 0; // marching kernel: restrict the launch to the local planes [lk_lo, lk_hi) (lk_hi > lk_lo; 0, 0 = all).  The
                               // multi-GPU loop launches K1 on the planes away from the ghosts first (halo exchange in flight)
+    int lk_lo2 = 0, lk_hi2 = 0;   // ... and a second, disjoint plane range in the SAME launch (the two edge planes of a slab: one launch, not two)
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
 };
 
-struct LaunchInfo { int grid = 0; int block = 256; };
+struct LaunchInfo { int grid = 0; int block = 256; bool dry = false; /* marching kernels: report the grid, launch nothing */ };
 
 int stencil_general(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 bool stencil_fast_supported(const GridDev& g, int element_mode);
@@ -240,12 +251,16 @@ int vec_zero(pdegpu_ctx* ctx, const GridDev& g, DevVec* v);
 // array of the slab) elsewhere
 int vec_set_bc(pdegpu_ctx* ctx, const GridDev& g, double* x, double fill, const double* nodal_dense, int only_bc);
 int vec_extrapolate(pdegpu_ctx* ctx, const GridDev& g, double* x, double* xprev, int first);   // x <- 2x - xprev; xprev <- x
-int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal);
+int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal, int sr = 0);
 int vec_k2(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* scal, double* partials, LaunchInfo* li,
            const DotIn& di = DotIn());
 // which: 0 p.q -> SC_PQ(_LOCAL); 1 r.r -> SC_RR_PREV <- SC_RR, SC_RR(_LOCAL); 2 r.r -> SC_RR(_LOCAL) only (SC_RR_PREV
 // already holds the previous value: end of a lazy chunk whose current slot is SC_RR_PREV)
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global);
+// single-reduction form: {SC_PQ, SC_QQ} <- sums of K1's two partial arrays (n1 each), SC_RR <- sum of K2's n3 partials (n3 < 0, the first
+// iteration: <- SC_RR_LOCAL, this slab's share of r_0.r_0 from the residual pass); one launch
+int vec_reduce_sr(pdegpu_ctx* ctx, const double* pq_part, const double* qq_part, int n1, const double* rr_part, int n3, double* scal);
+int vec_reduce_slot(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int slot);      // scal[slot] <- sum
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
 // weighted.hip
 int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, const double* lengths, double cM,

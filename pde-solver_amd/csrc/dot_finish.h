@@ -29,6 +29,14 @@ __device__ __forceinline__ double dot_in_sum(const double* __restrict__ part, in
 }
 // K1 side: rr_n (summed here or read from its slot), rr_{n-1}, pq_{n-1} -> alpha_{n-1}, beta_{n-1}
 __device__ __forceinline__ void cg_scalars_in(const DotIn& di, double* scal, double* sRed, double* alpha_prev, double* beta) {
+    if (di.sr) {
+        const double pq = scal[SC_PQ], rr_n = scal[SC_RR], qq = scal[SC_QQ];
+        const double a = (pq > 0.0 && rr_n > 0.0) ? rr_n / pq : 0.0;             // alpha_{n-1}; 0 on the first iteration (pq = 0)
+        const double rr_next = a * a * qq - rr_n;                                 // |r_n|^2 predicted from the block of iteration n-1
+        *alpha_prev = di.skip_x ? 0.0 : a;
+        *beta = (a > 0.0 && rr_next > 0.0) ? rr_next / rr_n : 0.0;                // a lost prediction restarts with steepest descent
+        return;
+    }
     double rr;
     if (di.part) {
         rr = dot_in_sum(di.part, di.n, sRed);
@@ -46,6 +54,10 @@ __device__ __forceinline__ void cg_scalars_in(const DotIn& di, double* scal, dou
 }
 // K2 side: alpha_n = rr_n / (p_n.q_n), p_n.q_n summed here or read from SC_PQ
 __device__ __forceinline__ double cg_alpha_in(const DotIn& di, double* scal, double* sRed) {
+    if (di.sr) {
+        const double pq_n = scal[SC_PQ];
+        return (pq_n > 0.0) ? scal[SC_RR] / pq_n : 0.0;
+    }
     double pq;
     if (di.part) {
         pq = dot_in_sum(di.part, di.n, sRed);

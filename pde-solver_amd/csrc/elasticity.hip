@@ -259,6 +259,8 @@ struct ElFastGeom {
     int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
     int nyg;                   // groups of 4 y-tiles (one workgroup each) of the y-hand-off variant
     int lkb, lke;              // local interior plane range [lkb, lke)
+    int lkb2, lke2, nzc1;      // plane-range launches of the slab loop: a second, disjoint range [lkb2, lke2) = the z-chunks nzc1 .. nzc-1 (the two edge
+                               // planes of a slab in ONE launch); nzc1 = nzc and an empty range otherwise
     int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
     int nb_bnd;                // boundary workgroups
     int bnd_last;              // 1: they take the LAST block indices
@@ -380,7 +382,8 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
                 else { j = 1 + (t - 2 * g.NX) / 2; i = ((t - 2 * g.NX) & 1) ? g.NX - 1 : 0; }
             } else {
                 e -= nlo + nhi;
-                lk = fg.lkb + (int)(e >> 2);
+                const int pl = (int)(e >> 2), n1 = fg.lke - fg.lkb;
+                lk = pl < n1 ? fg.lkb + pl : fg.lkb2 + (pl - n1);
                 j = (e & 2u) ? g.NY - 1 : 0;
                 i = (e & 1u) ? g.NX - 1 : 0;
             }
@@ -396,7 +399,8 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
                 i = (int)(e % (unsigned)g.NX);
             } else {
                 e -= fg.full_hi ? plane_nodes : 0u;
-                lk = fg.lkb + (int)(e / (unsigned)fg.ring);
+                const int pl = (int)(e / (unsigned)fg.ring), n1 = fg.lke - fg.lkb;
+                lk = pl < n1 ? fg.lkb + pl : fg.lkb2 + (pl - n1);
                 const int t = (int)(e % (unsigned)fg.ring);
                 if (t < g.NX) { j = 0; i = t; }
                 else if (t < 2 * g.NX) { j = g.NY - 1; i = t - g.NX; }
@@ -487,8 +491,9 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
         if (ghost_wave) yt = fg.nty - 1;                      // (loads stay inside the grid; nothing is stored)
         const int i = xt * kElXt + lane;                         // lanes 0 and 63: x-halo only (lane 0 of the first tile: the face x = 0)
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
-        const int lk0 = fg.lkb + zc * fg.zlen;
-        const int lk1 = min(lk0 + fg.zlen, fg.lke);
+        const bool range2 = zc >= fg.nzc1;
+        const int lk0 = range2 ? fg.lkb2 + (zc - fg.nzc1) * fg.zlen : fg.lkb + zc * fg.zlen;
+        const int lk1 = min(lk0 + fg.zlen, range2 ? fg.lke2 : fg.lke);
         if (zc >= 0 && lk0 < lk1) {
             // Loads are unconditional (branch-free, all of a plane in flight at once): every address a wave can form lies
             // inside the allocation — rows up to NY (= first row of the next plane), columns up to NX+60 < PX+64, planes
@@ -569,7 +574,8 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             const bool yz = (w.faces & 2) != 0, zf = ZF && (w.faces & 4) != 0;
             const bool ylo_wave = yz && !ghost_wave && yt == 0;                       // row 0 = the halo row below the first row tile
             const int r_hi = (yz && !ghost_wave && yt == fg.nty - 1) ? g.NY - j0 : 0;       // held-row index of the row NY-1 (2 .. RY+1)
-            const bool zlo_chunk = zf && fg.full_lo && zc == 0, zhi_chunk = zf && fg.full_hi && lk1 == fg.lke;
+            // (the chunk that starts at local plane 1 of a slab owning the global plane 0 / that ends below the global plane NZ-1)
+            const bool zlo_chunk = zf && fg.full_lo && lk0 == 1, zhi_chunk = zf && fg.full_hi && lk1 == g.nkl - 1;
             const bool out_f = lane >= 1 && lane <= kElXt && i >= 1 && i <= g.NX - 2;      // face nodes proper (the x-ends are edges of the box)
             auto face_finish = [&](long long o, const double* c0, double* y, const double* U, const double* Lw) __attribute__((always_inline)) {
 #pragma unroll
@@ -814,8 +820,10 @@ __global__ __launch_bounds__(256) void k_el_k2(ElArgs a, const double* __restric
 
 // p_n = z_n + beta p_{n-1};  x += alpha_{n-1} p_{n-1}   over the owned planes AND the ghost planes inside the domain
 // (so that the block apply that follows finds p_n on the ghosts: z and p_{n-1} were exchanged before)
+// Two index ranges in one launch: workgroups [0, nb1) take [first, first + total), the rest [first2, first2 + total2) — the two ghost planes of a
+// slab, updated after the halo exchange has completed (nb1 = gridDim.x and an empty second range otherwise).
 template <int D, bool NT>
-__global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, long long total) {
+__global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, long long total, long long first2, long long total2, int nb1) {
     __shared__ double sRed2[8];
     __shared__ double sDinv[27 * 3];
     if (threadIdx.x < 81) sDinv[threadIdx.x] = a.dinv[threadIdx.x];
@@ -852,15 +860,22 @@ __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, l
     // a.in = r; z = D^-1 r is formed here from the class of the node (Jacobi diagonal of its truncated stencil), so K2 does not
     // have to store z.  (i, j, lk) of a pair advance incrementally by the grid stride; lk starts at -1 when a lower ghost plane exists.
     const GridDev& g = a.g;
-    const long long total2 = total / 2;
+    const bool second = (int)blockIdx.x >= nb1;               // workgroup-uniform
+    if (second) {
+        first = first2;
+        total = total2;
+    }
+    const int bid = second ? (int)blockIdx.x - nb1 : (int)blockIdx.x, nbl = second ? (int)gridDim.x - nb1 : nb1;
+    const long long pairs = total / 2;
     const int PX2 = g.PX / 2;
-    const long long step = (long long)gridDim.x * 256;
+    const long long step = (long long)nbl * 256;
     const int di = (int)(step % PX2);
     const long long drow = step / PX2;
     const int dj = (int)(drow % g.NY), dk = (int)(drow / g.NY);
-    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long e = (long long)bid * 256 + threadIdx.x;
+    // (first is a multiple of PP, possibly negative: the lower ghost plane)
     int i2 = (int)(e % PX2), j = (int)((e / PX2) % g.NY), lk = (int)((e / PX2) / g.NY) + (int)(first / g.PP);
-    for (; e < total2; e += step) {
+    for (; e < pairs; e += step) {
         const long long idx = first + 2 * e;
         const int kg = g.k0 + lk;
         const int i = 2 * i2;
@@ -1092,26 +1107,6 @@ __global__ __launch_bounds__(256) void k_el_apply_mfma(GridDev g, long long stri
     }
 }
 
-// halo planes of the slab loop as ONE contiguous message per neighbour: [side][r0 r1 r2 p0 p1 p2][PP].  pack: first / last owned
-// plane -> send buffer; unpack: receive buffer -> ghost planes.  PP is a multiple of 16 doubles, origins are 128-B aligned.
-__global__ __launch_bounds__(256) void k_el_halo(double* __restrict__ r, double* __restrict__ p, long long stride, long long PP, int nkl,
-                                                  int lo, int hi, double* __restrict__ buf, int unpack) {
-    const long long per2 = PP / 2;                       // double2 per plane
-    const long long total = 12 * per2;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int slot = (int)(e / per2);                // side * 6 + vector * 3 + component
-        const long long w = e % per2;
-        const int side = slot / 6, vc = slot % 6;
-        if ((side == 0 && !lo) || (side == 1 && !hi)) continue;
-        double* v = (vc < 3 ? r : p) + (long long)(vc % 3) * stride;
-        const long long plane = unpack ? (side == 0 ? -1 : nkl) : (side == 0 ? 0 : nkl - 1);
-        double2* g2 = reinterpret_cast<double2*>(v + plane * PP) + w;
-        double2* b2 = reinterpret_cast<double2*>(buf) + e;
-        if (unpack) *g2 = *b2;
-        else *b2 = *g2;
-    }
-}
-
 inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
     long long nb = (n + 255) / 256;
     const long long cap = 8LL * ctx->num_cu;
@@ -1158,7 +1153,8 @@ struct ElSession {
     ElFastGeom fgeom{};
     unsigned* d_mask = nullptr;
     int last_apply_blocks = 1;      // workgroups (= partials) of the most recent apply launch
-    double *halo_send = nullptr, *halo_recv = nullptr;      // [2 sides][6 planes][PP] each (slab loop, allocated on first use)
+    int k1_parts = 0;               // workgroups (partials) of the parts of a split K1 so far
+    size_t npart3 = 0;              // doubles in part3
 
     double* alloc_vec() {
         double* base = nullptr;
@@ -1177,8 +1173,6 @@ struct ElSession {
         if (part2) (void)hipFree(part2);
         if (part3) (void)hipFree(part3);
         if (d_mask) (void)hipFree(d_mask);
-        if (halo_send) (void)hipFree(halo_send);
-        if (halo_recv) (void)hipFree(halo_recv);
         if (h_pin) (void)hipHostFree(h_pin);
         tables_free(&ht);
     }
@@ -1334,15 +1328,21 @@ bool el_face_weights(const double* tab /*[27][15][9]*/, int axis, double (*G)[3]
 
 bool el_vec_nt(const ElSession* s);
 
-void el_fast_geometry(ElSession* s) {
+// Launch geometry of the marching apply over the local planes [a, b) (and, in the same launch, [a2, b2): the two edge planes of a slab with
+// neighbours); the whole slab is (0, nkl).  A range takes the slab's global end plane (z-face: every node a boundary node) along when it
+// contains it.
+void el_fast_geometry_range(const ElSession* s, int a, int b, int a2, int b2, ElFastGeom* out) {
     const GridDev& g = s->g;
-    ElFastGeom& fg = s->fgeom;
+    ElFastGeom& fg = *out;
     const int RY = s->fast_ry;
-    fg.full_lo = g.k0 == 0 ? 1 : 0;
-    fg.full_hi = g.k0 + g.nkl == g.NZ ? 1 : 0;
-    fg.lkb = fg.full_lo;
-    fg.lke = g.nkl - fg.full_hi;
-    const int planes = std::max(0, fg.lke - fg.lkb);
+    const bool two = b2 > a2;
+    fg.full_lo = (g.k0 == 0 && a == 0) ? 1 : 0;
+    fg.full_hi = (g.k0 + g.nkl == g.NZ && (two ? b2 : b) == g.nkl) ? 1 : 0;
+    fg.lkb = a + fg.full_lo;
+    fg.lke = b - ((fg.full_hi && !two) ? 1 : 0);
+    fg.lkb2 = two ? a2 : 0;
+    fg.lke2 = two ? b2 - fg.full_hi : 0;
+    const int planes = std::max(0, fg.lke - fg.lkb), planes2 = std::max(0, fg.lke2 - fg.lkb2);
     const bool xface = s->w36.faces != 0;
     fg.ntx = (g.NX - (xface ? 1 : 2) + kElXt - 1) / kElXt;
     fg.nty = (g.NY - 2 + RY - 1) / RY;
@@ -1355,30 +1355,34 @@ void el_fast_geometry(ElSession* s) {
     long long nzc = (waves + cols - 1) / cols;
     nzc = std::max(1LL, std::min<long long>(nzc, std::max(1, planes)));
     fg.zlen = std::max(1, (int)((planes + nzc - 1) / nzc));
-    fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
+    if (planes == 0 && planes2 > 0) fg.zlen = planes2;
+    fg.nzc1 = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
+    fg.nzc = fg.nzc1 + (planes2 > 0 ? (planes2 + fg.zlen - 1) / fg.zlen : 0);
     fg.nb_fast = (int)((cols * fg.nzc + 3) / 4);
     fg.nb_fast = (fg.nb_fast + 7) / 8 * 8;          // multiple of 8 for the XCD-aware tile order (surplus waves find zc >= nzc and idle)
     fg.ring = 2 * g.NX + (xface ? 0 : 2 * (g.NY - 2));        // boundary nodes of an interior plane left to the class-table pass
-    fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * g.NX * g.NY + (long long)planes * fg.ring;
+    fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * g.NX * g.NY + (long long)(planes + planes2) * fg.ring;
     if (s->w36.faces & 2) {                                   // y-faces folded: 4 corners per interior plane; the planes 0 / NZ-1: perimeter | whole
         fg.ring = 4;
         const long long per = (s->w36.faces & 4) ? 2LL * g.NX + 2LL * (g.NY - 2) : (long long)g.NX * g.NY;
-        fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * per + 4LL * planes;
+        fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * per + 4LL * (planes + planes2);
     }
     fg.nb_bnd = (int)std::min<long long>((fg.nbnd + 255) / 256, 2LL * s->ctx->num_cu);      // grid-stride: the 29 KB table is loaded per workgroup
     fg.bnd_last = s->ctx->el_bnd_last != 0 ? 1 : 0;
     fg.mask = s->d_mask;
     fg.gf = reinterpret_cast<const double*>(s->d_mask + 32);
 }
+void el_fast_geometry(ElSession* s) { el_fast_geometry_range(s, 0, s->g.nkl, 0, 0, &s->fgeom); }
 
 // non-temporal hints where the vectors are HBM-resident (one component set beyond 64 MiB, the heat kernels' threshold); el_fast_nt = 0 | 1 forces
 bool el_vec_nt(const ElSession* s) {
     return s->ctx->el_fast_nt < 0 ? (long long)s->stride * 3 * 8 > (64LL << 20) : (s->ctx->el_fast_nt & 1) != 0;
 }
 
-int el_apply(ElSession* s, const ElArgs& a, int mode) {
+// fgr != nullptr: a plane-range launch of the marching apply (el_fast_geometry_range)
+int el_apply(ElSession* s, const ElArgs& a, int mode, const ElFastGeom* fgr = nullptr) {
     if (mode == APPLY_PLAIN && s->fast && s->ctx->el_fast) {
-        const ElFastGeom& fg = s->fgeom;
+        const ElFastGeom& fg = fgr ? *fgr : s->fgeom;
         const int nb = fg.nb_fast + fg.nb_bnd;
         const bool yx = s->ctx->el_fast_yx != 0;
         // (ZF = with the code for the planes 0 / NZ-1: it costs 60 VGPRs, so slabs without such a plane and sessions that leave those
@@ -1447,7 +1451,34 @@ int el_lazy_finish(ElSession* s, ElLazy* lazy) {
 // K1 = flat p-update (+ deferred x-update) followed by the plain block apply q = P A p with the p.q partials.
 // (The heat path recomputes p at the stencil neighbours to save an HBM pass; here everything is cache-resident and
 // the 15 x 3 x 2 neighbour reads of the fused form cost more than the extra launch: measured 110 -> ~60 us.)
-int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
+// The p-update covers the ghost planes too: p_n there comes from the exchanged r and the slab's own p_{n-1} of the ghost plane (same formula,
+// same global scalars as the neighbour rank), so ONLY r travels in the halo exchange.
+// part (slab loop, marching apply): -1 = the whole K1; 0 = everything that reads no ghost plane — the p-update of the owned planes and the apply
+// on the planes away from the ghosts — while the r planes travel; 1 = p-update of the ghost planes, apply on the edge planes (ONE launch for
+// both), p.q reduce.
+bool el_k1_splittable(const ElSession* s) {
+    const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
+    return s->D == 3 && s->fast && s->ctx->el_fast && (lo || hi) && s->g.nkl >= 4;
+}
+int el_pupdate_launch(ElSession* s, const ElArgs& a, long long first, long long total, long long first2 = 0, long long total2 = 0) {
+    int nb1 = s->nblk, nb = s->nblk;
+    if (total2 > 0) {                                          // two short ranges (ghost planes): workgroups in proportion, at least one each
+        auto want = [&](long long t) { return (int)std::max<long long>(1, std::min<long long>(s->nblk, (t / 2 + 255) / 256)); };
+        nb1 = want(total);
+        nb = nb1 + want(total2);
+    } else if (total < (long long)s->g.nkl * s->g.PP) {
+        nb1 = nb = (int)std::max<long long>(1, std::min<long long>(s->nblk, (total / 2 + 255) / 256));
+    }
+    if (s->D == 3) {
+        if (el_vec_nt(s)) hipLaunchKernelGGL((k_el_pupdate<3, true>), dim3(nb), dim3(256), 0, s->ctx->stream, a, first, total, first2, total2, nb1);
+        else hipLaunchKernelGGL((k_el_pupdate<3, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, first, total, first2, total2, nb1);
+    } else {
+        hipLaunchKernelGGL((k_el_pupdate<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, first, total, first2, total2, nb1);
+    }
+    PG_HIP(s->ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+int el_k1(ElSession* s, ElLazy* lazy = nullptr, int part = -1) {
     ElArgs a = s->args();
     a.in = s->r;                 // the p-update forms z = D^-1 r itself
     a.p_old = s->p[s->pcur];
@@ -1467,19 +1498,48 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr) {
             a.s_rz_old = lazy->cur == ESC_RZ ? ESC_RZ_PREV : ESC_RZ;
         }
     }
-    const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
-    const long long first = -(long long)lo * s->g.PP, total = (long long)(s->g.nkl + lo + hi) * s->g.PP;
-    if (s->D == 3) {
-        if (el_vec_nt(s)) hipLaunchKernelGGL((k_el_pupdate<3, true>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
-        else hipLaunchKernelGGL((k_el_pupdate<3, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
-    } else {
-        hipLaunchKernelGGL((k_el_pupdate<2, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, first, total);
+    const GridDev& g = s->g;
+    const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;
+    if (part >= 0 && !el_k1_splittable(s)) {                   // a driver may always call part 0 then part 1
+        if (part == 0) return PDEGPU_OK;
+        part = -1;
     }
-    PG_HIP(s->ctx, hipGetLastError());
-    s->pcur ^= 1;
     ElArgs b = s->args();
-    b.in = s->p[s->pcur];
     b.out = s->q;
+    if (part == 0) {
+        PG_TRY(el_pupdate_launch(s, a, 0, (long long)g.nkl * g.PP));
+        ElFastGeom fgr;
+        el_fast_geometry_range(s, lo, g.nkl - hi, 0, 0, &fgr);
+        b.in = s->p[1 - s->pcur];
+        b.partials = s->part3;
+        PG_TRY(el_apply(s, b, APPLY_PLAIN, &fgr));
+        s->k1_parts = s->last_apply_blocks;
+        return PDEGPU_OK;
+    }
+    if (part == 1) {
+        const long long lo_first = -(long long)g.PP, hi_first = (long long)g.nkl * g.PP;
+        if (lo && hi) PG_TRY(el_pupdate_launch(s, a, lo_first, g.PP, hi_first, g.PP));
+        else PG_TRY(el_pupdate_launch(s, a, lo ? lo_first : hi_first, g.PP));
+        s->pcur ^= 1;
+        ElFastGeom fgr;
+        if (lo && hi) el_fast_geometry_range(s, 0, 1, g.nkl - 1, g.nkl, &fgr);
+        else if (lo) el_fast_geometry_range(s, 0, 1, 0, 0, &fgr);
+        else el_fast_geometry_range(s, g.nkl - 1, g.nkl, 0, 0, &fgr);
+        if ((size_t)s->k1_parts + fgr.nb_fast + fgr.nb_bnd > s->npart3)
+            return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "split K1: %d + %d workgroups exceed the %zu partials of the session", s->k1_parts,
+                                  fgr.nb_fast + fgr.nb_bnd, s->npart3);
+        b.in = s->p[s->pcur];
+        b.partials = s->part3 + s->k1_parts;
+        PG_TRY(el_apply(s, b, APPLY_PLAIN, &fgr));
+        s->k1_parts += s->last_apply_blocks;
+        hipLaunchKernelGGL(k_el_reduce, dim3(1), dim3(256), 0, s->ctx->stream, s->part3, (const double*)nullptr, s->k1_parts, s->scal, 0);
+        PG_HIP(s->ctx, hipGetLastError());
+        return PDEGPU_OK;
+    }
+    const long long first = -(long long)lo * g.PP, total = (long long)(g.nkl + lo + hi) * g.PP;
+    PG_TRY(el_pupdate_launch(s, a, first, total));
+    s->pcur ^= 1;
+    b.in = s->p[s->pcur];
     b.partials = s->part3;
     PG_TRY(el_apply(s, b, APPLY_PLAIN));
     if (lazy) return PDEGPU_OK;
@@ -1552,7 +1612,18 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
         el_fast_geometry(s);
         if (s->fgeom.nbnd > 0x7fffffffLL) s->fast = false;
         npart = std::max(npart, (size_t)s->fgeom.nb_fast + (size_t)((s->fgeom.nbnd + 255) / 256));
+        // a split K1 (slab with neighbours) appends the partials of its two launches
+        const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
+        if ((lo || hi) && s->g.nkl >= 4) {
+            ElFastGeom f0, f1;
+            el_fast_geometry_range(s, lo, s->g.nkl - hi, 0, 0, &f0);
+            if (lo && hi) el_fast_geometry_range(s, 0, 1, s->g.nkl - 1, s->g.nkl, &f1);
+            else if (lo) el_fast_geometry_range(s, 0, 1, 0, 0, &f1);
+            else el_fast_geometry_range(s, s->g.nkl - 1, s->g.nkl, 0, 0, &f1);
+            npart = std::max(npart, (size_t)f0.nb_fast + f0.nb_bnd + f1.nb_fast + f1.nb_bnd);
+        }
     }
+    s->npart3 = npart;
     PG_HIP(ctx, hipMalloc(&s->part, npart * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->part2, npart * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->part3, npart * sizeof(double)));
@@ -1935,6 +2006,11 @@ extern "C" void pdegpu_el_session_destroy(pdegpu_el_session* h) {
 
 extern "C" int pdegpu_el_session_begin(pdegpu_el_session* h) { return h ? el_begin(&h->s, &h->el) : PDEGPU_EINVAL; }
 extern "C" int pdegpu_el_session_k1(pdegpu_el_session* h) { return h ? el_k1(&h->s) : PDEGPU_EINVAL; }
+extern "C" int pdegpu_el_session_can_split_k1(const pdegpu_el_session* h) { return (h && el_k1_splittable(&h->s)) ? 1 : 0; }
+extern "C" int pdegpu_el_session_k1_part(pdegpu_el_session* h, int part) {
+    if (!h || (part != 0 && part != 1)) return PDEGPU_EINVAL;
+    return el_k1(&h->s, nullptr, part);
+}
 extern "C" int pdegpu_el_session_k2(pdegpu_el_session* h) { return h ? el_k2(&h->s, 1) : PDEGPU_EINVAL; }
 extern "C" int pdegpu_el_session_flush(pdegpu_el_session* h) { return h ? el_flush(&h->s) : PDEGPU_EINVAL; }
 extern "C" double* pdegpu_el_session_scalars(pdegpu_el_session* h) { return h ? h->s.scal : nullptr; }
@@ -1954,37 +2030,6 @@ extern "C" void* pdegpu_el_session_plane_ptr(pdegpu_el_session* h, int vec, int 
     return base + (long long)comp * h->s.stride + which * h->s.g.PP;
 }
 
-// one contiguous halo message per neighbour: buffers [2 sides][r0 r1 r2 p0 p1 p2][plane_doubles]; side 0 = lower neighbour.
-// which = 0 send, 1 receive; side_doubles = 6 * plane_doubles
-extern "C" void* pdegpu_el_session_halo_buffer(pdegpu_el_session* h, int which, int side) {
-    if (!h || (which != 0 && which != 1) || (side != 0 && side != 1)) return nullptr;
-    ElSession& s = h->s;
-    const size_t bytes = (size_t)12 * s.g.PP * sizeof(double);
-    if (!s.halo_send) {
-        (void)hipSetDevice(s.ctx->device);
-        if (hipMalloc(&s.halo_send, bytes) != hipSuccess || hipMalloc(&s.halo_recv, bytes) != hipSuccess) return nullptr;
-        (void)hipMemsetAsync(s.halo_send, 0, bytes, s.ctx->stream);
-        (void)hipMemsetAsync(s.halo_recv, 0, bytes, s.ctx->stream);
-    }
-    return (which == 0 ? s.halo_send : s.halo_recv) + (size_t)side * 6 * s.g.PP;
-}
-// unpack = 0: first / last owned plane of r and p (current) -> send buffers; 1: receive buffers -> ghost planes.  Sides
-// without a slab neighbour are skipped.
-extern "C" int pdegpu_el_session_halo_pack(pdegpu_el_session* h, int unpack) {
-    if (!h) return PDEGPU_EINVAL;
-    ElSession& s = h->s;
-    if (!pdegpu_el_session_halo_buffer(h, 0, 0)) return pdegpu_set_err(s.ctx, PDEGPU_EHIP, "hipMalloc of the halo buffers failed");
-    const int lo = s.g.k0 > 0 ? 1 : 0, hi = (s.g.k0 + s.g.nkl < s.g.NZ) ? 1 : 0;
-    if (!lo && !hi) return PDEGPU_OK;
-    const long long total = 12 * (s.g.PP / 2);
-    const int nb = (int)std::min<long long>((total + 255) / 256, 2LL * s.ctx->num_cu);
-    hipLaunchKernelGGL(k_el_halo, dim3(nb), dim3(256), 0, s.ctx->stream, s.r, s.p[s.pcur], s.stride, s.g.PP, s.g.nkl, lo, hi,
-                       unpack ? s.halo_recv : s.halo_send, unpack);
-    PG_HIP(s.ctx, hipGetLastError());
-    return PDEGPU_OK;
-}
-
-// synchronises; out4 = {p.q, r.z, r.r, r.z of the previous iteration} (global values once the host has all-reduced them)
 extern "C" int pdegpu_el_session_scalars_host(pdegpu_el_session* h, double* out4) {
     if (!h || !out4) return PDEGPU_EINVAL;
     double sc[ESC_COUNT];

@@ -34,7 +34,7 @@ struct pdegpu_session {
     DevVec xprev;                  // u^{n-1} of a transient solve (allocated on first use)
     int pcur = 0;
     double* d_scal = nullptr;
-    double* d_part = nullptr;       // [2][npart]: per-workgroup partials; the second half takes K2's in the lazy loop
+    double* d_part = nullptr;       // [3][npart]: per-workgroup partials; the second block takes K2's (lazy loop, single-reduction form), the third K1's Ap.Ap
     int npart = 0;
     double* d_dense = nullptr;
     double* h_pin = nullptr;       // pinned host scalars
@@ -42,11 +42,20 @@ struct pdegpu_session {
     int last_iters = 0;            // CG iterations of the previous linear solve of this session (first poll of the next one)
     // per-call kernel timing of the stepwise protocol (pdegpu_session_set_timing): event pairs around every k1 part / k2 launch
     bool timing = false;
+    int timing_every = 1;          // event pairs on every timing_every-th iteration only (the records themselves cost stream time at high launch rates)
+    long long timing_iter = 0;     // iterations seen since set_timing
+    bool timing_now = false;       // the current iteration is a sampled one
     std::vector<hipEvent_t> tev;   // pairs: [2 i] start, [2 i + 1] stop
     std::vector<int> tev_kind;     // 0 K1 (a split K1 contributes several pairs), 1 K2
     size_t tev_used = 0;
     long long timed_k1 = 0, timed_k2 = 0;
     int k1_parts = 0;              // workgroups (partials) launched by the parts of a split K1 so far
+    // single-reduction form of the stepwise protocol (pdegpu_session_set_cg_variant 1): d_part = [p.Ap | r.r of K2 | Ap.Ap], npart each
+    int variant = 0;
+    bool sr_k2_pending = false;    // K2's r.r partials (d_part + npart) have not been summed into SC_RR yet: the next K1's reduce launch does
+    int sr_k2_grid = 0;
+    bool sr_skip_x = false;        // flush has applied the pending x += alpha p: the next K1 must not
+    int rr_slot = SC_RR;           // the scalar pdegpu_session_rr reports (SC_RR_POLL after pdegpu_session_sr_poll)
     Persist2d* p2d = nullptr;      // 2-D sessions: register-resident persistent CG (created on first use)
     // weighted (curvilinear) operators: per-node coefficients + Jacobi-PCG
     bool weighted = false;
@@ -228,6 +237,7 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     if (a.bnd_n > 0x7fffffffLL) return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "hybrid path: more than 2^31 boundary nodes");
     const int n1 = li_fast ? li_fast->grid : 0;
     a.partials = a.partials + n1;                 // appended to the marching launch's (K2: wherever the caller keeps its r.r partials)
+    if (a.partials2) a.partials2 = a.partials2 + n1;
     LaunchInfo l2;
     PG_TRY(stencil_general(s->ctx, a, mode, &l2));
     if (li_fast) li_fast->grid = n1 + l2.grid;
@@ -312,9 +322,18 @@ bool k2_is_stencil(const pdegpu_session* s) {
 
 // lk_lo < lk_hi: one part of a split K1 (marching sessions only) — the launch covers the local planes [lk_lo, lk_hi), appends its
 // partials at part_off and leaves the p ping-pong alone (the caller flips it after the last part)
-int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_lo = 0, int lk_hi = 0, int part_off = 0) {
+// single-reduction form: how K1 / K2 read the all-reduced block {SC_PQ, SC_RR, SC_QQ} (dot_finish.h)
+DotIn sr_dot_in(const pdegpu_session* s) {
+    DotIn d;
+    d.sr = 1;
+    d.skip_x = s->sr_skip_x ? 1 : 0;
+    return d;
+}
+
+int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_lo = 0, int lk_hi = 0, int part_off = 0, int lk_lo2 = 0, int lk_hi2 = 0) {
     StencilArgs a{};
     a.di = di;
+    if (di.sr) a.partials2 = s->d_part + 2 * (size_t)s->npart + part_off;
     a.g = s->g;
     a.in = s->weighted ? s->z.v : s->r.v;          // PCG: p = z + beta p with z = D^-1 r
     if (s->weighted) {
@@ -334,6 +353,8 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
     if (part) {
         a.lk_lo = lk_lo;
         a.lk_hi = lk_hi;
+        a.lk_lo2 = lk_lo2;
+        a.lk_hi2 = lk_hi2;
     }
     int rc;
     if (s->plane2d) {
@@ -691,7 +712,7 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     if (s->tile3d && stencil_tile3d_grid(s->g) > npart) npart = (int)stencil_tile3d_grid(s->g);
     if (rc == PDEGPU_OK && hipMalloc(&s->d_scal, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc scal");
     s->npart = npart;
-    if (rc == PDEGPU_OK && hipMalloc(&s->d_part, 2 * (size_t)npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
+    if (rc == PDEGPU_OK && hipMalloc(&s->d_part, 3 * (size_t)npart * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc partials");
     if (rc == PDEGPU_OK && hipHostMalloc(&s->h_pin, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipHostMalloc");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset scal");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_part, 0, npart * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset partials");
@@ -709,6 +730,8 @@ extern "C" int pdegpu_session_begin(pdegpu_session* s, double x_fill) {
     PG_TRY(vec_zero(ctx, s->g, &s->p[0]));
     PG_TRY(vec_zero(ctx, s->g, &s->p[1]));
     s->pcur = 0;
+    s->sr_k2_pending = s->sr_skip_x = false;
+    s->rr_slot = SC_RR;
     PG_TRY(set_bc_ext(s, s->x.v, x_fill, nullptr, 0));
     // constant-source right-hand side b = M (0 + f) = f m  (fenics_mcp_server.py:262, 394, 658)
     PG_TRY(vec_zero(ctx, s->g, &s->q));
@@ -740,13 +763,15 @@ extern "C" int pdegpu_session_residual(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     PG_TRY(op_residual(s, s->x.v, s->b.v, s->r.v, &li));
+    s->sr_k2_pending = false;      // r is recomputed: whatever a K2 left in its partials is void, scalars[3] is current again
+    s->rr_slot = SC_RR;
     return residual_finish(s, &li);
 }
 
 namespace {
 // event pair around one launch of the stepwise protocol (timing on): returns the index of the start event, -1 when off
 int timed_begin(pdegpu_session* s, int kind) {
-    if (!s->timing) return -1;
+    if (!s->timing || !s->timing_now) return -1;
     if (s->tev_used + 2 > s->tev.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
@@ -764,57 +789,103 @@ int timed_begin(pdegpu_session* s, int kind) {
 void timed_end(pdegpu_session* s, int at) {
     if (at >= 0) (void)hipEventRecord(s->tev[at + 1], s->ctx->stream);
 }
+// called where an iteration starts (k1 / k1_part(0)): decides whether this iteration's launches are bracketed by events
+void timed_iteration(pdegpu_session* s) {
+    if (!s->timing) return;
+    s->timing_now = (s->timing_iter % s->timing_every) == 0;
+    ++s->timing_iter;
+}
 // a K1 that can be split into plane ranges: marching kernel alone (no boundary pass, no one-round tiles), 3-D
 bool k1_splittable(const pdegpu_session* s) { return s->fast && !s->hybrid && !s->tile3d && !s->plane2d && s->g.dim == 3 && !s->weighted; }
 }  // namespace
+
+namespace {
+// single-reduction form, after the last launch of K1: ONE reduce launch sums K1's p.Ap and Ap.Ap partials and the r.r partials the K2 of the
+// iteration before left (on the first iteration: this slab's r_0.r_0 of the residual pass, SC_RR_LOCAL) into the block {SC_PQ, SC_RR, SC_QQ},
+// which the multi-GPU host all-reduces as one 24-byte message
+int sr_after_k1(pdegpu_session* s, int n1) {
+    PG_TRY(vec_reduce_sr(s->ctx, s->d_part, s->d_part + 2 * (size_t)s->npart, n1, s->d_part + s->npart, s->sr_k2_pending ? s->sr_k2_grid : -1, s->d_scal));
+    s->sr_k2_pending = false;
+    s->sr_skip_x = false;
+    s->rr_slot = SC_RR;
+    return PDEGPU_OK;
+}
+}  // namespace
+
+// 0 = classic CG (two scalar reductions per iteration: p.Ap after k1, r.r after k2); 1 = single-reduction form: k1 also sums Ap.Ap, k2's
+// r.r stays in its partials, and after k1 the block scalars[2..4] = {p.Ap, r.r, Ap.Ap} is the ONE message to all-reduce per iteration
+// (fenics_mcp_server.py:707-716 distributed).  Choose before begin() / residual(); not for weighted (Jacobi-PCG) sessions.
+extern "C" int pdegpu_session_set_cg_variant(pdegpu_session* s, int variant) {
+    if (!s) return PDEGPU_EINVAL;
+    if (variant != 0 && variant != 1) return pdegpu_set_err(s->ctx, PDEGPU_EINVAL, "cg variant must be 0 (classic) or 1 (single reduction)");
+    if (variant == 1 && s->weighted) return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "single-reduction CG: not for weighted (preconditioned) sessions");
+    s->variant = variant;
+    s->sr_k2_pending = false;
+    s->sr_skip_x = false;
+    s->rr_slot = SC_RR;
+    return PDEGPU_OK;
+}
+extern "C" int pdegpu_session_cg_variant(const pdegpu_session* s) { return s ? s->variant : -1; }
 
 extern "C" int pdegpu_session_k1(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
+    timed_iteration(s);
     const int at = timed_begin(s, 0);
-    PG_TRY(op_k1(s, &li));
+    PG_TRY(op_k1(s, &li, s->variant ? sr_dot_in(s) : DotIn()));
     timed_end(s, at);
-    if (s->timing) ++s->timed_k1;
+    if (s->timing && s->timing_now) ++s->timed_k1;
+    if (s->variant) return sr_after_k1(s, li.grid);
     return empty_dot(s, li, 0);
 }
 
 extern "C" int pdegpu_session_can_split_k1(const pdegpu_session* s) { return (s && k1_splittable(s)) ? 1 : 0; }
 
 // K1 in two steps for the multi-GPU loop: part 0 = the owned planes whose stencil does not touch a ghost plane (launched while
-// the halo exchange is in flight), part 1 = the one or two planes next to the ghosts + the sum of all partials.  Sessions
-// whose K1 cannot be split do nothing in part 0 and the whole K1 in part 1, so a driver may always call 0 then 1.
+// the halo exchange is in flight), part 1 = the one or two planes next to the ghosts — ONE launch covering both — + the sum of all
+// partials.  Sessions whose K1 cannot be split do nothing in part 0 and the whole K1 in part 1, so a driver may always call 0 then 1.
 extern "C" int pdegpu_session_k1_part(pdegpu_session* s, int part) {
     if (!s || (part != 0 && part != 1)) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     if (!k1_splittable(s)) return part == 0 ? PDEGPU_OK : pdegpu_session_k1(s);
     const GridDev& g = s->g;
     const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;      // slab neighbours below / above
+    const DotIn di = s->variant ? sr_dot_in(s) : DotIn();
     LaunchInfo li;
     if (part == 0) {
         s->k1_parts = 0;
+        timed_iteration(s);
         const int a0 = lo, a1 = g.nkl - hi;
         if (a1 > a0) {
             const int at = timed_begin(s, 0);
-            PG_TRY(op_k1(s, &li, DotIn(), a0, a1, 0));
+            PG_TRY(op_k1(s, &li, di, a0, a1, 0));
             timed_end(s, at);
             s->k1_parts = li.grid;
         }
         return PDEGPU_OK;
     }
     // edge planes: plane 0 (needs ghost -1) and plane nkl-1 (needs ghost nkl); one plane can be both
-    const int edges[2][2] = {{0, lo ? 1 : 0}, {hi ? std::max(g.nkl - 1, lo ? 1 : 0) : 0, hi ? g.nkl : 0}};
-    for (int e = 0; e < 2; ++e) {
-        if (edges[e][1] <= edges[e][0]) continue;
+    int e0[2] = {0, lo ? 1 : 0}, e1[2] = {hi ? std::max(g.nkl - 1, lo ? 1 : 0) : 0, hi ? g.nkl : 0};
+    if (e0[1] <= e0[0]) { e0[0] = e1[0]; e0[1] = e1[1]; e1[0] = e1[1] = 0; }      // a single edge goes first
+    if (e0[1] > e0[0]) {
+        // the partials of all parts share one block of npart doubles: ask for the launch's grid first
+        LaunchInfo dry;
+        dry.dry = true;
+        const int pcur = s->pcur;
+        PG_TRY(op_k1(s, &dry, di, e0[0], e0[1], s->k1_parts, e1[0], e1[1]));
+        s->pcur = pcur;
+        if (s->k1_parts + dry.grid > s->npart)
+            return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "split K1: %d + %d workgroups exceed the %d partials of the session", s->k1_parts, dry.grid, s->npart);
         const int at = timed_begin(s, 0);
-        PG_TRY(op_k1(s, &li, DotIn(), edges[e][0], edges[e][1], s->k1_parts));
+        PG_TRY(op_k1(s, &li, di, e0[0], e0[1], s->k1_parts, e1[0], e1[1]));
         timed_end(s, at);
         s->k1_parts += li.grid;
     }
     s->pcur ^= 1;
-    if (s->timing) ++s->timed_k1;
-    li.grid = s->k1_parts;
-    return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, 0, 1);
+    if (s->timing && s->timing_now) ++s->timed_k1;
+    if (s->variant) return sr_after_k1(s, s->k1_parts);
+    return vec_reduce(s->ctx, s->d_part, s->k1_parts, s->d_scal, 0, 1);
 }
 
 extern "C" int pdegpu_session_k2(pdegpu_session* s) {
@@ -822,10 +893,35 @@ extern "C" int pdegpu_session_k2(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
     const int at = timed_begin(s, 1);
+    if (s->variant) {
+        // r -= alpha A p with alpha from the all-reduced block; the r.r partials wait in the second block for the next K1's reduce launch
+        PG_TRY(op_k2(s, &li, sr_dot_in(s), s->d_part + s->npart));
+        timed_end(s, at);
+        if (s->timing && s->timing_now) ++s->timed_k2;
+        s->sr_k2_pending = true;
+        s->sr_k2_grid = li.grid;
+        return PDEGPU_OK;
+    }
     PG_TRY(op_k2(s, &li));
     timed_end(s, at);
-    if (s->timing) ++s->timed_k2;
+    if (s->timing && s->timing_now) ++s->timed_k2;
     return empty_dot(s, li, 1);
+}
+
+// single-reduction form: r.r of the residual the last k2 left -> scalars[6] (this slab's sum; the multi-GPU host all-reduces that one slot, 8
+// bytes, then reads it with pdegpu_session_rr).  For convergence polls only — the iteration itself never needs it.  Without a pending k2
+// (right after residual / k1) scalars[3] is current and rr reports that.
+extern "C" int pdegpu_session_sr_poll(pdegpu_session* s) {
+    if (!s) return PDEGPU_EINVAL;
+    if (!s->variant) return pdegpu_set_err(s->ctx, PDEGPU_EINVAL, "sr_poll: the session runs the classic form");
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    if (!s->sr_k2_pending) {
+        s->rr_slot = SC_RR;
+        return PDEGPU_OK;
+    }
+    PG_TRY(vec_reduce_slot(s->ctx, s->d_part + s->npart, s->sr_k2_grid, s->d_scal, SC_RR_POLL));
+    s->rr_slot = SC_RR_POLL;
+    return PDEGPU_OK;
 }
 
 // kernel timing of the stepwise protocol (k1 / k1_part / k2): on = 1 starts a fresh measurement; get_stats synchronises and
@@ -833,6 +929,9 @@ extern "C" int pdegpu_session_k2(pdegpu_session* s) {
 extern "C" int pdegpu_session_set_timing(pdegpu_session* s, int on) {
     if (!s) return PDEGPU_EINVAL;
     s->timing = on != 0;
+    s->timing_every = on > 1 ? on : 1;
+    s->timing_iter = 0;
+    s->timing_now = false;
     s->tev_used = 0;
     s->timed_k1 = s->timed_k2 = 0;
     return PDEGPU_OK;
@@ -887,6 +986,8 @@ extern "C" int pdegpu_session_lift_norm(pdegpu_session* s) {
     PG_TRY(set_bc_ext(s, s->q.v, 0.0, nullptr, 0));
     PG_TRY(op_residual(s, s->q.v, s->b.v, s->r.v, &li));
     PG_TRY(residual_finish(s, &li));
+    s->sr_k2_pending = false;
+    s->rr_slot = SC_RR;
     return vec_zero(ctx, s->g, &s->q);
 }
 extern "C" int pdegpu_session_reset_cg(pdegpu_session* s) {
@@ -894,15 +995,18 @@ extern "C" int pdegpu_session_reset_cg(pdegpu_session* s) {
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     PG_HIP(s->ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), s->ctx->stream));
     s->pcur = 0;      // the old p only ever meets beta = 0 (see linear_solve)
+    s->sr_k2_pending = s->sr_skip_x = false;
+    s->rr_slot = SC_RR;
     return PDEGPU_OK;
 }
 
 extern "C" int pdegpu_session_flush(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    PG_TRY(vec_axpy_flush(s->ctx, s->g, s->x.v, s->p[s->pcur].v, s->d_scal));
+    PG_TRY(vec_axpy_flush(s->ctx, s->g, s->x.v, s->p[s->pcur].v, s->d_scal, s->variant));
     // the pending update is applied: make the next K1 skip it (alpha_prev = 0) while beta stays valid
-    PG_HIP(s->ctx, hipMemsetAsync(s->d_scal + SC_PQ, 0, sizeof(double), s->ctx->stream));
+    if (s->variant) s->sr_skip_x = true;          // (beta needs p.Ap too in this form: the block stays, the kernel gets a flag)
+    else PG_HIP(s->ctx, hipMemsetAsync(s->d_scal + SC_PQ, 0, sizeof(double), s->ctx->stream));
     return PDEGPU_OK;
 }
 
@@ -924,6 +1028,7 @@ int persist2d_iterate(pdegpu_session* s, int iters, double target, int* done, in
 extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_kernels, pdegpu_stats* stats) {
     if (!s || iters < 0) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;
+    if (s->variant) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "pdegpu_session_iterate runs the classic form: set_cg_variant(0) and begin again");
     PG_HIP(ctx, hipSetDevice(ctx->device));
     if (!time_kernels && iters > 0 && use_persist2d(s)) {
         int done = 0;
@@ -1016,9 +1121,16 @@ extern "C" int pdegpu_session_rr(pdegpu_session* s, double* rr_out) {
     if (!s || !rr_out) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;
     PG_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->variant && s->sr_k2_pending && s->rr_slot != SC_RR_POLL) {
+        // single-reduction form: the r.r of the last k2 still sits in its partials
+        const int64_t nslow = s->grid.dim == 3 ? (int64_t)s->grid.n[2] + 1 : 1;
+        if (s->g.k0 != 0 || s->g.nkl != nslow)
+            return pdegpu_set_err(ctx, PDEGPU_EINVAL, "rr after k2 (single-reduction form, slab with neighbours): call pdegpu_session_sr_poll and all-reduce scalars[6] first");
+        PG_TRY(pdegpu_session_sr_poll(s));
+    }
     PG_HIP(ctx, hipMemcpyAsync(s->h_pin, s->d_scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *rr_out = s->h_pin[SC_RR];
+    *rr_out = s->h_pin[s->variant ? s->rr_slot : SC_RR];
     return PDEGPU_OK;
 }
 

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
     if (MODE == APPLY_CG_K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
     if (MODE == APPLY_CG_K2) res_scale = cg_alpha_in(a.di, a.scal, sRed);      // r -= alpha A p on the boundary nodes of a hybrid session
 
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;                              // acc2 (K1): (A p).(A p) of the single-reduction form
     for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += (long long)gridDim.x * 256) {
         long long idx = e0;
         int i, j, lk;
@@ -176,10 +176,15 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
         } else {
             if (a.out) a.out[idx] = s;                        // (64-B variant: q is not stored, K2 applies the operator again)
             acc += pn * s;
+            acc2 += s * s;
         }
     }
     const double tot = block_sum_256(acc, sRed);
     dot_finish(tot, a.partials);
+    if (MODE == APPLY_CG_K1 && a.partials2) {                 // kernel-uniform
+        __syncthreads();
+        dot_finish(block_sum_256(acc2, sRed), a.partials2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -191,6 +196,8 @@ struct FastGeom {
     int nxg, nyg, nzc;     // workgroup counts along x, y; z-chunks (linear: nxg = workgroups per z-chunk, nyg = 1)
     int linear;            // 1: the waves of a z-chunk are numbered row by row (w = yt * ntx + xt) and a workgroup takes four consecutive ones
     int lkb, lke;          // local interior plane range [lkb, lke)
+    int lkb2, lke2;        // a second, disjoint plane range of the same launch: z-chunks nzc1 .. nzc-1 (the two edge planes of a slab)
+    int nzc1;              // z-chunks of the first range
     int zlen;              // planes per z-chunk
     int jbase, jmax;       // first / last free row of the middle axis (1 .. NY-2; 0 .. 0 for the flat 2-D view)
 };
@@ -263,13 +270,14 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     }
     const int i0 = xt * 128 + 2 * lane;
     const int j0 = fg.jbase + yt * RY;
-    const int lk0 = fg.lkb + zc * fg.zlen;
-    const int lk1 = min(lk0 + fg.zlen, fg.lke);
+    const bool range2 = zc >= fg.nzc1;
+    const int lk0 = range2 ? fg.lkb2 + (zc - fg.nzc1) * fg.zlen : fg.lkb + zc * fg.zlen;
+    const int lk1 = min(lk0 + fg.zlen, range2 ? fg.lke2 : fg.lke);
     const bool active = (xt < fg.ntx) && (yt < fg.nty) && (lk0 < lk1);
     const int wave_x = fg.linear ? wv : wv % fg.wxt;         // position of this wave among the workgroup's x-adjacent tiles
     int estep = 0;                                            // LDS edge-exchange counter (same in every wave of the workgroup)
 
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;                              // acc2 (K1): (A p).(A p) of the single-reduction form
     // CG scalars: every thread of every workgroup takes part (the prologue sum of the previous launch's partials has barriers)
     double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
     if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 }
             }
         };
-        if (K1 && lk0 == fg.lkb && lk0 == 0 && g.k0 > 0) ghost_store(-1, P);
+        if (K1 && lk0 == 0 && g.k0 > 0) ghost_store(-1, P);              // (the chunk that starts the slab)
 
         for (int lk = lk0; lk < lk1; ++lk) {
             // ---- issue the loads of plane lk+1 (PF: of plane lk+2; lk1 + 1 would leave the allocation and is never used) ----
@@ -585,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                         o.x = ma ? qa : 0.0;
                         o.y = mb ? qb : 0.0;
                         acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
+                        if (K1) acc2 += o.x * o.x + o.y * o.y;
                     }
                     if (lane_ok && (!K1 || a.out)) store_pair<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
                 }
@@ -609,10 +618,14 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             }
         }
         // after the last rotation C holds plane lk1: the upper ghost plane when this is the slab's last chunk
-        if (K1 && lk1 == fg.lke && lk1 == g.nkl && g.k0 + g.nkl < g.NZ) ghost_store(lk1, C);
+        if (K1 && lk1 == g.nkl && g.k0 + g.nkl < g.NZ) ghost_store(lk1, C);
     }
     const double tot = block_sum_256(acc, sRed);
     dot_finish(tot, a.partials);
+    if (K1 && a.partials2) {                                  // kernel-uniform
+        __syncthreads();
+        dot_finish(block_sum_256(acc2, sRed), a.partials2);
+    }
 }
 
 
@@ -673,7 +686,7 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
             }
         }
     }
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
 #pragma unroll
     for (int r = 1; r <= RY; ++r) {
         const int j = j0 - 1 + r;
@@ -700,6 +713,7 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
                 }
                 const double2 o = make_double2(ma ? qa : 0.0, mb ? qb : 0.0);
                 acc += C[r].x * o.x + C[r].y * o.y;
+                acc2 += o.x * o.x + o.y * o.y;
                 if (lane_ok && a.out) *reinterpret_cast<double2*>(a.out + off) = o;
             } else {
                 const double2 rv = *reinterpret_cast<const double2*>(a.rhs + (lane_ok ? off : 0));
@@ -711,6 +725,10 @@ __global__ __launch_bounds__(256) void k_plane2d(StencilArgs a, int ntx, int nty
     }
     const double tot = block_sum_256(acc, sRed);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    if (K1 && a.partials2) {
+        __syncthreads();
+        dot_finish(block_sum_256(acc2, sRed), a.partials2);
+    }
 }
 
 
@@ -812,7 +830,7 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
             }
         }
     }
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
 #pragma unroll
     for (int c = 1; c <= RY; ++c) {
         const int j = j0 - 1 + c;
@@ -864,6 +882,7 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
                 }
                 const double2 o = make_double2(ma ? qa : 0.0, mb ? qb : 0.0);
                 acc += C[c].x * o.x + C[c].y * o.y;
+                acc2 += o.x * o.x + o.y * o.y;
                 if (lane_ok && a.out) put(a.out + off, o);
             } else if (PL) {
                 const double2 o = make_double2(ma ? qa : 0.0, mb ? qb : 0.0);
@@ -879,9 +898,14 @@ __global__ __launch_bounds__(256) void k_tile3d(StencilArgs a, int ntx, int nty)
     }
     const double tot = block_sum_256(acc, sRed);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    if (K1 && a.partials2) {
+        __syncthreads();
+        dot_finish(block_sum_256(acc2, sRed), a.partials2);
+    }
 }
 
-FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int mode, int lk_lo = 0, int lk_hi = 0, int slack8 = 0, int resident_cap = 0) {
+FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int mode, int lk_lo = 0, int lk_hi = 0, int slack8 = 0, int resident_cap = 0,
+                   int lk_lo2 = 0, int lk_hi2 = 0) {
     FastGeom fg{};
     fg.ntx = (g.NX - 1 + 127) / 128;
     fg.jbase = g.flat2d ? 0 : 1;
@@ -904,6 +928,12 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     }
     fg.lkb = g.k0 >= 1 ? 0 : 1 - g.k0;
     fg.lke = (g.NZ - 1 - g.k0) < g.nkl ? (g.NZ - 1 - g.k0) : g.nkl;
+    fg.lkb2 = fg.lke2 = 0;
+    if (lk_hi2 > lk_lo2) {                     // second plane range of the same launch, clipped to the free planes like the first
+        fg.lkb2 = std::max(fg.lkb, lk_lo2);
+        fg.lke2 = std::min(fg.lke, lk_hi2);
+        if (fg.lke2 < fg.lkb2) fg.lke2 = fg.lkb2;
+    }
     if (lk_hi > lk_lo) {                       // plane-range launch (K1 split of the multi-GPU loop)
         if (lk_lo > fg.lkb) fg.lkb = lk_lo;
         if (lk_hi < fg.lke) fg.lke = lk_hi;
@@ -990,6 +1020,11 @@ FastGeom fast_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_c
     }
     fg.zlen = planes > 0 ? (planes + nzc - 1) / nzc : 1;
     fg.nzc = planes > 0 ? (planes + fg.zlen - 1) / fg.zlen : 0;
+    fg.nzc1 = fg.nzc;
+    if (fg.lke2 > fg.lkb2) {                   // the second range is cut with the first one's chunk length (edge planes: one plane each)
+        if (planes <= 0) fg.zlen = fg.lke2 - fg.lkb2;
+        fg.nzc += (fg.lke2 - fg.lkb2 + fg.zlen - 1) / fg.zlen;
+    }
     return fg;
 }
 
@@ -1038,7 +1073,7 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     int slack8 = 0;
     if (mc.wg >= 1 && mc.wg <= 16) wg_per_cu = mc.wg;
     else if (hbm) { wg_per_cu = 2; slack8 = 1; }
-    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, mode, a.lk_lo, a.lk_hi, slack8, res_occ * ctx->num_cu);
+    FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, mode, a.lk_lo, a.lk_hi, slack8, res_occ * ctx->num_cu, a.lk_lo2, a.lk_hi2);
     // a multiple of 8 workgroups, so that the XCD-aware tile order of the kernel always applies (the surplus ones find zc >= nzc and idle;
     // 701 nodes per row: 525 workgroups -> 528)
     const int G = (fg.nxg * fg.nyg * fg.nzc + 7) / 8 * 8;
@@ -1053,7 +1088,7 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
                     mode, NPT, RY, EX, PF, a.g.NX, a.g.NY, a.g.nkl, fg.nxg, fg.nyg, fg.wxt, fg.wyt, fg.nzc, fg.zlen, occ[mode], G);
         }
     }
-    if (G == 0) return PDEGPU_OK;
+    if (G == 0 || (li && li->dry)) return PDEGPU_OK;
     switch (mode) {
         case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
         case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;

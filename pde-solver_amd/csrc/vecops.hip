@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void k_norm2(const double2* __restrict__ a, lo
 
 // x += alpha_prev p   (the update K1 would apply at the start of the next iteration)
 __global__ __launch_bounds__(256) void k_flush(double2* __restrict__ x, const double2* __restrict__ p, long long n2,
-                                                const double* __restrict__ scal) {
-    const double pq = scal[SC_PQ], rr_prev = scal[SC_RR_PREV];
+                                                const double* __restrict__ scal, int sr) {
+    const double pq = scal[SC_PQ], rr_prev = scal[sr ? SC_RR : SC_RR_PREV];       // (single-reduction form: the block holds r_n.r_n, p_n.Ap_n)
     const double alpha = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
     if (alpha == 0.0) return;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long long)gridDim.x * 256) {
@@ -156,6 +156,35 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ parti
             if (copy_to_global) scal[SC_RR] = tot;
         }
     }
+}
+
+// single-reduction form: three fixed-order sums in one launch (K1's p.Ap and Ap.Ap partials, K2's r.r partials of the iteration before)
+__global__ __launch_bounds__(256) void k_reduce_sr(const double* __restrict__ pq_part, const double* __restrict__ qq_part, int n1,
+                                                    const double* __restrict__ rr_part, int n3, double* __restrict__ scal) {
+    __shared__ double sRed[4];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int e = threadIdx.x; e < n1; e += 256) {
+        a += pq_part[e];
+        b += qq_part[e];
+    }
+    for (int e = threadIdx.x; e < n3; e += 256) c += rr_part[e];
+    const double ta = block_sum_256(a, sRed);
+    __syncthreads();
+    const double tb = block_sum_256(b, sRed);
+    __syncthreads();
+    const double tc = block_sum_256(c, sRed);
+    if (threadIdx.x == 0) {
+        scal[SC_PQ] = ta;
+        scal[SC_QQ] = tb;
+        scal[SC_RR] = n3 >= 0 ? tc : scal[SC_RR_LOCAL];      // first iteration: THIS slab's r_0.r_0 of the residual pass (the message is summed over ranks)
+    }
+}
+__global__ __launch_bounds__(256) void k_reduce_slot(const double* __restrict__ partials, int n, double* __restrict__ scal, int slot) {
+    __shared__ double sRed[4];
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += 256) acc += partials[e];
+    const double tot = block_sum_256(acc, sRed);
+    if (threadIdx.x == 0) scal[slot] = tot;
 }
 
 __global__ __launch_bounds__(256) void k_pack(GridDev g, const double* __restrict__ v, double* __restrict__ dense, int to_dense) {
@@ -232,10 +261,10 @@ int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partia
     return PDEGPU_OK;
 }
 
-int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal) {
+int vec_axpy_flush(pdegpu_ctx* ctx, const GridDev& g, double* x, const double* p, const double* scal, int sr) {
     const long long n2 = (long long)g.nkl * g.PP / 2;
     hipLaunchKernelGGL(k_flush, dim3(flat_grid(ctx, n2)), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(x),
-                       reinterpret_cast<const double2*>(p), n2, scal);
+                       reinterpret_cast<const double2*>(p), n2, scal, sr);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }
@@ -250,6 +279,17 @@ int vec_extrapolate(pdegpu_ctx* ctx, const GridDev& g, double* x, double* xprev,
 
 int vec_reduce(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int which, int copy_to_global) {
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, ctx->stream, partials, n, scal, which, copy_to_global);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+int vec_reduce_sr(pdegpu_ctx* ctx, const double* pq_part, const double* qq_part, int n1, const double* rr_part, int n3, double* scal) {
+    hipLaunchKernelGGL(k_reduce_sr, dim3(1), dim3(256), 0, ctx->stream, pq_part, qq_part, n1, rr_part, n3, scal);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+int vec_reduce_slot(pdegpu_ctx* ctx, const double* partials, int n, double* scal, int slot) {
+    hipLaunchKernelGGL(k_reduce_slot, dim3(1), dim3(256), 0, ctx->stream, partials, n, scal, slot);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

@@ -102,8 +102,8 @@ SYMBOLS = {
     "pdegpu_el_session_plane_doubles": (C.c_int64, [_vp]),
     "pdegpu_el_session_plane_ptr": (_vp, [_vp, C.c_int, C.c_int, C.c_int64]),
     "pdegpu_el_session_get_u": (C.c_int, [_vp, _dp]),
-    "pdegpu_el_session_halo_buffer": (_vp, [_vp, C.c_int, C.c_int]),
-    "pdegpu_el_session_halo_pack": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_el_session_can_split_k1": (C.c_int, [_vp]),
+    "pdegpu_el_session_k1_part": (C.c_int, [_vp, C.c_int]),
     "pdegpu_elasticity_postprocess": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp]),
     "pdegpu_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "pdegpu_session_destroy": (None, [_vp]),
@@ -117,6 +117,9 @@ SYMBOLS = {
     "pdegpu_session_k2": (C.c_int, [_vp]),
     "pdegpu_session_can_split_k1": (C.c_int, [_vp]),
     "pdegpu_session_k1_part": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_session_set_cg_variant": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_session_cg_variant": (C.c_int, [_vp]),
+    "pdegpu_session_sr_poll": (C.c_int, [_vp]),
     "pdegpu_session_set_timing": (C.c_int, [_vp, C.c_int]),
     "pdegpu_session_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "pdegpu_session_step_rhs": (C.c_int, [_vp]),

@@ -6,13 +6,16 @@ RCCL over xGMI) for the only two exchanges the path has —
     in the pitched layout ((nx+1 padded) x (ny+1) fp64 = 2.2 MB at 513^2), so there is no pack kernel; the
     four point-to-point transfers of one exchange are issued as one batch (one ncclGroup) and use the two
     xGMI links to the slab neighbours;
-  * dot products: one 8-byte all-reduce after K1 (p.q) and one after K2 (r.r).  They are latency-bound, the
-    result stays on the device, alpha / beta are formed inside the kernels: the host never synchronises in
-    the loop;
+  * dot products: ONE all-reduce per iteration (single-reduction form, the default where the engine offers it): after K1 the
+    24-byte block {p.Ap, r.r, Ap.Ap} — K1 also sums Ap.Ap, the r.r of K2's residual waits in its partials and joins the next
+    message, beta comes from the predicted |r_{n+1}|^2 = alpha^2 Ap.Ap - r.r (the same iterates in exact arithmetic).  The classic
+    form (variant="classic": 8 bytes after K1, 8 bytes after K2) stays selectable.  The messages are latency-bound, the result
+    stays on the device, alpha / beta are formed inside the kernels: the host never synchronises in the loop;
   * overlap: the exchange is posted first, K1 then runs on the owned planes whose stencil touches no ghost plane
     (engine.k1_part(0)) while the planes travel (RCCL works on its own stream), and the one or two planes next to the
-    ghosts follow once the transfer has completed (engine.k1_part(1)).  Elasticity sends ONE packed message per
-    neighbour (r and p, 3 components each).
+    ghosts follow once the transfer has completed (engine.k1_part(1)).  Elasticity works the same way: only r travels (three
+    contiguous component planes per neighbour in the one batch), the p-update of the owned planes and the block apply away from
+    the ghosts run meanwhile, the ghost planes' p-update and the edge planes follow.
 
 The compute engine is abstract so that the same driver runs (a) the HIP session through the C-ABI on GPUs and
 (b) under the `gloo` backend on CPU tensors in the test-suite (tests/ supply a numpy engine built on the
@@ -30,6 +33,7 @@ from . import _lib as L
 
 VEC_X, VEC_R, VEC_P, VEC_Q = 0, 1, 2, 3
 SC_PQ_LOCAL, SC_RR_LOCAL, SC_PQ, SC_RR, SC_RR_PREV = 0, 1, 2, 3, 4
+SC_QQ, SC_RR_POLL = 4, 6          # single-reduction form: the message is scalars[2:5] = {p.Ap, r.r, Ap.Ap}; polls read scalars[6]
 
 
 class _DevArray:
@@ -51,6 +55,7 @@ def slab_range(n_planes: int, world: int, rank: int):
 
 class GpuSlabEngine:
     """pdegpu_session on one GPU; device memory stays owned by the library, torch only sees plane views."""
+    supports_sr = True
 
     def __init__(self, grid, heat, k0: int, nk: int, device: int, stream: Optional[torch.cuda.Stream] = None):
         self.lib = L.load_library()
@@ -82,6 +87,14 @@ class GpuSlabEngine:
 
     def begin(self, x_fill: float):
         self._ck(self.lib.pdegpu_session_begin(self.s, x_fill))
+
+    def set_variant(self, sr: bool):
+        """single-reduction recurrences (one 24-byte message per iteration) or the classic ones; before begin()"""
+        self._ck(self.lib.pdegpu_session_set_cg_variant(self.s, 1 if sr else 0))
+        self.sr = bool(sr)
+
+    def sr_poll(self):
+        self._ck(self.lib.pdegpu_session_sr_poll(self.s))
 
     def residual(self):
         self._ck(self.lib.pdegpu_session_residual(self.s))
@@ -115,8 +128,9 @@ class GpuSlabEngine:
     def x_halo_tensors(self, which: int):
         return [self.plane_tensor(VEC_X, which)]
 
-    def set_timing(self, on: bool):
-        self._ck(self.lib.pdegpu_session_set_timing(self.s, 1 if on else 0))
+    def set_timing(self, on):
+        """True / 1: HIP-event pairs around every K1 / K2 launch; k > 1: around those of every k-th iteration; False / 0: off"""
+        self._ck(self.lib.pdegpu_session_set_timing(self.s, int(on)))
 
     def get_stats(self, stats):
         self._ck(self.lib.pdegpu_session_get_stats(self.s, stats))
@@ -153,6 +167,8 @@ class GpuSlabEngine:
         return [self.plane_tensor(v, which) for v in vecs]
 
     def global_slots(self, which: int):
+        if which == 0 and getattr(self, "sr", False):
+            return (SC_PQ, SC_QQ + 1)                    # {p.Ap, r.r, Ap.Ap}: one message
         return (SC_PQ, SC_PQ + 1) if which == 0 else (SC_RR, SC_RR + 1)
 
     def iterate_native(self, iters: int, time_kernels: bool, stats=None):
@@ -226,25 +242,16 @@ class GpuElasticitySlabEngine:
         return t
 
     def halo_tensors(self, which: int):
-        return [self.plane_tensor(v, c, which) for v in (1, 2) for c in range(3)]       # r and p, 3 components each (z = D^-1 r is formed by the p-update)
+        # r only (3 component planes, each contiguous: no pack kernel): z = D^-1 r is formed by the p-update, and p on the ghost planes is
+        # maintained by k1 itself from the slab's own p_{n-1} there (same formula, same global scalars as the neighbour rank)
+        return [self.plane_tensor(1, c, which) for c in range(3)]
 
-    # one contiguous message per neighbour (the driver prefers this protocol when an engine offers it)
-    def halo_pack(self):
-        self._ck(self.lib.pdegpu_el_session_halo_pack(self.s, 0))
+    def k1_part(self, part: int):
+        """part 0: everything that reads no ghost plane (halo exchange in flight); part 1: ghost p-update, edge planes, the p.q sum"""
+        self._ck(self.lib.pdegpu_el_session_k1_part(self.s, part))
 
-    def halo_unpack(self):
-        self._ck(self.lib.pdegpu_el_session_halo_pack(self.s, 1))
-
-    def halo_buffer(self, which: int, side: int) -> torch.Tensor:
-        """which 0 send / 1 receive; side 0 lower / 1 upper neighbour: [r0 r1 r2 p0 p1 p2] x plane, contiguous"""
-        key = ("buf", which, side)
-        t = self._planes.get(key)
-        if t is None:
-            ptr = self.lib.pdegpu_el_session_halo_buffer(self.s, which, side)
-            if not ptr:
-                raise L.PdeGpuError(L.EHIP, "halo buffers could not be allocated")
-            t = self._planes[key] = torch.as_tensor(_DevArray(ptr, 6 * self.plane), device=f"cuda:{self.device}")
-        return t
+    def can_split_k1(self) -> bool:
+        return bool(self.lib.pdegpu_el_session_can_split_k1(self.s))
 
     def global_slots(self, which: int):
         return (0, 1) if which == 0 else (1, 3)          # p.q | r.z and r.r as one 16-byte message
@@ -268,11 +275,21 @@ class GpuElasticitySlabEngine:
 class SlabCG:
     """CG over a 1-D slab decomposition.  `engine` owns planes [k0, k0+nk) plus one ghost plane per side."""
 
-    def __init__(self, engine, rank: int, world: int, group=None, overlap: bool = True):
+    def __init__(self, engine, rank: int, world: int, group=None, overlap: bool = True, variant: str = "auto"):
+        """variant: "sr" = single-reduction recurrences (ONE scalar message per iteration), "classic" = two; "auto" = "sr" where the
+        engine offers it (the heat engines; the elasticity PCG keeps the classic form)"""
         self.e, self.rank, self.world, self.group = engine, rank, world, group
         self.force_collectives = False      # measurement aid: run the scalar all-reduces through the process group at world == 1 too
         self.overlap = overlap
         self.iterations = 0
+        if variant not in ("auto", "sr", "classic"):
+            raise ValueError(f"variant must be auto, sr or classic, got {variant!r}")
+        can = bool(getattr(engine, "supports_sr", False))
+        if variant == "sr" and not can:
+            raise L.PdeGpuError(L.EUNSUPPORTED, "this engine has no single-reduction form")
+        self.sr = can and variant != "classic"
+        if can:
+            engine.set_variant(self.sr)
 
     # ---- the two exchanges -------------------------------------------------------------------------
     def _halo(self, which: int):
@@ -307,10 +324,6 @@ class SlabCG:
         if self.world == 1:
             return None
         e, nk = self.e, self.e.nk
-        if halo is None and hasattr(e, "halo_pack"):          # packed protocol: one contiguous message per neighbour
-            e.halo_pack()
-            works = self._post([(e.halo_buffer(0, 0), e.halo_buffer(1, 0))], [(e.halo_buffer(0, 1), e.halo_buffer(1, 1))])
-            return ("packed", works)
         halo = halo or self._halo
         works = self._post(list(zip(halo(0), halo(-1))), list(zip(halo(nk - 1), halo(nk))))
         return ("planes", works)
@@ -321,8 +334,6 @@ class SlabCG:
         kind, works = token
         for w in works:
             w.wait()          # stream-ordered for NCCL (the compute stream waits, the host does not); completes the copy for gloo
-        if kind == "packed":
-            self.e.halo_unpack()
 
     def exchange_halos(self, halo=None):
         self.exchange_end(self.exchange_begin(halo))
@@ -345,11 +356,15 @@ class SlabCG:
         for dev, buf in recvs:
             dev.copy_(buf)
 
-    def allreduce(self, which: int):
-        """local partial -> global scalar(s) (sum over ranks), in place; which: 0 after k1, 1 after k2"""
-        self.e.local_to_global(which)
+    def allreduce(self, which: int, slots=None):
+        """local partial -> global scalar(s) (sum over ranks), in place; which: 0 after k1, 1 after k2 (classic form) / after a
+        residual pass; slots = (a, b): that range of the scalar block instead"""
+        if slots is None:
+            self.e.local_to_global(which)
         if self.world > 1 or self.force_collectives:
-            if hasattr(self.e, "global_slots"):
+            if slots is not None:
+                a, b = slots
+            elif hasattr(self.e, "global_slots"):
                 a, b = self.e.global_slots(which)
             else:
                 a = SC_PQ if which == 0 else SC_RR
@@ -384,10 +399,19 @@ class SlabCG:
             else:
                 self.exchange_halos()
                 self.e.k1()
-            self.allreduce(0)
+            self.allreduce(0)                 # sr: {p.Ap, r.r, Ap.Ap} in one message; classic: p.Ap
             self.e.k2()
-            self.allreduce(1)
+            if not self.sr:
+                self.allreduce(1)
         self.iterations += iters
+
+    def rr(self) -> float:
+        """global r.r of the current residual (host value: synchronises).  Single-reduction form: the r.r of the last K2 is summed and
+        all-reduced here, for the poll only."""
+        if self.sr:
+            self.e.sr_poll()
+            self.allreduce(1, slots=(SC_RR_POLL, SC_RR_POLL + 1))
+        return self.e.rr()
 
     # ---- one backward-Euler step on slabs (fenics_mcp_server.py:702-716) ---------------------------
     def begin_step(self) -> float:
@@ -407,12 +431,12 @@ class SlabCG:
     def solve(self, bnorm2: float, rtol: float, max_iter: int = 100000, first_chunk: int = 8):
         """iterate until r.r <= rtol^2 bnorm2 (host polls once per chunk); returns (iterations, relative residual)"""
         target = rtol * rtol * bnorm2
-        rr, it, chunk = self.e.rr(), 0, first_chunk
+        rr, it, chunk = self.rr(), 0, first_chunk
         while rr > target and it < max_iter:
             n = min(chunk, max_iter - it)
             self.iterate(n)
             it += n
-            rr = self.e.rr()
+            rr = self.rr()
             chunk = min(2 * chunk, 64)
         self.finish()
         return it, (rr / bnorm2) ** 0.5 if bnorm2 > 0 else rr ** 0.5

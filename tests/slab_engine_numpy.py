@@ -8,9 +8,45 @@ import torch
 from oracle import cg_port
 
 SC_PQ_LOCAL, SC_RR_LOCAL, SC_PQ, SC_RR, SC_RR_PREV = 0, 1, 2, 3, 4
+SC_QQ, SC_RR_POLL = 4, 6          # single-reduction form (pdegpu_session_set_cg_variant 1): message = scal[2:5], polls read scal[6]
 
 
 class NumpySlabEngine:
+    supports_sr = True
+    sr = False
+
+    def set_variant(self, sr):
+        self.sr = bool(sr)
+        self._k2_rr, self._skip_x, self._rr_slot = None, False, SC_RR
+
+    def _k1_scalars(self):
+        """(alpha_{n-1}, beta_n) as the HIP kernels form them (csrc/dot_finish.h: cg_scalars_in)"""
+        if self.sr:
+            pq, rr, qq = (float(self.scal[i]) for i in (SC_PQ, SC_RR, SC_QQ))
+            a = rr / pq if (pq > 0 and rr > 0) else 0.0
+            rr_next = a * a * qq - rr
+            return (0.0 if self._skip_x else a), (rr_next / rr if (a > 0 and rr_next > 0) else 0.0)
+        pq, rr, rr_prev = (float(self.scal[i]) for i in (SC_PQ, SC_RR, SC_RR_PREV))
+        return (rr_prev / pq if (pq > 0 and rr_prev > 0) else 0.0), (rr / rr_prev if rr_prev > 0 else 0.0)
+
+    def _k1_done(self, pq, qq):
+        """K1's dot products: classic -> the local p.Ap slot; single-reduction -> the block {p.Ap, r.r of the last K2, Ap.Ap} (this slab's sums)"""
+        if not self.sr:
+            self.scal[SC_PQ_LOCAL] = pq
+            return
+        self.scal[SC_PQ], self.scal[SC_QQ] = pq, qq
+        # r.r of the residual this K1 started from, THIS slab's share (the message is summed over ranks): K2's, or on the first
+        # iteration the residual pass's
+        self.scal[SC_RR] = self._k2_rr if self._k2_rr is not None else self.scal[SC_RR_LOCAL]
+        self._k2_rr, self._skip_x, self._rr_slot = None, False, SC_RR
+
+    def sr_poll(self):
+        if self._k2_rr is None:
+            self._rr_slot = SC_RR
+        else:
+            self.scal[SC_RR_POLL] = self._k2_rr
+            self._rr_slot = SC_RR_POLL
+
     def __init__(self, n, Ls, kappa, source, T_boundary, k0, nk, dt=None):
         """dt = None: steady system kappa K u = f m;  dt > 0: one backward-Euler step matrix M + dt kappa K (15-point)"""
         self.n, self.k0, self.nk = n, k0, nk
@@ -33,6 +69,7 @@ class NumpySlabEngine:
         self.inside = (kg >= 0) & (kg <= self.NZ - 1)            # planes that exist in the global grid
         self.free = free
         self.own = slice(1, nk + 1)
+        self._k2_rr, self._skip_x, self._rr_slot = None, False, SC_RR
 
     # --- helpers ---
     def _apply(self, v, w=None):
@@ -57,6 +94,7 @@ class NumpySlabEngine:
     # --- engine interface used by SlabCG ---
     def begin(self, x_fill):
         self.scal.zero_()
+        self._k2_rr, self._skip_x, self._rr_slot = None, False, SC_RR
         for t in self.p:
             t.zero_()
         self.pcur = 0
@@ -72,11 +110,10 @@ class NumpySlabEngine:
         r[~self.free[self.own]] = 0.0
         self.r.numpy()[self.own] = r
         self._reduce_rr(float((r * r).sum()))
+        self._k2_rr, self._rr_slot = None, SC_RR
 
     def k1(self):
-        pq, rr, rr_prev = (float(self.scal[i]) for i in (SC_PQ, SC_RR, SC_RR_PREV))
-        alpha_prev = rr_prev / pq if (pq > 0 and rr_prev > 0) else 0.0
-        beta = rr / rr_prev if rr_prev > 0 else 0.0
+        alpha_prev, beta = self._k1_scalars()
         p_old = self.p[self.pcur].numpy()
         if alpha_prev != 0.0:
             self.x.numpy()[self.own] += alpha_prev * p_old[self.own]
@@ -85,16 +122,14 @@ class NumpySlabEngine:
         self.p[1 - self.pcur].numpy()[self.own] = pn[self.own]
         self.q.numpy()[self.own] = q
         self.pcur ^= 1
-        self.scal[SC_PQ_LOCAL] = float((pn[self.own] * q).sum())
+        self._k1_done(float((pn[self.own] * q).sum()), float((q * q).sum()))
 
     def k1_part(self, part):
         """the split K1 of the HIP session: part 0 may only touch planes whose stencil reads no ghost plane — checked here by
         running it on copies of r and p whose ghost planes are NaN (the receives may land in the real ones meanwhile)"""
         if part == 0:
-            self._pq_parts = 0.0
-            pq, rr, rr_prev = (float(self.scal[i]) for i in (SC_PQ, SC_RR, SC_RR_PREV))
-            self._alpha_prev = rr_prev / pq if (pq > 0 and rr_prev > 0) else 0.0
-            self._beta = rr / rr_prev if rr_prev > 0 else 0.0
+            self._pq_parts = self._qq_parts = 0.0
+            self._alpha_prev, self._beta = self._k1_scalars()
             lo = 1 if self.k0 > 0 else 0
             hi = 1 if self.k0 + self.nk < self.NZ else 0
             r, p_old = self.r.numpy().copy(), self.p[self.pcur].numpy().copy()
@@ -108,7 +143,7 @@ class NumpySlabEngine:
         for lk in self._edges:
             self._k1_planes(lk, lk + 1, self.r.numpy(), self.p[self.pcur].numpy())
         self.pcur ^= 1
-        self.scal[SC_PQ_LOCAL] = self._pq_parts
+        self._k1_done(self._pq_parts, self._qq_parts)
 
     def _k1_planes(self, a, b, r, p_old):
         """K1 on the local planes [a, b)"""
@@ -127,6 +162,7 @@ class NumpySlabEngine:
         self.p[1 - self.pcur].numpy()[own] = pn[1:-1]
         self.q.numpy()[own] = q
         self._pq_parts += float((pn[1:-1] * q).sum())
+        self._qq_parts += float((q * q).sum())
 
     # transient steps (pdegpu_session_step_rhs / lift_norm / reset_cg)
     def step_rhs(self):
@@ -149,15 +185,20 @@ class NumpySlabEngine:
         r = self.b.numpy()[self.own] - self._apply(g)
         r[~self.free[self.own]] = 0.0
         self._reduce_rr(float((r * r).sum()))
+        self._k2_rr, self._rr_slot = None, SC_RR
 
     def reset_cg(self):
         self.scal.zero_()
         self.pcur = 0
+        self._k2_rr, self._skip_x, self._rr_slot = None, False, SC_RR
 
     def x_halo_tensors(self, which):
         return [self.plane_tensor(0, which)]
 
     def rr(self):
+        if self.sr:
+            assert self._k2_rr is None or self._rr_slot == SC_RR_POLL, "rr after k2 in the single-reduction form: sr_poll + all-reduce first"
+            return float(self.scal[self._rr_slot])
         return float(self.scal[SC_RR])
 
     def k2(self):
@@ -165,17 +206,24 @@ class NumpySlabEngine:
         alpha = rr / pq if pq > 0 else 0.0
         r = self.r.numpy()
         r[self.own] -= alpha * self.q.numpy()[self.own]
-        self._reduce_rr(float((r[self.own] ** 2).sum()))
+        if self.sr:
+            self._k2_rr = float((r[self.own] ** 2).sum())       # stays local until the next K1's message (or a poll)
+        else:
+            self._reduce_rr(float((r[self.own] ** 2).sum()))
 
     def flush(self):
-        pq, rr_prev = float(self.scal[SC_PQ]), float(self.scal[SC_RR_PREV])
+        pq, rr_prev = float(self.scal[SC_PQ]), float(self.scal[SC_RR if self.sr else SC_RR_PREV])
         alpha = rr_prev / pq if (pq > 0 and rr_prev > 0) else 0.0
         self.x.numpy()[self.own] += alpha * self.p[self.pcur].numpy()[self.own]
-        self.scal[SC_PQ] = 0.0
+        if self.sr:
+            self._skip_x = True
+        else:
+            self.scal[SC_PQ] = 0.0
 
     def local_to_global(self, which):
         if which == 0:
-            self.scal[SC_PQ] = self.scal[SC_PQ_LOCAL]
+            if not self.sr:                                       # (single-reduction form: K1 wrote its sums into the message block itself)
+                self.scal[SC_PQ] = self.scal[SC_PQ_LOCAL]
         else:
             self.scal[SC_RR] = self.scal[SC_RR_LOCAL]
 
@@ -191,6 +239,8 @@ class NumpySlabEngine:
         return [self.plane_tensor(1, which), self.plane_tensor(2, which)]
 
     def global_slots(self, which):
+        if which == 0 and self.sr:
+            return (SC_PQ, SC_QQ + 1)
         return (SC_PQ, SC_PQ + 1) if which == 0 else (SC_RR, SC_RR + 1)
 
     def owned_x(self):

@@ -47,7 +47,7 @@ def _worker_transient(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, variant="sr"):
     for p in (ROOT, ROOT / "pde-solver_amd", ROOT / "tests"):
         if str(p) not in sys.path:
             sys.path.insert(0, str(p))
@@ -59,23 +59,24 @@ def _worker(rank, world, port, outdir):
         from slab_engine_numpy import NumpySlabEngine
         k0, nk = slab_range(N_CELLS[2] + 1, world, rank)
         eng = NumpySlabEngine(N_CELLS, LS, KAPPA, SRC, TB, k0, nk)
-        cg = SlabCG(eng, rank, world)
+        cg = SlabCG(eng, rank, world, variant=variant)
+        assert cg.sr == (variant == "sr")
         cg.start(0.0)
-        rr0 = float(eng.scalars()[3])
+        rr0 = cg.rr()
         cg.iterate(5)
-        rr5 = float(eng.scalars()[3])
+        rr5 = cg.rr()
         cg.iterate(ITERS - 5)
-        rr_end = float(eng.scalars()[3])
+        rr_end = cg.rr()
         cg.finish()
         np.savez(Path(outdir) / f"rank{rank}.npz", x=eng.owned_x(), k0=k0, nk=nk, rr=np.array([rr0, rr5, rr_end]))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, tmp_path):
-    out = tmp_path / f"w{world}"
+def _run(world, tmp_path, variant="sr"):
+    out = tmp_path / f"w{world}{variant}"
     out.mkdir()
-    mp.spawn(_worker, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(out), variant), nprocs=world, join=True)
     parts = [np.load(out / f"rank{r}.npz") for r in range(world)]
     assert sum(int(p["nk"]) for p in parts) == N_CELLS[2] + 1
     x = np.concatenate([p["x"] for p in parts], axis=0)
@@ -85,15 +86,20 @@ def _run(world, tmp_path):
 
 
 @pytest.mark.timeout(300)
-def test_slab_cg_world_1_2_3_agree_and_match_oracle(tmp_path):
+@pytest.mark.parametrize("variant", ["sr", "classic"])
+def test_slab_cg_world_1_2_3_agree_and_match_oracle(tmp_path, variant):
+    """both recurrences of the driver — single reduction (ONE 24-byte message per iteration, the default) and classic (two 8-byte ones)"""
     from oracle import fem_p1 as o
-    x1, rr1 = _run(1, tmp_path)
+    x1, rr1 = _run(1, tmp_path, variant)
     ref = o.solve_heat_3d(*LS, *N_CELLS, KAPPA, TB, 0.0, 0.1, 1, steady=True, source_type="constant", source_value=SRC)
     ref = ref.values[0].reshape(x1.shape)
     assert np.abs(x1 - ref).max() < 1e-9 * np.abs(ref).max()
     assert rr1[2] < 1e-20 * rr1[0]
+    if variant == "sr":                                           # the same iterates as the classic recurrences (exact arithmetic: identical)
+        xc, rrc = _run(1, tmp_path, "classic")
+        assert np.allclose(rr1[:2], rrc[:2], rtol=1e-10) and np.abs(x1 - xc).max() < 1e-11 * np.abs(ref).max()
     for world in (2, 3):
-        xw, rrw = _run(world, tmp_path)
+        xw, rrw = _run(world, tmp_path, variant)
         assert np.allclose(rrw[:2], rr1[:2], rtol=1e-11)           # same iterates up to summation order
         assert np.abs(xw - ref).max() < 1e-9 * np.abs(ref).max()
         assert np.abs(xw - x1).max() < 1e-11 * np.abs(ref).max()
@@ -130,12 +136,20 @@ def test_slab_engine_matches_c_port():
     from pdegpu.dist import SlabCG
     from slab_engine_numpy import NumpySlabEngine
     eng = NumpySlabEngine(N_CELLS, LS, KAPPA, SRC, TB, 0, N_CELLS[2] + 1)
-    cg = SlabCG(eng, 0, 1)
+    cg = SlabCG(eng, 0, 1, variant="classic")
     cg.start(0.0)
     hist = [float(eng.scalars()[3])]
     for _ in range(10):
         cg.iterate(1)
         hist.append(float(eng.scalars()[3]))
+    eng2 = NumpySlabEngine(N_CELLS, LS, KAPPA, SRC, TB, 0, N_CELLS[2] + 1)
+    cg2 = SlabCG(eng2, 0, 1, variant="sr")                       # single-reduction form: the same residual history
+    cg2.start(0.0)
+    hist2 = [cg2.rr()]
+    for _ in range(10):
+        cg2.iterate(1)
+        hist2.append(cg2.rr())
+    assert np.allclose(hist2, hist, rtol=1e-10)
     h = [LS[r] / N_CELLS[r] for r in range(3)]
     _, rr, _ = cg_port.run(tuple(n + 1 for n in N_CELLS), cg_port.p1_weights(h, 0.0, KAPPA), SRC * h[0] * h[1] * h[2], TB, 10)
     assert np.allclose(hist, rr, rtol=1e-10)

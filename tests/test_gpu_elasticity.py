@@ -141,15 +141,16 @@ def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
 
 
 @pytest.mark.parametrize("nslabs", [1, 2, 3])
-@pytest.mark.parametrize("packed", [False, True])
-def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, packed):
-    """the multi-GPU elasticity path on ONE GPU: slab sessions (ghost planes, global boundary classes), halo exchange of
-    z and p (3 components each) and the scalar all-reduces done by device copies in the order pdegpu.dist.SlabCG uses;
+@pytest.mark.parametrize("split", [False, True])
+def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split):
+    """the multi-GPU elasticity path on ONE GPU: slab sessions (ghost planes, global boundary classes), halo exchange of r (3 component
+    planes; p on the ghost planes is maintained by k1) and the scalar all-reduces done by device copies in the order pdegpu.dist.SlabCG
+    uses — split: k1 in two parts with the exchange in between (the overlapped order), the ghost planes of r poisoned while part 0 runs;
     then von Mises + project() from the gathered displacement.  Must reproduce the oracle."""
     import torch
     from pdegpu import _lib
     from pdegpu.dist import GpuElasticitySlabEngine, slab_range
-    n, Ls = (14, 4, 9), (1.0, 0.3, 0.6)
+    n, Ls = (14, 4, 13), (1.0, 0.3, 0.6)
     E, nu, body = 210e9, 0.3, (0.0, 2.0e4, -76518.0)
     grid = _lib.make_grid(3, n, Ls)
     el = _lib.Elasticity()
@@ -161,17 +162,6 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, packed):
         engs = [GpuElasticitySlabEngine(grid, el, *slab_range(n[2] + 1, nslabs, r), 0, stream) for r in range(nslabs)]
 
         def exchange():
-            if packed:
-                # ONE contiguous message per neighbour (the driver's protocol): pack, move the two buffers, unpack
-                for e in engs:
-                    e.halo_pack()
-                for r in range(nslabs - 1):
-                    lo, hi = engs[r], engs[r + 1]
-                    hi.halo_buffer(1, 0).copy_(lo.halo_buffer(0, 1))
-                    lo.halo_buffer(1, 1).copy_(hi.halo_buffer(0, 0))
-                for e in engs:
-                    e.halo_unpack()
-                return
             for r in range(nslabs - 1):
                 lo, hi = engs[r], engs[r + 1]
                 for a, b in zip(hi.halo_tensors(-1), lo.halo_tensors(lo.nk - 1)):
@@ -192,9 +182,20 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, packed):
         it = 0
         while it < 6000:
             for _ in range(50):
-                exchange()
-                for e in engs:
-                    e.k1()
+                if split:
+                    assert all(e.can_split_k1() == (nslabs > 1) for e in engs)
+                    for e in engs:                        # the receives have not landed yet: part 0 must not read a ghost plane of r
+                        for w in ((-1,) if e.k0 > 0 else ()) + ((e.nk,) if e.k0 + e.nk < n[2] + 1 else ()):
+                            for t in e.halo_tensors(w):
+                                t.fill_(float("nan"))
+                        e.k1_part(0)
+                    exchange()
+                    for e in engs:
+                        e.k1_part(1)
+                else:
+                    exchange()
+                    for e in engs:
+                        e.k1()
                 allreduce(0)
                 for e in engs:
                     e.k2()

@@ -388,13 +388,15 @@ def test_fast_and_general_sessions_agree(lib, gpu_ctx):
 @pytest.mark.parametrize("fast,variant", [(1, 1), (1, 0), (0, 0), (2, 1)])
 @pytest.mark.parametrize("nslabs", [2, 3])
 @pytest.mark.parametrize("split", [False, True])
-def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs, split):
+@pytest.mark.parametrize("sr", [False, True])
+def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs, split, sr):
     """slab sessions (k0 > 0, ghost planes, global boundary classes) with the halo exchange / all-reduce done by
     plain device copies on ONE GPU: same order of operations as pdegpu.dist.SlabCG.iterate, no RCCL needed.
-    Must reproduce the single-slab CG iterates and the oracle's solution."""
+    Must reproduce the single-slab CG iterates and the oracle's solution.  sr: the single-reduction recurrences — ONE message
+    {p.Ap, r.r, Ap.Ap} per iteration, summed here over the slabs — against the classic single-slab run."""
     import torch
     from pdegpu import _lib
-    from pdegpu.dist import GpuSlabEngine, slab_range, VEC_R, VEC_P, SC_PQ, SC_RR
+    from pdegpu.dist import GpuSlabEngine, slab_range, VEC_R, VEC_P, SC_PQ, SC_RR, SC_QQ, SC_RR_POLL
     n, Ls = (20, 9, 13), (1.0, 0.7, 1.2)
     grid = _lib.make_grid(3, n, Ls)
     h = _lib.Heat()
@@ -406,7 +408,7 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs,
         h.bc_mode, h.fast_path = _lib.BC_DIRECTIONAL, 1
     iters = 600 if hybrid else 150
 
-    def solve(ns):
+    def solve(ns, sr=False):
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
             engs = []
@@ -414,6 +416,7 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs,
                 k0, nk = slab_range(n[2] + 1, ns, r)
                 engs.append(GpuSlabEngine(grid, h, k0, nk, 0, stream))
                 _lib.check(engs[-1].ctx, lib.pdegpu_set_tunable(engs[-1].ctx, b"cg_variant", variant))
+                engs[-1].set_variant(sr)
             # the 64-B variant keeps p on the ghost planes itself: only r is exchanged
             # hybrid slabs with neighbours: q is stored, r and p travel; a hybrid session that owns every plane uses the 64-B form too
             assert engs[0].needs_p_halo() == (not (variant == 1 and (fast == 1 or (hybrid and ns == 1))))
@@ -426,19 +429,24 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs,
                         hi.plane_tensor(v, -1).copy_(lo.plane_tensor(v, lo.nk - 1))
                         lo.plane_tensor(v, lo.nk).copy_(hi.plane_tensor(v, 0))
 
-            def allreduce(which):
-                slot = SC_PQ if which == 0 else SC_RR
+            def allreduce(which, slots=None):
+                a, b = slots if slots else ((SC_PQ, SC_PQ + 1) if which == 0 else (SC_RR, SC_RR + 1))
+                tot = sum(e.scalars()[a:b].clone() for e in engs)
                 for e in engs:
-                    e.local_to_global(which)
-                tot = sum(e.scalars()[slot:slot + 1].clone() for e in engs)
-                for e in engs:
-                    e.scalars()[slot:slot + 1].copy_(tot)
+                    e.scalars()[a:b].copy_(tot)
+
+            def rr_now():
+                if sr:                                   # the r.r of the last K2 sits in its partials: sum, "all-reduce" scalars[6], read
+                    for e in engs:
+                        e.sr_poll()
+                    allreduce(1, (SC_RR_POLL, SC_RR_POLL + 1))
+                return engs[0].rr()
 
             for e in engs:
                 e.begin(0.0)
                 e.residual()
             allreduce(1)
-            hist = [engs[0].rr()]
+            hist = [rr_now()]
             for it in range(iters):
                 if split:
                     # the overlapped order of SlabCG.iterate: the bulk of K1 runs BEFORE the ghost planes arrive
@@ -452,12 +460,13 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs,
                     exchange()
                     for e in engs:
                         e.k1()
-                allreduce(0)
+                allreduce(0, (SC_PQ, SC_QQ + 1) if sr else None)      # sr: {p.Ap, r.r, Ap.Ap} in ONE message
                 for e in engs:
                     e.k2()
-                allreduce(1)
+                if not sr:
+                    allreduce(1)
                 if it < 6:
-                    hist.append(engs[0].rr())
+                    hist.append(rr_now())
             xs = []
             for e in engs:
                 e.flush()
@@ -472,7 +481,7 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs,
     split, keep = False, split
     x1, h1 = solve(1)
     split = keep
-    xs, hs = solve(nslabs)
+    xs, hs = solve(nslabs, sr)
     ref = o.solve_heat_3d(*Ls, *n, 1.1, 0.25, 0.0, 0.1, 1, steady=True, source_type="constant", source_value=3.0,
                           **(dict(T_left=0.25) if hybrid else {})).values[0]
     assert np.allclose(hs, h1, rtol=1e-10)

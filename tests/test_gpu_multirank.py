@@ -14,14 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
+@pytest.mark.parametrize("variant", ["sr", "classic"])
 @pytest.mark.parametrize("world,cells", [(2, 24), (3, 16)])
-def test_multi_process_slab_cg_matches_single_slab(lib, gpu_ctx, world, cells):
+def test_multi_process_slab_cg_matches_single_slab(lib, gpu_ctx, world, cells, variant):
+    """both recurrences of the driver: "sr" = single reduction (ONE 24-byte scalar message per iteration, the default), "classic" = two"""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "tools" / "rehearse_ranks.py"), str(cells), "80"]
+           "--master-port", str(port), str(ROOT / "tools" / "rehearse_ranks.py"), str(cells), "80", variant]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "REHEARSAL OK" in out.stdout

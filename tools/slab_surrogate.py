@@ -1,5 +1,6 @@
 """Per-rank surrogate of the multi-GPU runs on ONE GPU: what one rank of an N-way slab decomposition computes per CG iteration
-— K1 (split: bulk + edge planes), K2 and the two reduce launches of the stepwise protocol — timed on an interior slab of nk planes of
+— K1 (split: bulk + ONE launch for the edge planes), K2 and the reduce launch(es) of the stepwise protocol, in the single-reduction form
+("sr": one reduce launch, 4 launches per iteration) and the classic one (two) — timed on an interior slab of nk planes of
 the real global grid (ghost planes on both sides, no exchange: a rank's own work).  With the single-GPU iteration time t_1 and the
 surrogate t_N, strong-scaling efficiency is bounded by t_1 / (N t_N) before any communication; adding the measured or estimated
 exchange + all-reduce time gives the projection committed in profiles/.  usage: python tools/slab_surrogate.py [out.json]"""
@@ -20,7 +21,7 @@ out = {"heat": [], "elasticity": []}
 stream = torch.cuda.Stream(device=0)
 
 
-def heat_case(cells, Ls, world, label, iters=60):
+def heat_case(cells, Ls, world, label, iters=60, variant="sr"):
     nz = cells[2]
     rank = world // 2 if world > 2 else (1 if world == 2 else 0)           # an interior rank where there is one
     k0, nk = slab_range(nz + 1, world, rank)
@@ -31,22 +32,28 @@ def heat_case(cells, Ls, world, label, iters=60):
     h.bc_present[0] = 1
     with torch.cuda.stream(stream):
         eng = GpuSlabEngine(grid, h, k0, nk, 0, stream)
-        cg = SlabCG(eng, 0, 1)                                              # world 1: no exchange, the rank's own launches
+        cg = SlabCG(eng, 0, 1, variant=variant)                             # world 1: no exchange, the rank's own launches
         cg.start(0.0)
         cg.iterate(10)
         torch.cuda.synchronize()
-        eng.set_timing(True)
+        # wall time WITHOUT the per-launch HIP events (two event records per launch cost ~2 us of stream time each at these launch rates) ...
         t0 = time.perf_counter()
         cg.iterate(iters)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / iters * 1e3
+        # ... and the kernel times from a second, event-bracketed pass
+        eng.set_timing(True)
+        t0 = time.perf_counter()
+        cg.iterate(iters)
+        torch.cuda.synchronize()
+        wall_timed = (time.perf_counter() - t0) / iters * 1e3
         st = L.Stats()
         eng.get_stats(st)
         eng.close()
     k1, k2 = st.kernel_ms[0] / iters, st.kernel_ms[1] / iters
     unk = (cells[0] - 1) * (cells[1] - 1) * max(0, min(k0 + nk, nz) - max(k0, 1))
-    row = {"workload": label, "world": world, "rank": rank, "planes": nk, "unknowns_of_rank": unk, "k1_ms": k1, "k2_ms": k2,
-           "iteration_wall_ms": wall, "k1_frac_of_8TBs": 40.0 * unk / (k1 * 1e-3) / 8e12, "k2_frac_of_8TBs": 24.0 * unk / (k2 * 1e-3) / 8e12}
+    row = {"workload": label, "variant": variant, "world": world, "rank": rank, "planes": nk, "unknowns_of_rank": unk, "k1_ms": k1, "k2_ms": k2,
+           "iteration_wall_ms": wall, "iteration_wall_ms_with_event_pairs": wall_timed, "k1_frac_of_8TBs": 40.0 * unk / (k1 * 1e-3) / 8e12, "k2_frac_of_8TBs": 24.0 * unk / (k2 * 1e-3) / 8e12}
     out["heat"].append(row)
     print(row, flush=True)
 
@@ -75,22 +82,24 @@ def el_case(cells, Ls, world, iters=200):
     print(row, flush=True)
 
 
-for world in (1, 2, 4, 8):
-    heat_case((512, 512, 512), (1.0, 1.0, 1.0), world, "config 3 strong (512^3 split)")
-for world in (1, 2, 4, 8):
-    heat_case((512, 512, 1024), (1.0, 1.0, 2.0), world, "config 4 (1024x512x512, slabs across the 1024-cell axis)")
+for variant in ("sr", "classic"):
+    for world in (1, 2, 4, 8):
+        heat_case((512, 512, 512), (1.0, 1.0, 1.0), world, "config 3 strong (512^3 split)", variant=variant)
+    for world in (1, 2, 4, 8):
+        heat_case((512, 512, 1024), (1.0, 1.0, 2.0), world, "config 4 (1024x512x512, slabs across the 1024-cell axis)", variant=variant)
 for world in (1, 2, 4, 8):
     el_case((256, 64, 64), (1.0, 0.25, 0.25), world)
-t1 = {r["workload"]: r["iteration_wall_ms"] for r in out["heat"] if r["world"] == 1}
+t1 = {(r["workload"], r["variant"]): r["iteration_wall_ms"] for r in out["heat"] if r["world"] == 1}
 for r in out["heat"]:
-    r["compute_bound_on_efficiency"] = t1[r["workload"]] / (r["world"] * r["iteration_wall_ms"])
+    r["compute_bound_on_efficiency"] = t1[(r["workload"], r["variant"])] / (r["world"] * r["iteration_wall_ms"])
 e1 = [r for r in out["elasticity"] if r["world"] == 1][0]["iteration_wall_us"]
 for r in out["elasticity"]:
     r["compute_bound_on_efficiency"] = e1 / (r["world"] * r["iteration_wall_us"])
-out["note"] = ("one MI355X; each row = the launches ONE rank of an N-way slab decomposition issues per CG iteration (K1 bulk + K1 edge planes + "
-               "reduce + K2 + reduce through pdegpu.dist.SlabCG), on an interior slab of the global grid, without the exchange itself; "
-               "compute_bound_on_efficiency = t(1) / (N t(N)) is an UPPER bound of the strong-scaling efficiency — the halo exchange "
-               "(2.2 MB planes per neighbour, overlapped with K1's bulk) and two 8-byte all-reduces per iteration come on top")
+out["note"] = ("one MI355X; each row = the launches ONE rank of an N-way slab decomposition issues per CG iteration through pdegpu.dist.SlabCG "
+               "(sr: K1 bulk + K1 edge planes + reduce + K2 = 4 launches; classic: + a second reduce), on an interior slab of the global grid, "
+               "without the exchange itself; compute_bound_on_efficiency = t(1) / (N t(N)) within one variant is an UPPER bound of the "
+               "strong-scaling efficiency — the halo exchange (2.2 MB planes per neighbour, overlapped with K1's bulk) and ONE 24-byte "
+               "all-reduce per iteration (classic: two 8-byte ones) come on top")
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 1:
     Path(sys.argv[1]).write_text(json.dumps(out, indent=1))
