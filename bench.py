@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--cg-variant", choices=("sr", "classic"), default="sr", help="sr: single-reduction recurrences, ONE 24-byte scalar all-reduce per "
                     "iteration (default); classic: 8 bytes after K1 and 8 bytes after K2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tool-extras", action="store_true", help="skip the end-to-end tool-wall legs (config 3 / config 4 steady solves through the tool API)")
     ap.add_argument("--general", action="store_true", help="force the class-table kernels (diagnostic)")
     args = ap.parse_args()
 
@@ -406,8 +407,42 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             R.dist.destroy_process_group()
         except Exception as e:
             extras["collective_calls_one_rank"] = {"failed": repr(e)}
+    if world == 1 and not args.no_tool_extras:
+        # end-to-end cost of the tool boundary at BASELINE's sizes: wall time of the reference-named solver (_solve_heat_3d_raw: kwargs in,
+        # numpy field out) against the device time of its solve, then the pickle hand-off and the plot tool
+        try:
+            extras["tool_wall"] = tool_wall_extras(n)
+        except Exception as e:
+            extras["tool_wall"] = {"failed": repr(e)}
     wd.cancel()
     return extras
+
+
+def tool_wall_extras(n):
+    import tempfile
+    from pdegpu import heat as H
+    from pdegpu import server as S
+    out = {}
+    for label, kw in (("config3_steady", dict(Lx=1.0, Ly=1.0, Lz=1.0, nx=n, ny=n, nz=n)),
+                      ("config4_steady", dict(Lx=2.0, Ly=1.0, Lz=1.0, nx=2 * n, ny=n, nz=n))):
+        t0 = time.perf_counter()
+        f = H._solve_heat_3d_raw(diffusivity=1.0, T_boundary=0.0, T_initial=0.0, dt=0.1, num_steps=1, steady=True, source_type="constant",
+                                 source_value=1.0, rtol=1e-8, **kw)
+        wall = time.perf_counter() - t0
+        solve_s = f.meta["solve_ms"] / 1e3
+        row = {"raw_solver_wall_s": wall, "device_solve_s": solve_s, "wall_over_solve": wall / solve_s, "cg_iterations": f.meta["cg_iterations"],
+               "field_GB": f.values.nbytes / 1e9}
+        with tempfile.TemporaryDirectory() as td:
+            t0 = time.perf_counter()
+            res = S._store(f, td, "heat_3d")
+            row["pickle_store_s"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            S.plot_time_series_field_from_file(res.data_file, output_dir=td)
+            row["plot_tool_s"] = time.perf_counter() - t0
+        del f
+        out[label] = row
+        log(f"tool wall {label}: {row}")
+    return out
 
 
 if __name__ == "__main__":

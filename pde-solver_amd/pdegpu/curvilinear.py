@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _lib as L
-from .fields import TimeSeriesField
+from .fields import GridCoords, TimeSeriesField
 
 
 def run_weighted(dim, n, lengths, origin, kind, *, kappa, dt, num_steps, steady, source_type, source_value, T_initial,
@@ -193,9 +193,7 @@ def solve_heat_3d_box_core(Lx, Ly, Lz, nx, ny, nz, diffusivity, T_boundary, T_in
                                      T_initial=0.0 if initial_type == "zero" else T_initial, bc_mode=bc_mode, bc_value=bc_value,
                                      bc_present=bc_present, core_radius=core_radius, core_ratio=core_diffusivity / diffusivity,
                                      u0=u0, **opts)
-    x, y, z = _axes((nx, ny, nz), (0.0, 0.0, 0.0), (Lx, Ly, Lz))
-    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
-    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    coords = GridCoords(3, (nx, ny, nz), (Lx, Ly, Lz))
     meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cartesian", "Lx": Lx, "Ly": Ly, "Lz": Lz,
             "geometry_type": "box", "source_type": source_type, "source_value": source_value, "steady": steady}   # :721-733
     if directional:
@@ -240,9 +238,7 @@ def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_i
                                      T_initial=T_initial, bc_mode=bc_mode, bc_value=bc_value, bc_present=bc_present,
                                      core_radius=core_radius if composite else 0.0,
                                      core_ratio=core_diffusivity / diffusivity if composite else 1.0, u0=u0, **opts)
-    x, y, z = _axes((nx, ny2, nz2), (0.0, -R, -R), (Lx, 2 * R, 2 * R))
-    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
-    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    coords = GridCoords(3, (nx, ny2, nz2), (Lx, 2 * R, 2 * R), origin=(0.0, -R, -R))
     meta = {"name": "temperature", "unit": "°C", "pde": "heat", "coordinate_system": "cylindrical", "Lx": Lx, "Ly": R * 2,
             "Lz": R * 2, "geometry_type": "cylinder", "source_type": source_type, "source_value": source_value, "steady": steady,
             "cylinder_radius": R}                                                   # :721-736

@@ -86,7 +86,7 @@ def run_heat(dim, n, Ls, *, kappa, dt, num_steps, steady, source_type, source_va
 def _extra_meta(stats, element_mode):
     """Build-side additions go into meta only."""
     m = {"backend": "pdegpu-hip-gfx950", "element_mode": "q1" if element_mode == L.ELEM_Q1 else "p1split",
-         "cg_iterations": int(stats["cg_iterations"]), "solver_path": stats["path"]}
+         "cg_iterations": int(stats["cg_iterations"]), "solver_path": stats["path"], "solve_ms": float(stats["solve_ms"])}
     m.update(stats.get("snapshot_meta", {"snapshot_stride": 1}))
     return m
 

@@ -16,7 +16,51 @@ from . import curvilinear as _cv
 from . import elasticity as _el
 from . import heat as _heat
 from . import params as _params
-from .fields import PlotResult, SolveResult, TimeSeriesField
+from .fields import GridCoords, PlotResult, SolveResult, TimeSeriesField
+
+PREVIEW_MAX_FRAMES, PREVIEW_MAX_PIXELS = 60, 192
+
+
+def _grid_shape_of(coords):
+    """(NX, NY, NZ) of the structured node order behind `coords`: known for GridCoords, inferred from the repetition pattern otherwise"""
+    if isinstance(coords, GridCoords):
+        return coords.grid_shape
+    return _infer_grid(np.asarray(coords, dtype=float))
+
+
+def _validate(field):
+    """the shape checks of the reference's plotter (:3457-3466); returns (values, times) as arrays"""
+    coords = field.coords
+    values = np.asarray(field.values, dtype=float)
+    times = np.asarray(field.times, dtype=float)
+    cshape = tuple(coords.shape) if hasattr(coords, "shape") else np.asarray(coords, dtype=float).shape
+    if len(cshape) != 2 or cshape[1] != 3:
+        raise ValueError(f"coords must be [N,3], got {cshape}")
+    if values.ndim != 2 or values.shape[1] != cshape[0]:
+        raise ValueError(f"values must be [Nt,N] with N={cshape[0]}, got {values.shape}")
+    if times.shape != (values.shape[0],):
+        raise ValueError(f"times must be [Nt] with Nt={values.shape[0]}, got {times.shape}")
+    return values, times
+
+
+def _preview(field: TimeSeriesField):
+    """What the plot tool shows, cut from the field while it is in memory: <= 60 stored times, the mid-z plane (the only plane in 1-D / 2-D)
+    strided to <= 192 x 192, and min / max / mean of every shown state.  A few hundred KB next to a pickle of up to tens of GB."""
+    values, times = _validate(field)
+    shape = _grid_shape_of(field.coords)
+    tsel = np.unique(np.linspace(0, len(times) - 1, min(len(times), PREVIEW_MAX_FRAMES)).round().astype(int))
+    stats = np.array([[values[k].min(), values[k].max(), values[k].mean()] for k in tsel])
+    import json
+    out = {"tsel": tsel, "times": times[tsel], "stats": stats, "n_times": np.array(len(times)), "n_nodes": np.array(values.shape[1]),
+           "meta_json": np.array(json.dumps(field.meta, default=str)), "dim": np.array(int(field.dim)),
+           "vmin": np.array(float(values.min()) if values.size <= 1 << 27 else float(stats[:, 0].min())),
+           "vmax": np.array(float(values.max()) if values.size <= 1 << 27 else float(stats[:, 1].max()))}
+    if shape is not None and shape[0] * shape[1] * shape[2] == values.shape[1]:
+        nx, ny, nz = shape
+        sx, sy = max(1, -(-nx // PREVIEW_MAX_PIXELS)), max(1, -(-ny // PREVIEW_MAX_PIXELS))
+        out["frames"] = np.stack([values[k].reshape(nz, ny, nx)[nz // 2, ::sy, ::sx] for k in tsel])
+        out["shape"] = np.array(shape)
+    return out
 
 
 def _store(field: TimeSeriesField, data_dir: str, prefix: str) -> SolveResult:
@@ -25,6 +69,14 @@ def _store(field: TimeSeriesField, data_dir: str, prefix: str) -> SolveResult:
     filepath = data_path / f"{prefix}_{uuid.uuid4().hex[:8]}.pkl"
     with open(filepath, "wb") as f:
         pickle.dump(field, f, protocol=pickle.HIGHEST_PROTOCOL)
+    # the plot tool's view as a sidecar, so that plotting a 513^3 field does not un-pickle gigabytes to show 192 x 192 pixels of them
+    # (the pickle stays the complete hand-off of the reference, :1962-1968; the sidecar is optional and rebuilt from it when missing)
+    try:
+        pv = _preview(field)
+        if pv is not None:
+            np.savez(str(filepath) + ".preview.npz", **pv)
+    except Exception:  # noqa: BLE001 — a preview must never fail a solve
+        pass
     return SolveResult(data_file=str(filepath), dim=field.dim, meta=field.meta)
 
 
@@ -216,46 +268,44 @@ def plot_time_series_field_from_file(data_file: str, field_name: Optional[str] =
     same shapes the reference's plotter validates (:3457-3466)."""
     import base64
     import json
-    with open(data_file, "rb") as f:
-        field = pickle.load(f)
-    coords = np.asarray(field.coords, dtype=float)
-    values = np.asarray(field.values, dtype=float)
-    times = np.asarray(field.times, dtype=float)
-    if coords.ndim != 2 or coords.shape[1] != 3:
-        raise ValueError(f"coords must be [N,3], got {coords.shape}")
-    if values.ndim != 2 or values.shape[1] != coords.shape[0]:
-        raise ValueError(f"values must be [Nt,N] with N={coords.shape[0]}, got {values.shape}")
-    if times.shape != (values.shape[0],):
-        raise ValueError(f"times must be [Nt] with Nt={values.shape[0]}, got {times.shape}")
-    name = field_name or field.meta.get("name", "field")
-    unit = unit or field.meta.get("unit", "")
+    side = Path(str(data_file) + ".preview.npz")
+    pv, field = None, None
+    if side.exists() and side.stat().st_mtime >= Path(data_file).stat().st_mtime:
+        try:
+            with np.load(side) as z:
+                pv = {k: z[k] for k in z.files}
+        except Exception:  # noqa: BLE001 — a damaged sidecar: fall back to the pickle
+            pv = None
+    if pv is None:
+        with open(data_file, "rb") as f:
+            field = pickle.load(f)
+        pv = _preview(field)               # (validates the shapes the reference's plotter validates; raises ValueError)
+    meta, dim = json.loads(str(pv["meta_json"])), int(pv["dim"])
+    name = field_name or meta.get("name", "field")
+    unit = unit or meta.get("unit", "")
     out = Path(output_dir)
     out.mkdir(parents=True, exist_ok=True)
     stem = filename or (Path(data_file).stem + ".html")
     if not stem.endswith(".html"):
         stem += ".html"
-    tsel = np.unique(np.linspace(0, len(times) - 1, min(len(times), 60)).round().astype(int))
-    rows = "".join(f"<tr><td>{times[k]:.6g}</td><td>{values[k].min():.6g}</td><td>{values[k].max():.6g}</td>"
-                   f"<td>{values[k].mean():.6g}</td></tr>" for k in tsel)
-    meta_rows = "".join(f"<tr><td>{k}</td><td>{v}</td></tr>" for k, v in field.meta.items())
+    n_nodes, n_times = int(pv["n_nodes"]), int(pv["n_times"])
+    rows = "".join(f"<tr><td>{t:.6g}</td><td>{st[0]:.6g}</td><td>{st[1]:.6g}</td><td>{st[2]:.6g}</td></tr>" for t, st in zip(pv["times"], pv["stats"]))
+    meta_rows = "".join(f"<tr><td>{k}</td><td>{v}</td></tr>" for k, v in meta.items())
     view = ""
-    shape = _infer_grid(coords)
-    if shape is not None:
-        nx, ny, nz = shape
-        v = values[tsel].reshape(len(tsel), nz, ny, nx)[:, nz // 2]              # mid-z plane (the only plane in 1-D / 2-D)
-        sx, sy = max(1, -(-nx // 192)), max(1, -(-ny // 192))
-        v = v[:, ::sy, ::sx]
-        vmin, vmax = float(values.min()), float(values.max())
+    if "frames" in pv:
+        nx, ny, nz = (int(v) for v in pv["shape"])
+        v = pv["frames"]
+        vmin, vmax = float(pv["vmin"]), float(pv["vmax"])
         q = np.zeros_like(v, dtype=np.uint8) if vmax <= vmin else np.clip((v - vmin) / (vmax - vmin) * 255.0 + 0.5, 0, 255).astype(np.uint8)
-        doc = {"w": int(v.shape[2]), "h": int(v.shape[1]), "times": [float(t) for t in times[tsel]], "vmin": vmin, "vmax": vmax,
+        doc = {"w": int(v.shape[2]), "h": int(v.shape[1]), "times": [float(t) for t in pv["times"]], "vmin": vmin, "vmax": vmax,
                "unit": unit, "b64": base64.b64encode(q.tobytes()).decode("ascii")}
         what = "line" if ny == 1 else ("field" if nz == 1 else f"plane k = {nz // 2} of {nz}")
         view = (f"<p>{what}, {nx} x {ny} x {nz} nodes shown at {doc['w']} x {doc['h']}</p><canvas id='c' width='576' height='"
                 f"{576 if ny > 1 else 240}' style='border:1px solid #888'></canvas><br><input id='s' type='range' min='0' value='0' "
                 f"style='width:576px'><div id='l'></div><script type='application/json' id='d'>{json.dumps(doc)}</script>"
                 f"<script>{_PLOT_JS}</script>")
-    html = (f"<html><head><meta charset='utf-8'><title>{name}</title></head><body><h2>{name} [{unit}] — {field.dim}-D, "
-            f"{coords.shape[0]} nodes, {len(times)} stored times</h2>{view}<table border=1><tr><th>t</th><th>min</th><th>max</th>"
+    html = (f"<html><head><meta charset='utf-8'><title>{name}</title></head><body><h2>{name} [{unit}] — {dim}-D, "
+            f"{n_nodes} nodes, {n_times} stored times</h2>{view}<table border=1><tr><th>t</th><th>min</th><th>max</th>"
             f"<th>mean</th></tr>{rows}</table><h3>meta</h3><table border=1>{meta_rows}</table></body></html>")
     path = out / stem
     path.write_text(html, encoding="utf-8")

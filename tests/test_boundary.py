@@ -127,12 +127,17 @@ def test_plot_tool_downsamples_structured_fields(tmp_path, dim, n):
     from pdegpu.fields import TimeSeriesField, grid_coords
     Ls = (2.0, 1.0, 0.5)[:dim]
     c = grid_coords(dim, n, Ls)
-    assert server._infer_grid(c) == tuple(k + 1 for k in n) + (1,) * (3 - dim)
+    assert c.grid_shape == tuple(k + 1 for k in n) + (1,) * (3 - dim) and len(pickle.dumps(c)) < 400          # lazy: pickles as its axes' description
+    assert server._infer_grid(np.asarray(c)) == c.grid_shape                                                   # plain arrays: inferred from the node order
     nt = 130
     vals = np.linspace(0.0, 1.0, nt)[:, None] * (1.0 + c[:, 0])[None, :]
     f = TimeSeriesField(coords=c, values=vals, times=np.arange(nt) * 0.1, dim=dim, meta={"name": "temperature", "unit": "°C"})
     res = server._store(f, str(tmp_path / "data"), f"heat_{dim}d")
+    assert Path(res.data_file + ".preview.npz").exists()
     html = Path(server.plot_time_series_field_from_file(res.data_file, output_dir=str(tmp_path / "plots")).html_path).read_text()
+    # without the sidecar (a pickle written by someone else) the tool builds the same view from the pickle
+    Path(res.data_file + ".preview.npz").unlink()
+    assert Path(server.plot_time_series_field_from_file(res.data_file, output_dir=str(tmp_path / "plots2")).html_path).read_text() == html
     doc = json.loads(re.search(r"<script type='application/json' id='d'>(.*?)</script>", html, re.S).group(1))
     assert doc["w"] <= 192 and doc["h"] <= 192 and len(doc["times"]) <= 60
     assert doc["times"][0] == 0.0 and abs(doc["times"][-1] - 12.9) < 1e-12
