@@ -222,6 +222,20 @@ class Runner:
             eng.set_timing(False)
             res["rr_after"] = cg.rr()
             res["cg_variant"] = "sr" if cg.sr else "classic"
+            if case.get("collective_ab"):
+                # the same session, the same allocations (K1's time depends on them): the loop again with the scalar all-reduce of every
+                # iteration issued through the (one-rank) process group, then once more without — the difference is what the CALLS cost
+                ab = {}
+                for label, force in (("with_collective_calls", True), ("without", False), ("with_collective_calls_2", True), ("without_2", False)):
+                    cg.force_collectives = force
+                    cg.iterate(max(5, warmup // 2))
+                    self.fence()
+                    t0 = time.perf_counter()
+                    cg.iterate(steps)
+                    self.fence()
+                    ab[label] = (time.perf_counter() - t0) / steps * 1e3
+                cg.force_collectives = False
+                res["collective_ab_ms"] = ab
             if world > 1:
                 t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -397,13 +411,15 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             R.dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.torch.device(f"cuda:{R.local_rank}"))
             c3 = dict(case)
-            c3["force_collectives"] = True
+            c3["collective_ab"] = True
             st3 = max(20, args.steps // 2)
             r3 = R.run_case(c3, st3, max(5, args.warmup // 2))
+            ab = r3["collective_ab_ms"]
             extras["collective_calls_one_rank"] = {
-                "what": "main workload with the scalar all-reduce(s) of every iteration issued through a 1-rank RCCL group (no wire time)",
-                "steps": st3, "ms_per_step": r3["elapsed"] / st3 * 1e3, "value": r3["unknowns"] * st3 / r3["elapsed"], "unit": "DoF/s",
-                "ms_per_step_without": ms_per_step}
+                "what": "main workload, ONE session (same allocations): the loop with the scalar all-reduce of every iteration issued through a 1-rank "
+                        "RCCL group (no wire time) and without, alternating; the difference is torch.distributed's stream hand-over + RCCL's launch path",
+                "cg_variant": r3["cg_variant"], "steps": st3, "ms_per_step": ab,
+                "calls_cost_us_per_iteration": 0.5e3 * ((ab["with_collective_calls"] - ab["without"]) + (ab["with_collective_calls_2"] - ab["without_2"]))}
             R.dist.destroy_process_group()
         except Exception as e:
             extras["collective_calls_one_rank"] = {"failed": repr(e)}

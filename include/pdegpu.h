@@ -169,8 +169,8 @@ const char* pdegpu_version(void);
  * el_fast_yzface     | 3       | bit 0: y-face rows, bit 1: the planes 0 / NZ-1 as well (the class-table pass keeps the box edges)
  * el_fast_nt         | -1      | non-temporal stores of the output: 1|0, -1 = where the vectors are HBM-resident
  * el_fast_waves      | 0       | wavefront target of the marching part; 0 = 4096, 8192 on HBM-resident grids
- * el_split_min_planes| 24      | slab loop: k1 is split around the halo exchange on slabs of at least this many planes (two more
- *                    |         | launches: 8 planes per rank of config 5 ran 26 -> 34 us per iteration with the split)
+ * el_split_min_mb    | 32      | slab loop: k1 is split around the halo exchange where one vector of the slab holds at least this many
+ *                    |         | MiB (two more launches, ~9 us: config 5's slabs ran 26 -> 34 us per iteration at N = 8 with the split)
  * el_bnd_last        | 0       | boundary workgroups take the last block indices
  * el_grid_mult       | 4       | flat / class-table kernels: workgroups per CU
  */
@@ -272,7 +272,7 @@ int     pdegpu_el_session_get_u(pdegpu_el_session* s, double* u_out /* host [nk 
 /* k1 in two steps so that the halo exchange overlaps the part of it that reads no ghost plane (same protocol as pdegpu_session_k1_part):
  * part 0 = p-update of the owned planes + the marching apply on the planes away from the ghosts (call it right after posting the exchange),
  * part 1 = p-update of the ghost planes + the apply on the one or two edge planes (one launch) + the p.q sum.  can_split_k1 = 1 for 3-D
- * marching sessions on slabs of at least el_split_min_planes (24) planes with a neighbour; other sessions do nothing in part 0 and the whole k1 in part 1. */
+ * marching sessions on slabs with a neighbour whose vectors hold at least el_split_min_mb (32) MiB; other sessions do nothing in part 0 and the whole k1 in part 1. */
 int     pdegpu_el_session_can_split_k1(const pdegpu_el_session* s);
 int     pdegpu_el_session_k1_part(pdegpu_el_session* s, int part);
 /* von Mises + project() (:1840-1866) on one GPU from a displacement field gathered on the host, disp [N][dim] */

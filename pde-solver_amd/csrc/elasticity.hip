@@ -254,7 +254,9 @@ __device__ __forceinline__ ElW36 el_expand_weights(const ElW18& k) {
     w.faces = k.faces;
     return w;
 }
-constexpr int kElXt = 62;      // nodes a wave owns per row (lanes 1 .. 62; lanes 0 and 63 carry the x-halo)
+// nodes a wave owns per row (lanes 1 .. 62; lanes 0 and 63 carry the x-halo).  48-node tiles on 128-byte boundaries were measured twice and are
+// gone: slower at every size, HBM-resident grids included (profiles/r03_elasticity_apply_large_grids.log)
+constexpr int kElXt = 62;
 struct ElFastGeom {
     int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
     int nyg;                   // groups of 4 y-tiles (one workgroup each) of the y-hand-off variant
@@ -1458,9 +1460,10 @@ int el_lazy_finish(ElSession* s, ElLazy* lazy) {
 // both), p.q reduce.
 bool el_k1_splittable(const ElSession* s) {
     const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
-    // (two more launches than the unsplit K1: pays only where the bulk of the apply is long enough to hide the exchange behind —
-    // measured on the per-rank surrogate, config 5 at 8 planes per rank: 26 -> 34 us per iteration with the split)
-    return s->D == 3 && s->fast && s->ctx->el_fast && (lo || hi) && s->g.nkl >= std::max(4, s->ctx->el_split_min_planes);
+    // (two more launches than the unsplit K1, ~9 us per iteration on the per-rank surrogate — config 5: 26 -> 34 us at 8 planes per rank, 44 -> 53 us
+    // at 33: it pays only where the apply on the planes away from the ghosts is long enough to hide a sizeable exchange, i.e. on big slabs)
+    const double slab_mb = (double)s->g.nkl * (double)s->g.PP * 3.0 * 8.0 / (1 << 20);
+    return s->D == 3 && s->fast && s->ctx->el_fast && (lo || hi) && s->g.nkl >= 4 && slab_mb >= (double)s->ctx->el_split_min_mb;
 }
 int el_pupdate_launch(ElSession* s, const ElArgs& a, long long first, long long total, long long first2 = 0, long long total2 = 0) {
     int nb1 = s->nblk, nb = s->nblk;

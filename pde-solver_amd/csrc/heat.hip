@@ -223,6 +223,9 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     // it (a.fx_hi); otherwise that one column stays here
     const bool fx = a.free_x == 2;
     a.bnd_xcols = fx ? (a.fx_hi ? 0 : 1) : 2;
+    // (Round 3 computed that column in the marching K1 / K2 instead — the last lane of a row's last tile holds its value and neighbours as
+    // tile-edge values — parity-green and SLOWER: the edge values of all rows of three planes cost the 7-point kernels 134 -> 182 (K1) and
+    // 109 -> 138 (K2) VGPRs; 512^3, T_left only: 85-87 -> 67-71 GDoF/s; removed, profiles/r03_natural_face_column_in_marching_kernel.log.)
     // The column x = NX-1 that the tiles do not reach (2^k * 128 + 1 nodes per row) is the expensive part of this pass — one node per 4 KB row, 57 of
     // its 97 us in K1 and 32 of 56 us in K2 at 512^3 (profiles/r02_exp20_*.log).  Where that face is Dirichlet there is nothing to compute on it:
     // the CG vectors r, p vanish there and stay so (only these two passes write them: K1 would store p = 0 + beta 0, the in-place K2 r = 0), x keeps
@@ -459,7 +462,7 @@ static const char* const kTunableKeys[] = {
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
     "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
-    "el_fast_waves", "el_split_min_planes"};
+    "el_fast_waves", "el_split_min_mb"};
 
 extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
     if (!out) return PDEGPU_EINVAL;
@@ -531,7 +534,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "el_fast_yzface")) return &ctx->el_fast_yzface;
     if (!strcmp(key, "el_fast_nt")) return &ctx->el_fast_nt;
     if (!strcmp(key, "el_fast_waves")) return &ctx->el_fast_waves;
-    if (!strcmp(key, "el_split_min_planes")) return &ctx->el_split_min_planes;
+    if (!strcmp(key, "el_split_min_mb")) return &ctx->el_split_min_mb;
     return nullptr;
 }
 }  // namespace

@@ -160,8 +160,8 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split):
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         engs = [GpuElasticitySlabEngine(grid, el, *slab_range(n[2] + 1, nslabs, r), 0, stream) for r in range(nslabs)]
-        for e in engs:                      # (the default splits slabs of >= 24 planes only: thin slabs lose more on the two extra launches)
-            _lib.check(e.ctx, lib.pdegpu_set_tunable(e.ctx, b"el_split_min_planes", 4))
+        for e in engs:                      # (the default splits only slabs whose vectors hold >= 32 MiB: small slabs lose more on the two extra launches)
+            _lib.check(e.ctx, lib.pdegpu_set_tunable(e.ctx, b"el_split_min_mb", 0))
 
         def exchange():
             for r in range(nslabs - 1):

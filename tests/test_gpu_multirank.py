@@ -53,11 +53,11 @@ def test_bench_line_of_the_multi_rank_path(lib, gpu_ctx):
 
 def test_multi_process_elasticity_slabs(lib, gpu_ctx):
     """solve_elasticity_slabs with 2 ranks sharing the GPU (gloo rehearsal): von Mises field == the single-process solve; k1 split
-    around the exchange (forced on these 5-plane slabs: the default splits slabs of >= 24 planes)"""
+    around the exchange (forced on these 5-plane slabs: the default splits slabs of >= 32 MiB per vector)"""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PDEGPU_EL_SPLIT_MIN_PLANES="4")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PDEGPU_EL_SPLIT_MIN_MB="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "tools" / "rehearse_elasticity.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
