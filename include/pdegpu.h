@@ -169,6 +169,8 @@ const char* pdegpu_version(void);
  * el_fast_yzface     | 3       | bit 0: y-face rows, bit 1: the planes 0 / NZ-1 as well (the class-table pass keeps the box edges)
  * el_fast_nt         | -1      | non-temporal stores of the output: 1|0, -1 = where the vectors are HBM-resident
  * el_fast_waves      | 0       | wavefront target of the marching part; 0 = 4096, 8192 on HBM-resident grids
+ * el_cg_variant      | 1       | PCG recurrences: 1 = single-reduction form (the r- and p-updates fused into ONE pass of 7 vector reads /
+ *                    |         | writes, one scalar reduction per iteration; same iteration counts), 0 = classic (p-update, apply, K2)
  * el_split_min_mb    | 32      | slab loop: k1 is split around the halo exchange where one vector of the slab holds at least this many
  *                    |         | MiB (two more launches, ~9 us: config 5's slabs ran 26 -> 34 us per iteration at N = 8 with the split)
  * el_bnd_last        | 0       | boundary workgroups take the last block indices
@@ -275,6 +277,16 @@ int     pdegpu_el_session_get_u(pdegpu_el_session* s, double* u_out /* host [nk 
  * marching sessions on slabs with a neighbour whose vectors hold at least el_split_min_mb (32) MiB; other sessions do nothing in part 0 and the whole k1 in part 1. */
 int     pdegpu_el_session_can_split_k1(const pdegpu_el_session* s);
 int     pdegpu_el_session_k1_part(pdegpu_el_session* s, int part);
+/* The PCG recurrences of a session (default: the context's el_cg_variant tunable).  0 = classic: the host all-reduces scalars[0] (p.Ap) after k1 and
+ * scalars[1..2] (r.z, r.r) after k2.  1 = single-reduction form: the residual update r -= a q moves INTO k1, fused with the p-update (7 vector
+ * passes instead of 8, one launch less); k2 and flush do nothing; after k1 / k1_part(1) the block scalars[0..3] = {p.Ap, r.z, r.r, Ap.D^-1 Ap} is
+ * the ONE 32-byte message of the iteration; beta comes from the predicted r.z = a^2 (Ap.D^-1 Ap) - r.z (exact arithmetic: the same iterates; the
+ * true r.z of every residual forms the next alpha).  On a slab with neighbours r changes inside k1, so its halo exchange moves there too:
+ * k1_pre (update pass of the owned planes) -> exchange the first / last owned plane of r -> k1_part(0) -> k1_part(1); k1_pre is a no-op in the
+ * classic form, so a driver may always call it.  x always matches the residual scalars[2] reports.  Choose before begin(). */
+int     pdegpu_el_session_set_cg_variant(pdegpu_el_session* s, int variant);
+int     pdegpu_el_session_cg_variant(const pdegpu_el_session* s);
+int     pdegpu_el_session_k1_pre(pdegpu_el_session* s);
 /* von Mises + project() (:1840-1866) on one GPU from a displacement field gathered on the host, disp [N][dim] */
 int     pdegpu_elasticity_postprocess(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, const double* disp,
                                       double* field_out);

@@ -47,6 +47,7 @@ struct pdegpu_ctx {
     int el_fast_nt = -1;        // k_el_fast: non-temporal stores of the output: 1 | 0; -1 = where the vectors are HBM-resident
     int el_bnd_last = 0;        // k_el_fast: 1 = the boundary workgroups take the last block indices instead of the first
     int el_fast_ry = 2;         // rows per wavefront column of k_el_fast (1 | 2)
+    int el_cg_variant = 1;      // elasticity PCG: 1 = single-reduction form (K2 and p-update fused into one pass, one scalar reduction per iteration); 0 = classic
     int el_split_min_mb = 32;   // slab loop: K1 is split around the halo exchange where one vector of the slab (3 components) holds at least this many MiB
     int el_fast_waves = 0;      // wavefronts the marching part aims for (sets the z-chunk length); 0 = 4096, 8192 on HBM-resident grids
     int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never

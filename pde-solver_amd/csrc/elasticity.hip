@@ -19,7 +19,9 @@
 namespace {
 
 // device scalars of the elasticity PCG; RZ and RR are adjacent so the multi-GPU host all-reduces them as one 16-byte message
-enum { ESC_PQ = 0, ESC_RZ = 1, ESC_RR = 2, ESC_RZ_PREV = 3, ESC_COUNT = 8 };
+// Single-reduction form (el_cg_variant 1): the block {ESC_PQ, ESC_RZ, ESC_RR, ESC_QMQ} = {p.Ap, r.z, r.r, Ap.D^-1 Ap} is ONE 32-byte message per iteration
+// (ESC_QMQ takes the slot the classic form uses for the previous r.z).
+enum { ESC_PQ = 0, ESC_RZ = 1, ESC_RR = 2, ESC_RZ_PREV = 3, ESC_QMQ = 3, ESC_COUNT = 8 };
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -79,6 +81,12 @@ struct ElArgs {
     const double* din2 = nullptr;
     int din_n = 0;
     int s_rz = 1, s_rz_old = 3;     // ESC_RZ / ESC_RZ_PREV: slots of r.z of this and of the previous iteration
+    // single-reduction form: the apply also sums (A p) . D^-1 (A p) into partials_qmq (same indexing as partials); the fused update pass finds the
+    // apply's two partial arrays in din3 / din4 (din_n2 entries each) next to its own r.z / r.r partials of the iteration before (din / din2)
+    double* partials_qmq = nullptr;
+    const double* din3 = nullptr;
+    const double* din4 = nullptr;
+    int din_n2 = 0;
 };
 
 // fixed-order sum of n partials by all 256 threads (identical in every workgroup; the order k_el_reduce uses)
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void k_el_apply(ElArgs a, ElInterior wi) {
         alpha_prev = (pq > 0.0 && rz_prev > 0.0) ? rz_prev / pq : 0.0;
         beta = (rz_prev > 0.0) ? rz / rz_prev : 0.0;
     }
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int i = (int)(idx % g.PX);
         const long long row = idx / g.PX;
@@ -182,7 +190,10 @@ __global__ __launch_bounds__(256) void k_el_apply(ElArgs a, ElInterior wi) {
         for (int c = 0; c < D; ++c) {
             if (MODE == APPLY_PLAIN) {
                 a.out[c * a.stride + idx] = s[c];
-                if (real) acc += a.in[c * a.stride + idx] * s[c];
+                if (real) {
+                    acc += a.in[c * a.stride + idx] * s[c];
+                    if (a.partials_qmq) acc2 += a.dinv[cls * 3 + c] * s[c] * s[c];      // (kernel-uniform branch)
+                }
             } else if (MODE == APPLY_RESIDUAL) {
                 double rv = 0.0;
                 if (real && !dir) rv = a.rhs[c * a.stride + idx] - s[c];
@@ -196,6 +207,10 @@ __global__ __launch_bounds__(256) void k_el_apply(ElArgs a, ElInterior wi) {
     }
     const double tot = block_sum_256(acc, sRed);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    if (a.partials_qmq) {
+        const double t2 = block_sum_256(acc2, sRed);
+        if (threadIdx.x == 0) a.partials_qmq[blockIdx.x] = t2;
+    }
 }
 
 
@@ -358,9 +373,9 @@ __device__ __forceinline__ void el_face_node(const ElW36& w, const double (*G)[3
 
 // Boundary workgroups of the marching launches: the nodes the marching part does not compute (all boundary nodes, or with faces folded in the
 // edges and corners of the box), one thread per node, truncated class stencils from LDS.  Returns this thread's share of p . q.
-__device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, const ElFastGeom& fg, int bidx, double* sTab, unsigned* sMask) {
+__device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, const ElFastGeom& fg, int bidx, double* sTab, unsigned* sMask, double* acc2_out) {
     const GridDev& g = a.g;
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
     // ---- boundary nodes: one thread per node, truncated class stencils from LDS -----------------------------
     for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
     if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
@@ -420,6 +435,7 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
         // offset that leaves the grid still lands inside the allocation (ghost planes / guards / row pads, all zero
         // or finite neighbour data) and meets a class weight that is exactly 0.
         double s[3] = {0.0, 0.0, 0.0};
+        const int cls = pg_axis_class(i, g.NX) + 3 * pg_axis_class(j, g.NY) + 9 * pg_axis_class(kg, g.NZ);
         double nv[PG_NOFF15][3];
 #pragma unroll
         for (int q = 0; q < PG_NOFF15; ++q) {
@@ -430,7 +446,6 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
             for (int c = 0; c < 3; ++c) nv[q][c] = a.in[c * a.stride + nb];
         }
         if (!dir) {
-            const int cls = pg_axis_class(i, g.NX) + 3 * pg_axis_class(j, g.NY) + 9 * pg_axis_class(kg, g.NZ);
             const double* wtab = &sTab[cls * PG_NOFF15 * 9];
 #pragma unroll
             for (int q = 0; q < PG_NOFF15; ++q) {
@@ -443,8 +458,10 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
         for (int c = 0; c < 3; ++c) {
             a.out[c * a.stride + idx] = s[c];
             acc += pc[c] * s[c];
+            if (a.partials_qmq) acc2 += a.dinv[cls * 3 + c] * s[c] * s[c];      // (kernel-uniform branch; 81 doubles, cache-resident)
         }
     }
+    *acc2_out = acc2;
     return acc;
 }
 
@@ -458,12 +475,13 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
     __shared__ double sRed[8];
     constexpr int RH = RY + 2;
     const GridDev& g = a.g;
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;                             // acc2: (A p) . D^-1 (A p) of the single-reduction PCG (a.partials_qmq)
+    const bool qmq = a.partials_qmq != nullptr;              // kernel-uniform
     // workgroup roles: bnd_last = 0: boundary workgroups take the first nb_bnd block indices; 1: the last ones (they then start as the
     // marching workgroups retire, filling the tail of the launch)
     const int bidx = fg.bnd_last ? ((int)blockIdx.x >= fg.nb_fast ? (int)blockIdx.x - fg.nb_fast : -1) : ((int)blockIdx.x < fg.nb_bnd ? (int)blockIdx.x : -1);
     if (bidx >= 0) {
-        acc = el_boundary_role(a, w.faces, fg, bidx, sTab, sMask);
+        acc = el_boundary_role(a, w.faces, fg, bidx, sTab, sMask, &acc2);
     } else {
         // ---- interior nodes: z-marching ------------------------------------------------------------------------
         const int lane = threadIdx.x & 63;
@@ -471,8 +489,9 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
         // [x*G/8, (x+1)*G/8) of tiles: y-neighbouring columns, whose halo rows overlap, then meet in one L2 (speed only)
         int bm = fg.bnd_last ? (int)blockIdx.x : (int)blockIdx.x - fg.nb_bnd;
         if ((fg.nb_fast & 7) == 0) bm = (bm & 7) * (fg.nb_fast >> 3) + (bm >> 3);
-        if (w.faces) {                                        // every wave of the workgroup passes here
-            if (threadIdx.x < 27) sTab[3200 + threadIdx.x] = fg.gf[threadIdx.x];
+        if (w.faces || qmq) {                                 // every wave of the workgroup passes here
+            if (w.faces && threadIdx.x < 27) sTab[3200 + threadIdx.x] = fg.gf[threadIdx.x];
+            if (qmq && threadIdx.x < 81) sTab[3240 + threadIdx.x] = a.dinv[threadIdx.x];      // Jacobi diagonals of the 27 boundary classes
             __syncthreads();
         }
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and known to the compiler as such:
@@ -507,6 +526,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             const bool wave_has_face = (w.faces & 1) && (xt == 0 || (xt + 1) * kElXt >= g.NX - 1);      // wave-uniform
             const double kup = face_hi ? 0.0 : 1.0, klo = face_lo ? 0.0 : 1.0;      // no coupling across the face (the lanes beyond hold finite pad values)
             const bool out_x = (lane >= 1 && lane <= kElXt && i <= g.NX - ((w.faces & 1) ? 1 : 2)) || face_lo;
+            const int cls_x = i == 0 ? 0 : (i == g.NX - 1 ? 2 : 1);      // boundary class of the lane's column along x
             const int rows_out = ghost_wave ? 0 : min(RY, g.NY - 1 - j0);      // owned rows inside the grid (wave-uniform)
             // lanes beyond the padded row (the last 62-node tile overshoots: 558 columns for a 513-node row) read the row's last pad
             // entry instead of the next row's data: same cache line as real data, no traffic of their own (9 % of the loads at
@@ -579,7 +599,15 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             // (the chunk that starts at local plane 1 of a slab owning the global plane 0 / that ends below the global plane NZ-1)
             const bool zlo_chunk = zf && fg.full_lo && lk0 == 1, zhi_chunk = zf && fg.full_hi && lk1 == g.nkl - 1;
             const bool out_f = lane >= 1 && lane <= kElXt && i >= 1 && i <= g.NX - 2;      // face nodes proper (the x-ends are edges of the box)
-            auto face_finish = [&](long long o, const double* c0, double* y, const double* U, const double* Lw) __attribute__((always_inline)) {
+            // D^-1 of one boundary class from LDS (read where it is used: hoisted out of the z-loop the values would cost registers the
+            // marching loop does not have)
+            auto dinv_of = [&](int cls) __attribute__((always_inline)) {
+                int off = 3240 + 3 * cls;
+                asm volatile("" : "+v"(off));
+                return sTab + off;
+            };
+            // cls_face: boundary class of the face nodes this call finishes (x interior: 1 + 3 cy + 9 cz)
+            auto face_finish = [&](long long o, const double* c0, double* y, const double* U, const double* Lw, int cls_face) __attribute__((always_inline)) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) y[c] += el_dpp_upper(U[c]) + el_dpp_lower(Lw[c]);
                 if (out_f) {
@@ -587,6 +615,11 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                     for (int c = 0; c < 3; ++c) {
                         a.out[c * a.stride + o] = y[c];
                         acc += c0[c] * y[c];
+                    }
+                    if (qmq) {
+                        const double* dv = dinv_of(cls_face);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc2 += dv[c] * y[c] * y[c];
                     }
                 }
             };
@@ -598,7 +631,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                 for (int r = 1; r <= RY; ++r) {
                     double y[3], U[3], Lw[3];
                     el_face_node<2, false>(w, face_g(2), P0[r], P0[r + 1], P0[r - 1], Pin[r], Pin[r + 1], y, U, Lw);
-                    if (r <= rows_out) face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw);
+                    if (r <= rows_out) face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw, 1 + 3 + 0);
                 }
             };
             auto zface_hi = [&](int lk, double (*P0)[3], double (*Pin)[3]) __attribute__((always_inline)) {
@@ -607,7 +640,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                 for (int r = 1; r <= RY; ++r) {
                     double y[3], U[3], Lw[3];
                     el_face_node<2, true>(w, face_g(2), P0[r], P0[r + 1], P0[r - 1], Pin[r], Pin[r - 1], y, U, Lw);
-                    if (r <= rows_out) face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw);
+                    if (r <= rows_out) face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw, 1 + 3 + 18);
                 }
             };
             auto step = [&](int lk, double (*Pm)[3], double (*P0)[3], double (*Pp)[3], double (*Pn)[3]) __attribute__((always_inline)) {
@@ -683,13 +716,18 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                             else *dst = y[c];
                             acc += P0[r][c] * y[c];
                         }
+                        if (qmq) {                            // rows and planes interior: the class is that of the lane's x-position
+                            const double* dv = dinv_of(cls_x + 3 + 9);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) acc2 += dv[c] * y[c] * y[c];
+                        }
                     }
                 }
                 // y-face rows of this plane (wave-uniform branches): row 0 by the first row tile, row NY-1 by the last one
                 if (ylo_wave) {
                     double y[3], U[3], Lw[3];
                     el_face_node<1, false>(w, face_g(1), P0[0], Pp[0], Pm[0], P0[1], Pp[1], y, U, Lw);
-                    face_finish(obase, P0[0], y, U, Lw);
+                    face_finish(obase, P0[0], y, U, Lw, 1 + 0 + 9);
                 }
                 if (r_hi > 0) {
 #pragma unroll
@@ -697,7 +735,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                         if (r == r_hi) {
                             double y[3], U[3], Lw[3];
                             el_face_node<1, true>(w, face_g(1), P0[r], Pp[r], Pm[r], P0[r - 1], Pm[r - 1], y, U, Lw);
-                            face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw);
+                            face_finish(obase + (long long)r * g.PX, P0[r], y, U, Lw, 1 + 6 + 9);
                         }
                 }
             };
@@ -729,6 +767,10 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
     }
     const double tot = block_sum_256(acc, sRed);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+    if (qmq) {
+        const double t2 = block_sum_256(acc2, sRed);
+        if (threadIdx.x == 0) a.partials_qmq[blockIdx.x] = t2;
+    }
 }
 
 // 16-byte accesses of the flat PCG kernels; NT = non-temporal (compile-time: HBM-resident grids only — on config 5 each kernel reads what the
@@ -903,6 +945,144 @@ __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, l
                 el_st2<NT>(a.x + c * a.stride + idx, xv);
             }
         }
+    }
+}
+
+// Single-reduction PCG, the fused update pass (K2 + p-update in one sweep):
+//   alpha = r.z / p.Ap,  beta = (alpha^2 (Ap . D^-1 Ap) - r.z) / r.z   from the block of the iteration before ({p.Ap, r.z, r.r, Ap.D^-1 Ap}: read from the
+//   scalars, or — single-slab loops — summed here from the partials of the apply (din3 / din4) and of the previous update pass (din / din2));
+//   r -= alpha q;  z = D^-1 r;  x += alpha p_old;  p_new = z + beta p_old;  partials of r.z and r.r.
+// The recurrence |r_new|_D^2 = alpha^2 |Ap|_D^2 - r.z (exact arithmetic: q.z = p.Ap) predicts the next r.z for beta only; the true r.z summed here joins
+// the next block and forms the next alpha.  7 vector passes (read r, q, p_old, x; write r, p_new, x) where K2 + p-update make 8, one launch less, and
+// ONE scalar reduction per iteration.  ghost != 0: only p_new = D^-1 r + beta p_old on up to two index ranges (the ghost planes of a slab, whose r has
+// just arrived from the neighbour), no sums.
+template <int D, bool NT>
+__global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __restrict__ q, double* __restrict__ r, int ghost, long long first,
+                                                    long long total, long long first2, long long total2, int nb1) {
+    __shared__ double sRed4[16];
+    __shared__ double sDinv[27 * 3];
+    if (threadIdx.x < 81) sDinv[threadIdx.x] = a.dinv[threadIdx.x];
+    __syncthreads();
+    double pq, qmq, rz;
+    if (a.din) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;       // all loads issued before the first barrier
+        for (int e = threadIdx.x; e < a.din_n; e += 256) {
+            s1 += a.din[e];
+            s2 += a.din2[e];
+        }
+        for (int e = threadIdx.x; e < a.din_n2; e += 256) {
+            s3 += a.din3[e];
+            s4 += a.din4[e];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        s3 = wave_sum(s3);
+        s4 = wave_sum(s4);
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            sRed4[w] = s1;
+            sRed4[4 + w] = s2;
+            sRed4[8 + w] = s3;
+            sRed4[12 + w] = s4;
+        }
+        __syncthreads();
+        rz = (sRed4[0] + sRed4[1]) + (sRed4[2] + sRed4[3]);
+        const double rr = (sRed4[4] + sRed4[5]) + (sRed4[6] + sRed4[7]);
+        pq = (sRed4[8] + sRed4[9]) + (sRed4[10] + sRed4[11]);
+        qmq = (sRed4[12] + sRed4[13]) + (sRed4[14] + sRed4[15]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {            // for the host's polls; no workgroup of this launch reads the scalars
+            double* sc = const_cast<double*>(a.scal);
+            sc[ESC_PQ] = pq;
+            sc[ESC_RZ] = rz;
+            sc[ESC_RR] = rr;
+            sc[ESC_QMQ] = qmq;
+        }
+    } else {
+        pq = a.scal[ESC_PQ];
+        rz = a.scal[ESC_RZ];
+        qmq = a.scal[ESC_QMQ];
+    }
+    const double alpha = (pq > 0.0 && rz > 0.0) ? rz / pq : 0.0;                  // 0 on the first iteration (p.Ap = 0)
+    const double rz_next = alpha * alpha * qmq - rz;
+    const double beta = (alpha > 0.0 && rz_next > 0.0) ? rz_next / rz : 0.0;      // a lost prediction restarts with the preconditioned residual
+    const GridDev& g = a.g;
+    const bool second = (int)blockIdx.x >= nb1;               // workgroup-uniform
+    if (second) {
+        first = first2;
+        total = total2;
+    }
+    const int bid = second ? (int)blockIdx.x - nb1 : (int)blockIdx.x, nbl = second ? (int)gridDim.x - nb1 : nb1;
+    const long long pairs = total / 2;
+    const int PX2 = g.PX / 2;
+    const long long step = (long long)nbl * 256;
+    const int di = (int)(step % PX2);
+    const long long drow = step / PX2;
+    const int dj = (int)(drow % g.NY), dk = (int)(drow / g.NY);
+    long long e = (long long)bid * 256 + threadIdx.x;
+    int i2 = (int)(e % PX2), j = (int)((e / PX2) % g.NY), lk = (int)((e / PX2) / g.NY) + (int)(first / g.PP);
+    double acc_rz = 0.0, acc_rr = 0.0;
+    for (; e < pairs; e += step) {
+        const long long idx = first + 2 * e;
+        const int kg = g.k0 + lk;
+        const int i = 2 * i2;
+        const int cyz = 3 * (g.dim >= 2 ? pg_axis_class(j, g.NY) : 1) + 9 * (g.dim >= 3 ? pg_axis_class(kg, g.NZ) : 1);
+        const int cls0 = pg_axis_class(i < g.NX ? i : 1, g.NX) + cyz;
+        const int cls1 = pg_axis_class(i + 1 < g.NX ? i + 1 : 1, g.NX) + cyz;
+        i2 += di;
+        j += dj;
+        lk += dk;
+        if (i2 >= PX2) { i2 -= PX2; ++j; }
+        if (j >= g.NY) { j -= g.NY; ++lk; }
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double2 po = el_ld2<NT>(a.p_old + c * a.stride + idx);
+            double2 rv = el_ld2<NT>(r + c * a.stride + idx);
+            if (!ghost && alpha != 0.0) {
+                const double2 qv = el_ld2<NT>(q + c * a.stride + idx);
+                rv.x -= alpha * qv.x;
+                rv.y -= alpha * qv.y;
+                el_st2<NT>(r + c * a.stride + idx, rv);
+                double2 xv = el_ld2<NT>(a.x + c * a.stride + idx);
+                xv.x += alpha * po.x;
+                xv.y += alpha * po.y;
+                el_st2<NT>(a.x + c * a.stride + idx, xv);
+            }
+            const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv.x, sDinv[cls1 * 3 + c] * rv.y);
+            acc_rz += rv.x * zv.x + rv.y * zv.y;
+            acc_rr += rv.x * rv.x + rv.y * rv.y;
+            // (p_n is read by the block apply that follows: a plain store even with NT)
+            *reinterpret_cast<double2*>(a.p_new + c * a.stride + idx) = make_double2(zv.x + beta * po.x, zv.y + beta * po.y);
+        }
+    }
+    if (!ghost) {
+        const double t1 = block_sum_256(acc_rz, sRed4);
+        const double t2 = block_sum_256(acc_rr, sRed4);
+        if (threadIdx.x == 0) {
+            a.partials[blockIdx.x] = t1;
+            a.partials2[blockIdx.x] = t2;
+        }
+    }
+}
+
+// single-reduction PCG: the block {p.Ap, r.z, r.r, Ap.D^-1 Ap} from the apply's partials (nA each) and the update pass's (nU each), one launch
+__global__ __launch_bounds__(256) void k_el_reduce4(const double* __restrict__ pq, const double* __restrict__ qmq, int nA, const double* __restrict__ rz,
+                                                     const double* __restrict__ rr, int nU, double* __restrict__ scal) {
+    __shared__ double sRed[4];
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    for (int e = threadIdx.x; e < nA; e += 256) {
+        a1 += pq[e];
+        a2 += qmq[e];
+    }
+    for (int e = threadIdx.x; e < nU; e += 256) {
+        a3 += rz[e];
+        a4 += rr[e];
+    }
+    const double t1 = block_sum_256(a1, sRed), t2 = block_sum_256(a2, sRed), t3 = block_sum_256(a3, sRed), t4 = block_sum_256(a4, sRed);
+    if (threadIdx.x == 0) {
+        scal[ESC_PQ] = t1;
+        scal[ESC_QMQ] = t2;
+        scal[ESC_RZ] = t3;
+        scal[ESC_RR] = t4;
     }
 }
 
@@ -1157,6 +1337,12 @@ struct ElSession {
     int last_apply_blocks = 1;      // workgroups (= partials) of the most recent apply launch
     int k1_parts = 0;               // workgroups (partials) of the parts of a split K1 so far
     size_t npart3 = 0;              // doubles in part3
+    // single-reduction PCG (variant 1): part4 = the apply's Ap.D^-1 Ap partials; the update pass writes its r.z / r.r partials alternately to
+    // (part, part2) and (partB, partB2) — in a single-slab loop its own prologue still reads the previous pair
+    int variant = 0;
+    double *part4 = nullptr, *partB = nullptr, *partB2 = nullptr;
+    int ucur = 0;                   // which pair the NEXT update pass writes
+    bool sr_mem = true;             // the next update pass reads the block from the scalars (first pass of a solve / of a chunk; slab loop: always)
 
     double* alloc_vec() {
         double* base = nullptr;
@@ -1174,6 +1360,9 @@ struct ElSession {
         if (part) (void)hipFree(part);
         if (part2) (void)hipFree(part2);
         if (part3) (void)hipFree(part3);
+        if (part4) (void)hipFree(part4);
+        if (partB) (void)hipFree(partB);
+        if (partB2) (void)hipFree(partB2);
         if (d_mask) (void)hipFree(d_mask);
         if (h_pin) (void)hipHostFree(h_pin);
         tables_free(&ht);
@@ -1552,6 +1741,119 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr, int part = -1) {
     PG_HIP(s->ctx, hipGetLastError());
     return PDEGPU_OK;
 }
+// ---- single-reduction PCG (variant 1) ---------------------------------------------------------------------------------------------------
+// update pass over the owned planes; lazy: sum the previous block from partials in the prologue (single-slab loops) unless the block has just
+// been reduced into the scalars (sr_mem)
+int el_sr_update(ElSession* s, bool lazy) {
+    const GridDev& g = s->g;
+    ElArgs a = s->args();
+    a.p_old = s->p[s->pcur];
+    a.p_new = s->p[1 - s->pcur];
+    a.x = s->x;
+    a.partials = s->ucur ? s->partB : s->part;
+    a.partials2 = s->ucur ? s->partB2 : s->part2;
+    if (lazy && !s->sr_mem) {
+        a.din = s->ucur ? s->part : s->partB;
+        a.din2 = s->ucur ? s->part2 : s->partB2;
+        a.din_n = s->nblk;
+        a.din3 = s->part3;
+        a.din4 = s->part4;
+        a.din_n2 = s->last_apply_blocks;
+    }
+    const long long total = (long long)g.nkl * g.PP;
+    if (s->D == 3) {
+        if (el_vec_nt(s)) hipLaunchKernelGGL((k_el_update<3, true>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk);
+        else hipLaunchKernelGGL((k_el_update<3, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk);
+    } else {
+        hipLaunchKernelGGL((k_el_update<2, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk);
+    }
+    PG_HIP(s->ctx, hipGetLastError());
+    s->ucur ^= 1;
+    s->sr_mem = false;
+    return PDEGPU_OK;
+}
+// p_new = D^-1 r + beta p_old on the ghost planes (r has arrived from the neighbours; the same beta: the scalars still hold the block the update pass used)
+int el_sr_ghost_update(ElSession* s) {
+    const GridDev& g = s->g;
+    const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;
+    if (!lo && !hi) return PDEGPU_OK;
+    ElArgs a = s->args();
+    a.p_old = s->p[s->pcur];
+    a.p_new = s->p[1 - s->pcur];
+    a.x = s->x;
+    const long long lo_first = -(long long)g.PP, hi_first = (long long)g.nkl * g.PP;
+    const long long f1 = lo ? lo_first : hi_first, f2 = (lo && hi) ? hi_first : 0, t2 = (lo && hi) ? (long long)g.PP : 0;
+    const int nbp = (int)std::max<long long>(1, std::min<long long>(s->nblk, ((long long)g.PP / 2 + 255) / 256));
+    const int nb1 = nbp, nb = t2 > 0 ? 2 * nbp : nbp;
+    if (s->D == 3) hipLaunchKernelGGL((k_el_update<3, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 1, f1, (long long)g.PP, f2, t2, nb1);
+    else hipLaunchKernelGGL((k_el_update<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 1, f1, (long long)g.PP, f2, t2, nb1);
+    PG_HIP(s->ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+// the block {p.Ap, r.z, r.r, Ap.D^-1 Ap} -> scalars (this slab's sums; the multi-GPU host all-reduces scalars[0..3], 32 bytes)
+int el_sr_reduce(ElSession* s, int n_apply) {
+    const double* urz = s->ucur ? s->part : s->partB;        // the pair the LAST update pass wrote (ucur has been flipped since)
+    const double* urr = s->ucur ? s->part2 : s->partB2;
+    hipLaunchKernelGGL(k_el_reduce4, dim3(1), dim3(256), 0, s->ctx->stream, s->part3, s->part4, n_apply, urz, urr, s->nblk, s->scal);
+    PG_HIP(s->ctx, hipGetLastError());
+    s->sr_mem = true;
+    return PDEGPU_OK;
+}
+// One iteration = update pass + apply.  part: -1 whole (slabs without neighbours; lazy: no reduce launch), 0 = the update pass of the owned planes
+// (the host then posts the exchange of r), 1 = the apply on the planes away from the ghosts (overlaps the exchange), 2 = the ghost planes'
+// p-update, the remaining apply and the block reduce.
+int el_sr_k1(ElSession* s, bool lazy, int part) {
+    const GridDev& g = s->g;
+    const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;
+    ElArgs b = s->args();
+    b.out = s->q;
+    b.partials_qmq = s->part4;
+    if (part < 0) {
+        if (lo || hi) return pdegpu_set_err(s->ctx, PDEGPU_EINVAL, "single-reduction PCG on a slab with neighbours: the residual update is part of k1, "
+                                                                    "so r travels INSIDE it — call k1_pre, exchange r, then k1_part(0) and k1_part(1)");
+        PG_TRY(el_sr_update(s, lazy));
+        s->pcur ^= 1;
+        b.in = s->p[s->pcur];
+        b.partials = s->part3;
+        PG_TRY(el_apply(s, b, APPLY_PLAIN));
+        if (lazy) return PDEGPU_OK;
+        return el_sr_reduce(s, s->last_apply_blocks);
+    }
+    if (part == 0) return el_sr_update(s, false);
+    const bool split = el_k1_splittable(s);
+    if (part == 1) {
+        s->k1_parts = 0;
+        if (!split) return PDEGPU_OK;
+        ElFastGeom fgr;
+        el_fast_geometry_range(s, lo, g.nkl - hi, 0, 0, &fgr);
+        b.in = s->p[1 - s->pcur];
+        b.partials = s->part3;
+        PG_TRY(el_apply(s, b, APPLY_PLAIN, &fgr));
+        s->k1_parts = s->last_apply_blocks;
+        return PDEGPU_OK;
+    }
+    PG_TRY(el_sr_ghost_update(s));
+    s->pcur ^= 1;
+    b.in = s->p[s->pcur];
+    if (split) {
+        ElFastGeom fgr;
+        if (lo && hi) el_fast_geometry_range(s, 0, 1, g.nkl - 1, g.nkl, &fgr);
+        else if (lo) el_fast_geometry_range(s, 0, 1, 0, 0, &fgr);
+        else el_fast_geometry_range(s, g.nkl - 1, g.nkl, 0, 0, &fgr);
+        if ((size_t)s->k1_parts + fgr.nb_fast + fgr.nb_bnd > s->npart3)
+            return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "split K1: partials of the session exceeded");
+        b.partials = s->part3 + s->k1_parts;
+        b.partials_qmq = s->part4 + s->k1_parts;
+        PG_TRY(el_apply(s, b, APPLY_PLAIN, &fgr));
+        s->k1_parts += s->last_apply_blocks;
+    } else {
+        b.partials = s->part3;
+        PG_TRY(el_apply(s, b, APPLY_PLAIN));
+        s->k1_parts = s->last_apply_blocks;
+    }
+    return el_sr_reduce(s, s->k1_parts);
+}
+
 int el_scalars(ElSession* s, double* out8) {
     PG_HIP(s->ctx, hipMemcpyAsync(s->h_pin, s->scal, ESC_COUNT * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
     PG_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
@@ -1632,6 +1934,10 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     PG_HIP(ctx, hipMalloc(&s->part, npart * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->part2, npart * sizeof(double)));
     PG_HIP(ctx, hipMalloc(&s->part3, npart * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&s->part4, npart * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&s->partB, npart * sizeof(double)));
+    PG_HIP(ctx, hipMalloc(&s->partB2, npart * sizeof(double)));
+    s->variant = ctx->el_cg_variant != 0 ? 1 : 0;
     PG_TRY(tables_build(ctx, grid, &s->ht));
     double** vecs[] = {&s->x, &s->r, &s->p[0], &s->p[1], &s->q, &s->b};
     for (double** v : vecs) {
@@ -1649,6 +1955,8 @@ int el_begin(ElSession* s, const pdegpu_elasticity* el) {
         PG_HIP(ctx, hipMemsetAsync(v - vec_front(s->g), 0, bytes, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(s->scal, 0, ESC_COUNT * sizeof(double), ctx->stream));
     s->pcur = 0;
+    s->ucur = 0;
+    s->sr_mem = true;
     hipLaunchKernelGGL(k_el_load, dim3(s->nblk), dim3(256), 0, ctx->stream, s->g, s->stride, s->D, s->ht.d_load, el->body[0], el->body[1],
                        s->D == 3 ? el->body[2] : 0.0, s->b);
     PG_HIP(ctx, hipGetLastError());
@@ -1807,20 +2115,28 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     PG_HIP(ctx, hipEventRecord(cgt.a, ctx->stream));
     while (rr > target && it < max_iter && std::isfinite(rr)) {
         const int n = std::min(chunk, max_iter - it);
-        ElLazy lazy;
-        ElLazy* lz = ctx->lazy_dot ? &lazy : nullptr;
-        for (int i = 0; i < n; ++i) {
-            PG_TRY(el_k1(&s, lz));
-            PG_TRY(el_k2(&s, 1, lz));
+        if (s.variant) {
+            // single-reduction PCG: update pass (K2 and p-update fused) + block apply; with lazy_dot the update pass sums the previous block in its
+            // prologue and one reduce launch closes the chunk for the poll
+            const bool lz = ctx->lazy_dot != 0;
+            for (int i = 0; i < n; ++i) PG_TRY(el_sr_k1(&s, lz, -1));
+            if (lz) PG_TRY(el_sr_reduce(&s, s.last_apply_blocks));
+        } else {
+            ElLazy lazy;
+            ElLazy* lz = ctx->lazy_dot ? &lazy : nullptr;
+            for (int i = 0; i < n; ++i) {
+                PG_TRY(el_k1(&s, lz));
+                PG_TRY(el_k2(&s, 1, lz));
+            }
+            if (lz) PG_TRY(el_lazy_finish(&s, lz));
         }
-        if (lz) PG_TRY(el_lazy_finish(&s, lz));
         it += n;
         const double rr_before = rr;
         PG_TRY(el_scalars(&s, sc));
         rr = sc[ESC_RR];
         chunk = next_poll_chunk(rr_before, rr, target, n, chunk, 256);
     }
-    PG_TRY(el_flush(&s));
+    if (!s.variant) PG_TRY(el_flush(&s));      // (single-reduction form: x is the iterate whose residual the last poll read; nothing is pending)
     PG_HIP(ctx, hipEventRecord(cgt.b, ctx->stream));
     const float cms = cgt.elapsed();
     st.cg_iterations = it;
@@ -2010,14 +2326,38 @@ extern "C" void pdegpu_el_session_destroy(pdegpu_el_session* h) {
 }
 
 extern "C" int pdegpu_el_session_begin(pdegpu_el_session* h) { return h ? el_begin(&h->s, &h->el) : PDEGPU_EINVAL; }
-extern "C" int pdegpu_el_session_k1(pdegpu_el_session* h) { return h ? el_k1(&h->s) : PDEGPU_EINVAL; }
+extern "C" int pdegpu_el_session_k1(pdegpu_el_session* h) {
+    if (!h) return PDEGPU_EINVAL;
+    return h->s.variant ? el_sr_k1(&h->s, false, -1) : el_k1(&h->s);
+}
 extern "C" int pdegpu_el_session_can_split_k1(const pdegpu_el_session* h) { return (h && el_k1_splittable(&h->s)) ? 1 : 0; }
 extern "C" int pdegpu_el_session_k1_part(pdegpu_el_session* h, int part) {
     if (!h || (part != 0 && part != 1)) return PDEGPU_EINVAL;
-    return el_k1(&h->s, nullptr, part);
+    return h->s.variant ? el_sr_k1(&h->s, false, part + 1) : el_k1(&h->s, nullptr, part);
 }
-extern "C" int pdegpu_el_session_k2(pdegpu_el_session* h) { return h ? el_k2(&h->s, 1) : PDEGPU_EINVAL; }
-extern "C" int pdegpu_el_session_flush(pdegpu_el_session* h) { return h ? el_flush(&h->s) : PDEGPU_EINVAL; }
+// 0 = classic Jacobi-PCG (scalars[0] after k1, scalars[1..2] after k2); 1 = single-reduction form: the residual update moves INTO k1 (fused with
+// the p-update), k2 does nothing, and after k1 / k1_part(1) the block scalars[0..3] = {p.Ap, r.z, r.r, Ap.D^-1 Ap} is the ONE message of the
+// iteration.  On a slab with neighbours r changes inside k1, so the protocol becomes: k1_pre (update pass of the owned planes) -> exchange the
+// first / last owned plane of r -> k1_part(0) (apply away from the ghosts; may run while the planes travel) -> k1_part(1).  Choose before begin().
+extern "C" int pdegpu_el_session_set_cg_variant(pdegpu_el_session* h, int variant) {
+    if (!h || (variant != 0 && variant != 1)) return PDEGPU_EINVAL;
+    h->s.variant = variant;
+    h->s.sr_mem = true;
+    return PDEGPU_OK;
+}
+extern "C" int pdegpu_el_session_cg_variant(const pdegpu_el_session* h) { return h ? h->s.variant : -1; }
+extern "C" int pdegpu_el_session_k1_pre(pdegpu_el_session* h) {
+    if (!h) return PDEGPU_EINVAL;
+    return h->s.variant ? el_sr_k1(&h->s, false, 0) : PDEGPU_OK;
+}
+extern "C" int pdegpu_el_session_k2(pdegpu_el_session* h) {
+    if (!h) return PDEGPU_EINVAL;
+    return h->s.variant ? PDEGPU_OK : el_k2(&h->s, 1);
+}
+extern "C" int pdegpu_el_session_flush(pdegpu_el_session* h) {
+    if (!h) return PDEGPU_EINVAL;
+    return h->s.variant ? PDEGPU_OK : el_flush(&h->s);      // (single-reduction form: nothing is pending, x matches the r that r.r reports)
+}
 extern "C" double* pdegpu_el_session_scalars(pdegpu_el_session* h) { return h ? h->s.scal : nullptr; }
 extern "C" int64_t pdegpu_el_session_plane_doubles(const pdegpu_el_session* h) { return h ? (int64_t)h->s.g.PP : -1; }
 

@@ -104,6 +104,9 @@ SYMBOLS = {
     "pdegpu_el_session_get_u": (C.c_int, [_vp, _dp]),
     "pdegpu_el_session_can_split_k1": (C.c_int, [_vp]),
     "pdegpu_el_session_k1_part": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_el_session_set_cg_variant": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_el_session_cg_variant": (C.c_int, [_vp]),
+    "pdegpu_el_session_k1_pre": (C.c_int, [_vp]),
     "pdegpu_elasticity_postprocess": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Elasticity), _dp, _dp]),
     "pdegpu_session_create": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "pdegpu_session_destroy": (None, [_vp]),

@@ -56,6 +56,7 @@ def slab_range(n_planes: int, world: int, rank: int):
 class GpuSlabEngine:
     """pdegpu_session on one GPU; device memory stays owned by the library, torch only sees plane views."""
     supports_sr = True
+    sr_rr_lags = True        # single-reduction form: the r.r of the last K2 sits in its partials until the next message (polls: sr_poll)
 
     def __init__(self, grid, heat, k0: int, nk: int, device: int, stream: Optional[torch.cuda.Stream] = None):
         self.lib = L.load_library()
@@ -185,6 +186,8 @@ class GpuSlabEngine:
 
 class GpuElasticitySlabEngine:
     """pdegpu_el_session on one GPU (3-D elasticity, Jacobi-PCG): the same driver protocol as the heat engine."""
+    supports_sr = True
+    sr_rr_lags = False       # single-reduction PCG: the residual update is part of k1, scalars[2] is the r.r of the current residual
 
     def __init__(self, grid, el, k0: int, nk: int, device: int, stream: Optional[torch.cuda.Stream] = None):
         self.lib = L.load_library()
@@ -213,6 +216,15 @@ class GpuElasticitySlabEngine:
 
     def begin(self, x_fill: float = 0.0):
         self._ck(self.lib.pdegpu_el_session_begin(self.s))
+
+    def set_variant(self, sr: bool):
+        """single-reduction PCG (r- and p-update fused into k1, ONE 32-byte message per iteration) or the classic recurrences; before begin()"""
+        self._ck(self.lib.pdegpu_el_session_set_cg_variant(self.s, 1 if sr else 0))
+        self.sr = bool(sr)
+
+    def k1_pre(self):
+        """single-reduction form: the update pass of the owned planes (r changes here: its halo exchange follows); classic form: nothing"""
+        self._ck(self.lib.pdegpu_el_session_k1_pre(self.s))
 
     def residual(self):
         pass                                            # begin() already formed r = P b, z and the local sums (x = 0)
@@ -254,6 +266,8 @@ class GpuElasticitySlabEngine:
         return bool(self.lib.pdegpu_el_session_can_split_k1(self.s))
 
     def global_slots(self, which: int):
+        if which == 0 and getattr(self, "sr", False):
+            return (0, 4)                                # {p.Ap, r.z, r.r, Ap.D^-1 Ap}: the one message of an iteration
         return (0, 1) if which == 0 else (1, 3)          # p.q | r.z and r.r as one 16-byte message
 
     def scalars_host(self):
@@ -390,8 +404,16 @@ class SlabCG:
         # K1 needs r_n (z_n) and p_{n-1} on the ghost planes; engines whose K1 maintains p there itself only exchange r.
         # Engines that can split K1 run its bulk while the planes travel.
         split = self.overlap and hasattr(self.e, "k1_part")
+        # engines whose single-reduction form updates r INSIDE k1 (elasticity PCG): k1_pre, then the exchange, then the two parts
+        pre = getattr(self.e, "k1_pre", None) if self.sr else None
         for _ in range(iters):
-            if split:
+            if pre is not None:
+                pre()
+                token = self.exchange_begin()
+                self.e.k1_part(0)
+                self.exchange_end(token)
+                self.e.k1_part(1)
+            elif split:
                 token = self.exchange_begin()
                 self.e.k1_part(0)
                 self.exchange_end(token)
@@ -408,7 +430,7 @@ class SlabCG:
     def rr(self) -> float:
         """global r.r of the current residual (host value: synchronises).  Single-reduction form: the r.r of the last K2 is summed and
         all-reduced here, for the poll only."""
-        if self.sr:
+        if self.sr and getattr(self.e, "sr_rr_lags", True):
             self.e.sr_poll()
             self.allreduce(1, slots=(SC_RR_POLL, SC_RR_POLL + 1))
         return self.e.rr()

@@ -142,11 +142,13 @@ def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
 
 @pytest.mark.parametrize("nslabs", [1, 2, 3])
 @pytest.mark.parametrize("split", [False, True])
-def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split):
+@pytest.mark.parametrize("sr", [True, False])
+def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split, sr):
     """the multi-GPU elasticity path on ONE GPU: slab sessions (ghost planes, global boundary classes), halo exchange of r (3 component
     planes; p on the ghost planes is maintained by k1) and the scalar all-reduces done by device copies in the order pdegpu.dist.SlabCG
     uses — split: k1 in two parts with the exchange in between (the overlapped order), the ghost planes of r poisoned while part 0 runs;
-    then von Mises + project() from the gathered displacement.  Must reproduce the oracle."""
+    then von Mises + project() from the gathered displacement.  Must reproduce the oracle.  sr: the single-reduction PCG — the residual update is
+    part of k1 (k1_pre -> exchange of r -> k1_part 0 / 1), k2 does nothing, ONE block {p.Ap, r.z, r.r, Ap.D^-1 Ap} is summed over the slabs."""
     import torch
     from pdegpu import _lib
     from pdegpu.dist import GpuElasticitySlabEngine, slab_range
@@ -161,7 +163,8 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split):
     with torch.cuda.stream(stream):
         engs = [GpuElasticitySlabEngine(grid, el, *slab_range(n[2] + 1, nslabs, r), 0, stream) for r in range(nslabs)]
         for e in engs:                      # (the default splits only slabs whose vectors hold >= 32 MiB: small slabs lose more on the two extra launches)
-            _lib.check(e.ctx, lib.pdegpu_set_tunable(e.ctx, b"el_split_min_mb", 0))
+            _lib.check(e.ctx, lib.pdegpu_set_tunable(e.ctx, b"el_split_min_mb", 0 if split else 1 << 20))
+            e.set_variant(sr)
 
         def exchange():
             for r in range(nslabs - 1):
@@ -184,9 +187,10 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split):
         it = 0
         while it < 6000:
             for _ in range(50):
-                if split:
-                    assert all(e.can_split_k1() == (nslabs > 1) for e in engs)
-                    for e in engs:                        # the receives have not landed yet: part 0 must not read a ghost plane of r
+                assert all(e.can_split_k1() == (split and nslabs > 1) for e in engs)
+                if sr or split:
+                    for e in engs:                        # the receives have not landed yet: nothing before the exchange may read a ghost plane of r
+                        e.k1_pre()                        # (sr: the update pass of the owned planes — r changes here; classic: nothing)
                         for w in ((-1,) if e.k0 > 0 else ()) + ((e.nk,) if e.k0 + e.nk < n[2] + 1 else ()):
                             for t in e.halo_tensors(w):
                                 t.fill_(float("nan"))
@@ -200,8 +204,9 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split):
                         e.k1()
                 allreduce(0)
                 for e in engs:
-                    e.k2()
-                allreduce(1)
+                    e.k2()                                # (sr: a no-op)
+                if not sr:
+                    allreduce(1)
             it += 50
             if engs[0].rr() <= 1e-24 * rr0:
                 break
@@ -262,12 +267,13 @@ def test_row_and_kernel_variants_agree(lib, gpu_ctx):
         for cfg in (dict(el_fast=1, el_fast_ry=2, el_fast_yx=1), dict(el_fast=1, el_fast_ry=1, el_fast_yx=1), dict(el_fast=1, el_fast_ry=2, el_fast_yx=0),
                     dict(el_fast=0), dict(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=0), dict(el_grid_mult=1), dict(el_grid_mult=16, el_fast_waves=300),
                     dict(el_fast_ry=4, el_fast_yx=1), dict(el_fast_ry=4, el_fast_yx=0), dict(el_fast_xface=0), dict(el_fast_xface=0, el_fast_ry=1),
-                    dict(el_fast_nt=1), dict(el_fast_nt=1, el_fast_ry=1), dict(el_fast_yzface=1), dict(el_fast_yzface=0, el_fast_nt=0)):
+                    dict(el_fast_nt=1), dict(el_fast_nt=1, el_fast_ry=1), dict(el_fast_yzface=1), dict(el_fast_yzface=0, el_fast_nt=0),
+                    dict(el_cg_variant=0), dict(el_cg_variant=0, lazy_dot=0), dict(el_cg_variant=0, el_fast=0)):
             tun(**cfg)
             outs.append(elasticity._solve_elasticity_3d_static(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress",
                                                                rtol=1e-12))
     finally:
-        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=0, el_fast_xface=1, el_fast_nt=-1, el_fast_yzface=3)
+        tun(el_fast=1, el_fast_ry=2, el_fast_yx=1, lazy_dot=1, el_grid_mult=4, el_fast_waves=0, el_fast_xface=1, el_fast_nt=-1, el_fast_yzface=3, el_cg_variant=1)
     ref = o.solve_elasticity_3d(1.0, 0.3, 0.2, 70, 6, 5, 210e9, 0.3, 1.0e3, 0.0, -7.0e4, "stress")
     for f in outs:
         assert rel_err(f.values, ref.values) < TOL
