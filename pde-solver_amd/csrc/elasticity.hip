@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             const double kup = face_hi ? 0.0 : 1.0, klo = face_lo ? 0.0 : 1.0;      // no coupling across the face (the lanes beyond hold finite pad values)
             const bool out_x = (lane >= 1 && lane <= kElXt && i <= g.NX - ((w.faces & 1) ? 1 : 2)) || face_lo;
             const int cls_x = i == 0 ? 0 : (i == g.NX - 1 ? 2 : 1);      // boundary class of the lane's column along x
+            double S2[3] = {0.0, 0.0, 0.0};                              // sum of y_c^2 over the lane's interior-row outputs (single-reduction PCG)
             const int rows_out = ghost_wave ? 0 : min(RY, g.NY - 1 - j0);      // owned rows inside the grid (wave-uniform)
             // lanes beyond the padded row (the last 62-node tile overshoots: 558 columns for a 513-node row) read the row's last pad
             // entry instead of the next row's data: same cache line as real data, no traffic of their own (9 % of the loads at
@@ -716,10 +717,9 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                             else *dst = y[c];
                             acc += P0[r][c] * y[c];
                         }
-                        if (qmq) {                            // rows and planes interior: the class is that of the lane's x-position
-                            const double* dv = dinv_of(cls_x + 3 + 9);
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) acc2 += dv[c] * y[c] * y[c];
+                        if (qmq) {                            // rows and planes interior: the class is that of the lane's x-position for the whole
+#pragma unroll                                                // march, so the lane sums y_c^2 per component and applies D^-1 once, after the loop
+                            for (int c = 0; c < 3; ++c) S2[c] = fma(y[c], y[c], S2[c]);
                         }
                     }
                 }
@@ -752,6 +752,11 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                 step(lk + 2, PC, PD, PA, PB);
                 if (lk + 3 >= lk1) break;
                 step(lk + 3, PD, PA, PB, PC);
+            }
+            if (qmq) {
+                const double* dv = dinv_of(cls_x + 3 + 9);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc2 = fma(dv[c], S2[c], acc2);
             }
             if constexpr (ZF) if (zhi_chunk) {
                 // the plane NZ-1 and its inward neighbour are read once more (cache hits) rather than taken from the rotating buffers: which
