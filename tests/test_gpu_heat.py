@@ -533,6 +533,85 @@ def test_rccl_backend_on_library_owned_memory(lib, gpu_ctx):
         dist.destroy_process_group()
 
 
+def test_two_slabs_exchanging_through_rccl_in_the_overlapped_order(lib, gpu_ctx):
+    """The closest thing to N = 2 over RCCL one GPU allows: two slab sessions in ONE process whose ghost planes travel as `nccl` point-to-point
+    messages (sends to self, one batch per exchange = one ncclGroup) in exactly the order SlabCG.iterate uses — exchange posted, K1 on the planes
+    away from the ghosts while it is in flight, wait (stream-ordered), the edge planes, ONE message {p.Ap, r.r, Ap.Ap} through dist.all_reduce, K2 —
+    on zero-copy views of library-owned memory.  A receive that landed late, or early into planes part 0 still reads, would change the iterates:
+    the residual history must be the single slab's."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pdegpu import _lib
+    from pdegpu.dist import GpuSlabEngine, SlabCG, slab_range, VEC_R, SC_PQ, SC_QQ, SC_RR, SC_RR_POLL
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        n, Ls = (140, 33, 27), (1.0, 0.7, 1.2)
+        grid = _lib.make_grid(3, n, Ls)
+        h = _lib.Heat()
+        h.kappa, h.steady, h.source = 1.1, 1, 3.0
+        h.bc_mode, h.fast_path = _lib.BC_UNIFORM, 1
+        h.bc_present[0], h.bc_value[0] = 1, 0.25
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            one = GpuSlabEngine(grid, h, 0, n[2] + 1, 0, stream)
+            c1 = SlabCG(one, 0, 1, variant="classic")
+            c1.start(0.0)
+            ref = [c1.rr()]
+            for _ in range(8):
+                c1.iterate(5)
+                ref.append(c1.rr())
+            one.close()
+            engs = [GpuSlabEngine(grid, h, *slab_range(n[2] + 1, 2, r), 0, stream) for r in range(2)]
+            lo, hi = engs
+            for e in engs:
+                e.set_variant(True)
+                assert e.can_split_k1() and not e.needs_p_halo()
+                e.begin(0.0)
+                e.residual()
+
+            def sum_over_slabs(a, b):
+                tot = lo.scalars()[a:b] + hi.scalars()[a:b]
+                for e in engs:
+                    e.scalars()[a:b].copy_(tot)
+                    dist.all_reduce(e.scalars()[a:b], op=dist.ReduceOp.SUM)      # world 1: the identity, through RCCL, in place on library memory
+
+            def rr_now():
+                for e in engs:
+                    e.sr_poll()
+                sum_over_slabs(SC_RR_POLL, SC_RR_POLL + 1)
+                return lo.rr()
+
+            sum_over_slabs(SC_RR, SC_RR + 1)
+            hist = [rr_now()]
+            for it in range(40):
+                ops = [dist.P2POp(dist.isend, lo.plane_tensor(VEC_R, lo.nk - 1), 0), dist.P2POp(dist.irecv, hi.plane_tensor(VEC_R, -1), 0),
+                       dist.P2POp(dist.isend, hi.plane_tensor(VEC_R, 0), 0), dist.P2POp(dist.irecv, lo.plane_tensor(VEC_R, lo.nk), 0)]
+                works = dist.batch_isend_irecv(ops)
+                for e in engs:
+                    e.k1_part(0)
+                for w in works:
+                    w.wait()
+                for e in engs:
+                    e.k1_part(1)
+                sum_over_slabs(SC_PQ, SC_QQ + 1)
+                for e in engs:
+                    e.k2()
+                if it % 5 == 4:
+                    hist.append(rr_now())
+            for e in engs:
+                e.close()
+        assert np.allclose(hist, ref, rtol=1e-9), (hist, ref)
+        assert hist[-1] < 1e-2 * hist[0]
+    finally:
+        dist.destroy_process_group()
+
+
 def test_random_shapes_fast_and_general_apply(lib, gpu_ctx):
     """seeded sweep over ragged 3-D shapes and anisotropic cells: tile edges of the z-marching kernels (x-tiles of
     128, y-tiles of 2 rows, z-chunks) and every boundary class of the general kernels vs the assembled matrices"""
