@@ -33,6 +33,15 @@ for dim, n, Ls in ((1, (5,), (1.0,)), (2, (4, 3), (1.0, 2.0)), (3, (3, 4, 2), (1
 k0, nk = C.c_int64(), C.c_int64()
 for r in range(8):
     assert lib.pdegpu_slab_partition(513, 8, r, C.byref(k0), C.byref(nk)) == 0
+for dim, n in ((1, (4,)), (2, (2, 3)), (3, (2, 3, 2)), (3, (4, 2, 3))):
+    g = L.make_grid(dim, n, (1.0,) * dim)
+    N = int(lib.pdegpu_grid_num_nodes(g))
+    hh = L.Heat(); hh.bc_mode = L.BC_DIRECTIONAL
+    for r in range(3): hh.bc_present[r], hh.bc_value[r] = 1, float(r + 1)
+    m, v = np.zeros(N, np.uint8), np.zeros(N)
+    assert lib.pdegpu_dirichlet_set_host(g, hh, m.ctypes.data_as(C.POINTER(C.c_uint8)), L.dptr(v)) == 0
+g4 = (C.c_int32 * 4)()
+assert lib.pdegpu_marching_geometry(256, 513, 513, 513, 2, 3, g4) == 0
 h = L.Heat(); h.num_steps = 200; h.snapshot_stride = 7
 assert lib.pdegpu_heat_num_snapshots(h) == 30
 ctx = C.c_void_p()
