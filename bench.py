@@ -236,10 +236,33 @@ class Runner:
                     ab[label] = (time.perf_counter() - t0) / steps * 1e3
                 cg.force_collectives = False
                 res["collective_ab_ms"] = ab
-            if world > 1:
-                t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu")
+            def max_over_ranks(v):
+                if world == 1:
+                    return v
+                t = torch.tensor([v], dtype=torch.float64, device=f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                elapsed = float(t.item())
+                return float(t.item())
+
+            if case.get("native_comm"):
+                # the same session again with the exchange and the all-reduce(s) issued by the library itself on its own RCCL communicator
+                # (csrc/comm.hip; a chunk of iterations = ONE C call), alternating with the torch.distributed-driven loop
+                from pdegpu.dist import NativeComm
+                comm = NativeComm(eng, rank, world)
+                ab = {}
+                for label, c in (("library_rccl", comm), ("torch_distributed", None), ("library_rccl_2", comm), ("torch_distributed_2", None)):
+                    cg.comm = c
+                    cg.force_collectives = c is None and world == 1
+                    cg.iterate(max(5, warmup // 2))
+                    self.fence()
+                    t0 = time.perf_counter()
+                    cg.iterate(steps)
+                    self.fence()
+                    ab[label] = max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+                cg.comm, cg.force_collectives = None, False
+                res["native_comm_ms"] = ab
+                res["rr_after_native_comm"] = cg.rr()
+                comm.close()
+            elapsed = max_over_ranks(elapsed)
             res["elapsed"] = elapsed
             res["k1_ms"] = stats.kernel_ms[0] / max(1, stats.kernel_launches[0])
             res["k2_ms"] = stats.kernel_ms[1] / max(1, stats.kernel_launches[1])
@@ -293,6 +316,7 @@ def main():
     ap.add_argument("--cg-variant", choices=("sr", "classic"), default="sr", help="sr: single-reduction recurrences, ONE 24-byte scalar all-reduce per "
                     "iteration (default); classic: 8 bytes after K1 and 8 bytes after K2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-native-comm", action="store_true", help="skip the library-issued RCCL legs of the extras (csrc/comm.hip against torch.distributed)")
     ap.add_argument("--no-tool-extras", action="store_true", help="skip the end-to-end tool-wall legs (config 3 / config 4 steady solves through the tool API)")
     ap.add_argument("--general", action="store_true", help="force the class-table kernels (diagnostic)")
     args = ap.parse_args()
@@ -360,6 +384,9 @@ def main():
 
 
 EXTRAS_ABORT_RC = 3
+NATIVE_COMM_NOTE = ("the same session, alternating: halo exchange + scalar all-reduce issued by libpdegpu itself on its own RCCL communicator "
+                    "(csrc/comm.hip; pdegpu_session_iterate_slab: a chunk of iterations is ONE C call) against the loop of pdegpu.dist.SlabCG that "
+                    "issues them through torch.distributed (the configuration `value` is measured in).")
 
 
 def run_extras_guarded(R, args, case, out, ms_per_step):
@@ -391,8 +418,13 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
         if world == 1 and wl == "config3":
             continue                                    # weak == strong == the main line on one GPU
         try:
+            if world > 1 and R.backend == "nccl" and not args.no_native_comm:
+                c2["native_comm"] = True
             r2 = R.run_case(c2, max(20, args.steps // 2), max(5, args.warmup // 2))
             st2 = max(20, args.steps // 2)
+            if "native_comm_ms" in r2:
+                extras.setdefault("library_rccl", {"what": NATIVE_COMM_NOTE})[f"{wl}_{c2['scaling']}"] = {
+                    "ms_per_step": r2["native_comm_ms"], "rr_after": r2["rr_after_native_comm"]}
             extras[f"{wl}_{c2['scaling']}"] = {
                 "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
                 "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
@@ -400,6 +432,16 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
         except Exception as e:                          # an extra must never void the main number
             extras[f"{wl}_{sc}"] = {"failed": repr(e)}
             break
+    if world > 1 and R.backend == "nccl" and not args.no_native_comm and not any("failed" in v for v in extras.values() if isinstance(v, dict)):
+        try:                                            # the main workload once more, library-issued against torch-issued communication
+            c2 = dict(case)
+            c2["native_comm"] = True
+            st2 = max(20, args.steps // 2)
+            r2 = R.run_case(c2, st2, max(5, args.warmup // 2))
+            extras.setdefault("library_rccl", {"what": NATIVE_COMM_NOTE})["main_workload"] = {
+                "ms_per_step": r2["native_comm_ms"], "rr_after": r2["rr_after_native_comm"]}
+        except Exception as e:
+            extras.setdefault("library_rccl", {})["main_workload"] = {"failed": repr(e)}
     if world == 1 and not extras.get("config4_strong", {}).get("failed"):
         # what the collective calls themselves cost (no wire): the same 512^3 loop with its scalar all-reduce(s) of every iteration going
         # through a ONE-rank RCCL process group — torch.distributed's stream hand-over + RCCL's launch path, on this GPU
@@ -412,6 +454,7 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             R.dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.torch.device(f"cuda:{R.local_rank}"))
             c3 = dict(case)
             c3["collective_ab"] = True
+            c3["native_comm"] = not args.no_native_comm
             st3 = max(20, args.steps // 2)
             r3 = R.run_case(c3, st3, max(5, args.warmup // 2))
             ab = r3["collective_ab_ms"]
@@ -420,6 +463,9 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
                         "RCCL group (no wire time) and without, alternating; the difference is torch.distributed's stream hand-over + RCCL's launch path",
                 "cg_variant": r3["cg_variant"], "steps": st3, "ms_per_step": ab,
                 "calls_cost_us_per_iteration": 0.5e3 * ((ab["with_collective_calls"] - ab["without"]) + (ab["with_collective_calls_2"] - ab["without_2"]))}
+            if "native_comm_ms" in r3:
+                extras["library_rccl"] = {"what": NATIVE_COMM_NOTE + "  One rank: no exchange, and RCCL completes an in-place one-rank all-reduce without a kernel — this leg shows the call path only.",
+                                          "main_workload": {"ms_per_step": r3["native_comm_ms"], "rr_after": r3["rr_after_native_comm"]}}
             R.dist.destroy_process_group()
         except Exception as e:
             extras["collective_calls_one_rank"] = {"failed": repr(e)}

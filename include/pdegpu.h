@@ -372,6 +372,42 @@ int         pdegpu_session_debug_time_k1(pdegpu_session* s, const int32_t* roles
 int  pdegpu_session_get_x(pdegpu_session* s, double* x_out /* host [nk][plane nodes] */);
 int  pdegpu_session_sync(pdegpu_session* s);
 
+/* ---- the slab loop's communication issued by the library itself (csrc/comm.hip) ------------------------------------------------------------
+ * The reference has no multi-process code (its only MPI-adjacent line is fenics_mcp_server.py:141); a host that distributes the solve of
+ * :702-716 over slabs may drive the exchange / all-reduce itself on the pointers above (pdegpu/dist.py does, through torch.distributed), or hand
+ * the library an RCCL communicator and let it run whole iterations: no host-language call path in the loop (tools/dist_overhead.py: 14 us of
+ * C-ABI calls per iteration against 124 us with torch.distributed's all-reduce and point-to-point batch).  RCCL is resolved at run time from the copy
+ * the process already holds (else librccl.so.1 of the loader's path): libpdegpu.so does not link it.
+ *   unique_id: 128 bytes (ncclUniqueId) made on one rank and carried to the others by the host's own bootstrap (MPI_Bcast, torch.distributed
+ *   broadcast of a byte tensor, a file); create: collective over all `world` ranks, one process per GPU, the context's device.
+ * Stream protocol of an exchange: exchange_begin makes the communicator's own stream wait for everything enqueued so far on the context stream,
+ * posts ONE group of sends / receives there (first owned plane -> rank-1's upper ghost, last owned plane -> rank+1's lower ghost; heat: r, plus p
+ * where k1 does not maintain it on the ghosts, or x with x_planes != 0 for a transient step's right-hand side; elasticity: the three component planes
+ * of r) and returns; exchange_end makes LATER launches on the context stream wait for their arrival — whatever is enqueued in between overlaps the
+ * transfer.  allreduce sums scalars[first .. first+count) over the ranks in place on the context stream.  iterate_slab = `iters` times
+ * {exchange_begin, k1_part(0), exchange_end, k1_part(1), all-reduce, k2 (, all-reduce)} in the session's CG variant — heat single-reduction form:
+ * 4 launches + ONE 24-byte collective per iteration; elasticity: k1_pre first, ONE 32-byte collective.  Nothing here synchronises the host.
+ * exchange_post is the building block (what: bit 0 the sends, bit 1 the receives; lo_rank / hi_rank < 0 = rank -/+ 1) for hosts that group several
+ * sessions' messages themselves, bracketed by pdegpu_comm_group_begin / _end. */
+typedef struct pdegpu_comm pdegpu_comm;
+int  pdegpu_comm_unique_id(void* id128_out);
+int  pdegpu_comm_create(pdegpu_ctx* ctx, int rank, int world, const void* id128, pdegpu_comm** out);
+void pdegpu_comm_destroy(pdegpu_comm* c);
+int  pdegpu_comm_rank(const pdegpu_comm* c);
+int  pdegpu_comm_world(const pdegpu_comm* c);
+int  pdegpu_comm_group_begin(pdegpu_comm* c);               /* comm stream waits for the context stream; ncclGroupStart */
+int  pdegpu_comm_group_end(pdegpu_comm* c);                 /* ncclGroupEnd; marks the end of the exchange for exchange_end */
+int  pdegpu_session_exchange_post(pdegpu_session* s, pdegpu_comm* c, int what, int x_planes, int lo_rank, int hi_rank);
+int  pdegpu_session_exchange_begin(pdegpu_session* s, pdegpu_comm* c, int x_planes);
+int  pdegpu_session_exchange_end(pdegpu_session* s, pdegpu_comm* c);
+int  pdegpu_session_allreduce(pdegpu_session* s, pdegpu_comm* c, int first, int count);
+int  pdegpu_session_iterate_slab(pdegpu_session* s, pdegpu_comm* c, int iters);
+int  pdegpu_el_session_exchange_post(pdegpu_el_session* s, pdegpu_comm* c, int what, int lo_rank, int hi_rank);
+int  pdegpu_el_session_exchange_begin(pdegpu_el_session* s, pdegpu_comm* c);
+int  pdegpu_el_session_exchange_end(pdegpu_el_session* s, pdegpu_comm* c);
+int  pdegpu_el_session_allreduce(pdegpu_el_session* s, pdegpu_comm* c, int first, int count);
+int  pdegpu_el_session_iterate_slab(pdegpu_el_session* s, pdegpu_comm* c, int iters);
+
 /* ---- CPU-visible helpers that need no GPU (used by `-m "not gpu"` tests) ---------------------- */
 int64_t pdegpu_grid_num_nodes(const pdegpu_grid* grid);
 /* the Dirichlet set (mask_out [N] 0/1, value_out [N] nullable) the kernels use for `grid` with the boundary arguments of `heat`

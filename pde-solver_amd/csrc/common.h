@@ -288,6 +288,19 @@ int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double*
                   double* scal, int iters_max, double target, int* iters_done, int fresh);
 void persist2d_free(Persist2d* p);
 
+// comm.hip: the library's RCCL communicator (halo exchange on its own stream, scalar all-reduce on the compute stream)
+struct pdegpu_comm;
+int comm_rank(const pdegpu_comm* c);
+int comm_world(const pdegpu_comm* c);
+int comm_ready(pdegpu_comm* c, hipStream_t compute);     // the planes to send are final: the exchange stream may start
+int comm_group_start(pdegpu_comm* c);
+int comm_group_end(pdegpu_comm* c);
+int comm_send(pdegpu_comm* c, const double* buf, size_t n, int peer);
+int comm_recv(pdegpu_comm* c, double* buf, size_t n, int peer);
+int comm_done(pdegpu_comm* c);                           // marks the end of the exchange posted so far
+int comm_wait(pdegpu_comm* c, hipStream_t compute);      // later launches on `compute` see the received planes
+int comm_allreduce(pdegpu_comm* c, double* buf, size_t n, hipStream_t compute);
+
 int next_poll_chunk(double rr_before, double rr_after, double target, int n_done, int chunk, int cap);   // heat.hip
 GridDev make_grid_dev(const pdegpu_grid* grid, const pdegpu_heat* heat, int64_t k0, int64_t nk);
 int validate_grid(pdegpu_ctx* ctx, const pdegpu_grid* grid);

@@ -2363,6 +2363,82 @@ extern "C" int pdegpu_el_session_flush(pdegpu_el_session* h) {
     if (!h) return PDEGPU_EINVAL;
     return h->s.variant ? PDEGPU_OK : el_flush(&h->s);      // (single-reduction form: nothing is pending, x matches the r that r.r reports)
 }
+// ---- exchange and scalar reduction through the library's own RCCL communicator (comm.hip): same protocol as the heat session ----
+namespace {
+// first / last owned plane of r (3 component planes, each contiguous) <-> the neighbours' ghost planes; what: bit 0 sends, bit 1 receives
+int el_exchange_post(ElSession* s, pdegpu_comm* c, int what, int lo_rank, int hi_rank) {
+    const GridDev& g = s->g;
+    const bool lo = g.k0 > 0, hi = g.k0 + g.nkl < g.NZ;
+    if (lo_rank < 0) lo_rank = comm_rank(c) - 1;
+    if (hi_rank < 0) hi_rank = comm_rank(c) + 1;
+    const size_t n = (size_t)g.PP;
+    for (int comp = 0; comp < s->D; ++comp) {
+        double* base = s->r + (long long)comp * s->stride;
+        if (what & 1) {
+            if (lo) PG_TRY(comm_send(c, base, n, lo_rank));
+            if (hi) PG_TRY(comm_send(c, base + (long long)(g.nkl - 1) * g.PP, n, hi_rank));
+        }
+        if (what & 2) {
+            if (lo) PG_TRY(comm_recv(c, base - g.PP, n, lo_rank));
+            if (hi) PG_TRY(comm_recv(c, base + (long long)g.nkl * g.PP, n, hi_rank));
+        }
+    }
+    return PDEGPU_OK;
+}
+}  // namespace
+
+extern "C" int pdegpu_el_session_exchange_post(pdegpu_el_session* h, pdegpu_comm* c, int what, int lo_rank, int hi_rank) {
+    if (!h || !c || (what & ~3) || !what) return PDEGPU_EINVAL;
+    PG_HIP(h->s.ctx, hipSetDevice(h->s.ctx->device));
+    return el_exchange_post(&h->s, c, what, lo_rank, hi_rank);
+}
+extern "C" int pdegpu_el_session_exchange_begin(pdegpu_el_session* h, pdegpu_comm* c) {
+    if (!h || !c) return PDEGPU_EINVAL;
+    ElSession* s = &h->s;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    const bool any = s->g.k0 > 0 || s->g.k0 + s->g.nkl < s->g.NZ;
+    PG_TRY(comm_ready(c, s->ctx->stream));
+    if (any) {
+        PG_TRY(comm_group_start(c));
+        const int rc = el_exchange_post(s, c, 3, -1, -1);
+        PG_TRY(comm_group_end(c));
+        PG_TRY(rc);
+    }
+    return comm_done(c);
+}
+extern "C" int pdegpu_el_session_exchange_end(pdegpu_el_session* h, pdegpu_comm* c) {
+    if (!h || !c) return PDEGPU_EINVAL;
+    PG_HIP(h->s.ctx, hipSetDevice(h->s.ctx->device));
+    return comm_wait(c, h->s.ctx->stream);
+}
+extern "C" int pdegpu_el_session_allreduce(pdegpu_el_session* h, pdegpu_comm* c, int first, int count) {
+    if (!h || !c || first < 0 || count < 1 || first + count > ESC_COUNT) return PDEGPU_EINVAL;
+    PG_HIP(h->s.ctx, hipSetDevice(h->s.ctx->device));
+    return comm_allreduce(c, h->s.scal + first, (size_t)count, h->s.ctx->stream);
+}
+// `iters` PCG iterations of this rank's slab, exchange and reduction(s) issued from here (the loop of pdegpu.dist.SlabCG.iterate).  Single-reduction
+// form: update pass of the owned planes -> exchange of r posted -> apply away from the ghosts -> wait -> ghost update + edge planes + reduce -> ONE
+// 32-byte all-reduce; classic form: exchange around the split apply, 8 bytes after it, 16 after k2.
+extern "C" int pdegpu_el_session_iterate_slab(pdegpu_el_session* h, pdegpu_comm* c, int iters) {
+    if (!h || !c || iters < 0) return PDEGPU_EINVAL;
+    ElSession* s = &h->s;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    const bool multi = comm_world(c) > 1;
+    for (int it = 0; it < iters; ++it) {
+        PG_TRY(pdegpu_el_session_k1_pre(h));
+        if (multi) PG_TRY(pdegpu_el_session_exchange_begin(h, c));
+        PG_TRY(pdegpu_el_session_k1_part(h, 0));
+        if (multi) PG_TRY(pdegpu_el_session_exchange_end(h, c));
+        PG_TRY(pdegpu_el_session_k1_part(h, 1));
+        PG_TRY(comm_allreduce(c, s->scal, s->variant ? 4 : 1, s->ctx->stream));
+        if (!s->variant) {
+            PG_TRY(pdegpu_el_session_k2(h));
+            PG_TRY(comm_allreduce(c, s->scal + 1, 2, s->ctx->stream));
+        }
+    }
+    return PDEGPU_OK;
+}
+
 extern "C" double* pdegpu_el_session_scalars(pdegpu_el_session* h) { return h ? h->s.scal : nullptr; }
 extern "C" int64_t pdegpu_el_session_plane_doubles(const pdegpu_el_session* h) { return h ? (int64_t)h->s.g.PP : -1; }
 

@@ -1122,6 +1122,90 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
     return PDEGPU_OK;
 }
 
+// ---- the slab loop's two exchanges through the library's own RCCL communicator (comm.hip) ------------------------------------------------
+namespace {
+// first / last owned plane -> the neighbours' ghost planes.  what: bit 0 the sends, bit 1 the receives (both in real use; a test that runs two
+// slabs in one process posts them separately so that sends to self meet their receives in order).  x_planes: the solution vector (the x-halo of a
+// backward-Euler step) instead of the CG vectors (r, and p where K1 does not maintain it on the ghost planes).
+int session_exchange_post(pdegpu_session* s, pdegpu_comm* c, int what, int x_planes, int lo_rank, int hi_rank) {
+    const GridDev& g = s->g;
+    const bool lo = g.k0 > 0, hi = g.k0 + g.nkl < g.NZ;
+    if (lo_rank < 0) lo_rank = comm_rank(c) - 1;
+    if (hi_rank < 0) hi_rank = comm_rank(c) + 1;
+    double* vecs[2];
+    int nv = 0;
+    if (x_planes) {
+        vecs[nv++] = s->x.v;
+    } else {
+        vecs[nv++] = s->r.v;
+        if (!k2_is_stencil(s)) vecs[nv++] = s->p[s->pcur].v;
+    }
+    const size_t n = (size_t)g.PP;
+    for (int v = 0; v < nv; ++v) {
+        double* base = vecs[v];
+        if (what & 1) {
+            if (lo) PG_TRY(comm_send(c, base, n, lo_rank));
+            if (hi) PG_TRY(comm_send(c, base + (long long)(g.nkl - 1) * g.PP, n, hi_rank));
+        }
+        if (what & 2) {
+            if (lo) PG_TRY(comm_recv(c, base - g.PP, n, lo_rank));
+            if (hi) PG_TRY(comm_recv(c, base + (long long)g.nkl * g.PP, n, hi_rank));
+        }
+    }
+    return PDEGPU_OK;
+}
+}  // namespace
+
+extern "C" int pdegpu_session_exchange_post(pdegpu_session* s, pdegpu_comm* c, int what, int x_planes, int lo_rank, int hi_rank) {
+    if (!s || !c || (what & ~3) || !what) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return session_exchange_post(s, c, what, x_planes, lo_rank, hi_rank);
+}
+// post the exchange: everything enqueued on the session's stream before this call is visible to the sends; returns at once
+extern "C" int pdegpu_session_exchange_begin(pdegpu_session* s, pdegpu_comm* c, int x_planes) {
+    if (!s || !c) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    const bool any = s->g.k0 > 0 || s->g.k0 + s->g.nkl < s->g.NZ;
+    PG_TRY(comm_ready(c, s->ctx->stream));
+    if (any) {
+        PG_TRY(comm_group_start(c));
+        const int rc = session_exchange_post(s, c, 3, x_planes, -1, -1);
+        PG_TRY(comm_group_end(c));
+        PG_TRY(rc);
+    }
+    return comm_done(c);
+}
+// launches enqueued on the session's stream after this call see the received ghost planes (the host does not wait)
+extern "C" int pdegpu_session_exchange_end(pdegpu_session* s, pdegpu_comm* c) {
+    if (!s || !c) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return comm_wait(c, s->ctx->stream);
+}
+// scalars[first .. first + count) summed over the ranks, in place, stream-ordered with the session's kernels
+extern "C" int pdegpu_session_allreduce(pdegpu_session* s, pdegpu_comm* c, int first, int count) {
+    if (!s || !c || first < 0 || count < 1 || first + count > SC_COUNT) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return comm_allreduce(c, s->d_scal + first, (size_t)count, s->ctx->stream);
+}
+// `iters` CG iterations of this rank's slab with the exchange and the scalar reduction(s) issued from here: the loop of pdegpu.dist.SlabCG.iterate
+// without the host language in it (fenics_mcp_server.py:707-716 distributed).  Single-reduction form: exchange posted -> K1 away from the ghosts ->
+// wait -> K1 edge planes + one reduce -> ONE all-reduce of {p.Ap, r.r, Ap.Ap} -> K2; classic form: 8 bytes after K1 and 8 after K2.
+extern "C" int pdegpu_session_iterate_slab(pdegpu_session* s, pdegpu_comm* c, int iters) {
+    if (!s || !c || iters < 0) return PDEGPU_EINVAL;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    const bool multi = comm_world(c) > 1;
+    for (int it = 0; it < iters; ++it) {
+        if (multi) PG_TRY(pdegpu_session_exchange_begin(s, c, 0));
+        PG_TRY(pdegpu_session_k1_part(s, 0));
+        if (multi) PG_TRY(pdegpu_session_exchange_end(s, c));
+        PG_TRY(pdegpu_session_k1_part(s, 1));
+        PG_TRY(comm_allreduce(c, s->d_scal + SC_PQ, s->variant ? 3 : 1, s->ctx->stream));
+        PG_TRY(pdegpu_session_k2(s));
+        if (!s->variant) PG_TRY(comm_allreduce(c, s->d_scal + SC_RR, 1, s->ctx->stream));
+    }
+    return PDEGPU_OK;
+}
+
 extern "C" int pdegpu_session_rr(pdegpu_session* s, double* rr_out) {
     if (!s || !rr_out) return PDEGPU_EINVAL;
     pdegpu_ctx* ctx = s->ctx;

@@ -123,6 +123,23 @@ SYMBOLS = {
     "pdegpu_session_set_cg_variant": (C.c_int, [_vp, C.c_int]),
     "pdegpu_session_cg_variant": (C.c_int, [_vp]),
     "pdegpu_session_sr_poll": (C.c_int, [_vp]),
+    "pdegpu_comm_unique_id": (C.c_int, [_vp]),
+    "pdegpu_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "pdegpu_comm_destroy": (None, [_vp]),
+    "pdegpu_comm_rank": (C.c_int, [_vp]),
+    "pdegpu_comm_world": (C.c_int, [_vp]),
+    "pdegpu_comm_group_begin": (C.c_int, [_vp]),
+    "pdegpu_comm_group_end": (C.c_int, [_vp]),
+    "pdegpu_session_exchange_post": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pdegpu_session_exchange_begin": (C.c_int, [_vp, _vp, C.c_int]),
+    "pdegpu_session_exchange_end": (C.c_int, [_vp, _vp]),
+    "pdegpu_session_allreduce": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "pdegpu_session_iterate_slab": (C.c_int, [_vp, _vp, C.c_int]),
+    "pdegpu_el_session_exchange_post": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "pdegpu_el_session_exchange_begin": (C.c_int, [_vp, _vp]),
+    "pdegpu_el_session_exchange_end": (C.c_int, [_vp, _vp]),
+    "pdegpu_el_session_allreduce": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "pdegpu_el_session_iterate_slab": (C.c_int, [_vp, _vp, C.c_int]),
     "pdegpu_session_set_timing": (C.c_int, [_vp, C.c_int]),
     "pdegpu_session_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "pdegpu_session_step_rhs": (C.c_int, [_vp]),

@@ -17,6 +17,11 @@ RCCL over xGMI) for the only two exchanges the path has —
     contiguous component planes per neighbour in the one batch), the p-update of the owned planes and the block apply away from
     the ghosts run meanwhile, the ghost planes' p-update and the edge planes follow.
 
+  * who issues them: by default this module, through torch.distributed (P2POp batch + all_reduce: 20 + 90 us of host time per iteration,
+    tools/dist_overhead.py — hidden behind 1.4 ms of kernels on a 512^3 slab, not behind the 25-60 us of a thin one).  With
+    SlabCG(..., comm=NativeComm(...)) the library issues them itself on its own RCCL communicator (csrc/comm.hip) and a whole chunk of
+    iterations is ONE C call (pdegpu_session_iterate_slab): same messages, same order, same stream protocol, no host language in the loop.
+
 The compute engine is abstract so that the same driver runs (a) the HIP session through the C-ABI on GPUs and
 (b) under the `gloo` backend on CPU tensors in the test-suite (tests/ supply a numpy engine built on the
 oracle) — the N>1 logic (partition, ownership of planes in the dot products, ghost exchange, scalar flow) is
@@ -51,6 +56,38 @@ def slab_range(n_planes: int, world: int, rank: int):
     if rc != 0:
         raise L.PdeGpuError(rc, f"cannot split {n_planes} planes over {world} ranks")
     return k0.value, nk.value
+
+
+class NativeComm:
+    """RCCL communicator owned by libpdegpu (csrc/comm.hip) for the context of `engine`: one per rank, created collectively.  The 128-byte
+    unique id travels through the torch.distributed group the ranks already share (any backend), or is made locally when world == 1."""
+
+    def __init__(self, engine, rank: int, world: int, group=None):
+        self.lib = L.load_library()
+        self.rank, self.world, self.ctx = rank, world, engine.ctx
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            rc = self.lib.pdegpu_comm_unique_id(ident)
+            if rc != 0:
+                raise L.PdeGpuError(rc, "pdegpu_comm_unique_id failed: librccl.so.1 cannot be loaded or refused to make an id")
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.h = C.c_void_p()
+        L.check(self.ctx, self.lib.pdegpu_comm_create(self.ctx, rank, world, ident, C.byref(self.h)))
+
+    def close(self):
+        """before the engine (its context) is closed"""
+        if self.h:
+            self.lib.pdegpu_comm_destroy(self.h)
+            self.h = None
+
+    def group_begin(self):
+        L.check(self.ctx, self.lib.pdegpu_comm_group_begin(self.h))
+
+    def group_end(self):
+        L.check(self.ctx, self.lib.pdegpu_comm_group_end(self.h))
 
 
 class GpuSlabEngine:
@@ -172,6 +209,22 @@ class GpuSlabEngine:
             return (SC_PQ, SC_QQ + 1)                    # {p.Ap, r.r, Ap.Ap}: one message
         return (SC_PQ, SC_PQ + 1) if which == 0 else (SC_RR, SC_RR + 1)
 
+    # ---- exchange / reduction issued by the library on its own RCCL communicator (NativeComm) ----
+    def comm_exchange_begin(self, comm, x_planes: bool = False):
+        self._ck(self.lib.pdegpu_session_exchange_begin(self.s, comm.h, 1 if x_planes else 0))
+
+    def comm_exchange_end(self, comm):
+        self._ck(self.lib.pdegpu_session_exchange_end(self.s, comm.h))
+
+    def comm_exchange_post(self, comm, what: int, x_planes: bool = False, lo_rank: int = -1, hi_rank: int = -1):
+        self._ck(self.lib.pdegpu_session_exchange_post(self.s, comm.h, what, 1 if x_planes else 0, lo_rank, hi_rank))
+
+    def comm_allreduce(self, comm, first: int, count: int):
+        self._ck(self.lib.pdegpu_session_allreduce(self.s, comm.h, first, count))
+
+    def iterate_slab(self, comm, iters: int):
+        self._ck(self.lib.pdegpu_session_iterate_slab(self.s, comm.h, iters))
+
     def iterate_native(self, iters: int, time_kernels: bool, stats=None):
         self._ck(self.lib.pdegpu_session_iterate(self.s, iters, 1 if time_kernels else 0, stats))
 
@@ -270,6 +323,21 @@ class GpuElasticitySlabEngine:
             return (0, 4)                                # {p.Ap, r.z, r.r, Ap.D^-1 Ap}: the one message of an iteration
         return (0, 1) if which == 0 else (1, 3)          # p.q | r.z and r.r as one 16-byte message
 
+    def comm_exchange_begin(self, comm, x_planes: bool = False):
+        self._ck(self.lib.pdegpu_el_session_exchange_begin(self.s, comm.h))
+
+    def comm_exchange_end(self, comm):
+        self._ck(self.lib.pdegpu_el_session_exchange_end(self.s, comm.h))
+
+    def comm_exchange_post(self, comm, what: int, x_planes: bool = False, lo_rank: int = -1, hi_rank: int = -1):
+        self._ck(self.lib.pdegpu_el_session_exchange_post(self.s, comm.h, what, lo_rank, hi_rank))
+
+    def comm_allreduce(self, comm, first: int, count: int):
+        self._ck(self.lib.pdegpu_el_session_allreduce(self.s, comm.h, first, count))
+
+    def iterate_slab(self, comm, iters: int):
+        self._ck(self.lib.pdegpu_el_session_iterate_slab(self.s, comm.h, iters))
+
     def scalars_host(self):
         out = (C.c_double * 4)()
         self._ck(self.lib.pdegpu_el_session_scalars_host(self.s, out))
@@ -289,10 +357,14 @@ class GpuElasticitySlabEngine:
 class SlabCG:
     """CG over a 1-D slab decomposition.  `engine` owns planes [k0, k0+nk) plus one ghost plane per side."""
 
-    def __init__(self, engine, rank: int, world: int, group=None, overlap: bool = True, variant: str = "auto"):
+    def __init__(self, engine, rank: int, world: int, group=None, overlap: bool = True, variant: str = "auto", comm: Optional[NativeComm] = None):
         """variant: "sr" = single-reduction recurrences (ONE scalar message per iteration), "classic" = two; "auto" = "sr" where the
-        engine offers it (the heat engines; the elasticity PCG keeps the classic form)"""
+        engine offers it.  comm: a NativeComm of the same rank / world — the library then issues the exchange and the all-reduces itself
+        (HIP engines only) and iterate() is one C call per chunk; None: torch.distributed on `group`."""
         self.e, self.rank, self.world, self.group = engine, rank, world, group
+        if comm is not None and (comm.rank != rank or comm.world != world or not hasattr(engine, "iterate_slab")):
+            raise L.PdeGpuError(L.EINVAL, "comm must be a NativeComm of this rank / world and the engine a HIP engine")
+        self.comm = comm
         self.force_collectives = False      # measurement aid: run the scalar all-reduces through the process group at world == 1 too
         self.overlap = overlap
         self.iterations = 0
@@ -332,11 +404,14 @@ class SlabCG:
             return []
         return dist.batch_isend_irecv(ops)
 
-    def exchange_begin(self, halo=None):
+    def exchange_begin(self, halo=None, x_planes: bool = False):
         """first / last owned plane -> the neighbours' ghost planes.  Returns a token for exchange_end; between the two calls
         the engine may compute on everything that does not read a ghost plane."""
         if self.world == 1:
             return None
+        if self.comm is not None:
+            self.e.comm_exchange_begin(self.comm, x_planes)
+            return ("native", None)
         e, nk = self.e, self.e.nk
         halo = halo or self._halo
         works = self._post(list(zip(halo(0), halo(-1))), list(zip(halo(nk - 1), halo(nk))))
@@ -346,11 +421,14 @@ class SlabCG:
         if token is None:
             return
         kind, works = token
+        if kind == "native":
+            self.e.comm_exchange_end(self.comm)
+            return
         for w in works:
             w.wait()          # stream-ordered for NCCL (the compute stream waits, the host does not); completes the copy for gloo
 
-    def exchange_halos(self, halo=None):
-        self.exchange_end(self.exchange_begin(halo))
+    def exchange_halos(self, halo=None, x_planes: bool = False):
+        self.exchange_end(self.exchange_begin(halo, x_planes))
 
     def _exchange_staged(self, ops):
         """gloo cannot send device memory: stage the planes through host buffers.  Only for rehearsing the multi-rank
@@ -383,6 +461,9 @@ class SlabCG:
             else:
                 a = SC_PQ if which == 0 else SC_RR
                 b = a + 1
+            if self.comm is not None:
+                self.e.comm_allreduce(self.comm, a, b - a)
+                return
             t = self.e.scalars()[a:b]
             if t.is_cuda and dist.get_backend(self.group) == "gloo":       # rehearsal transport, see _exchange_staged
                 h = t.cpu()
@@ -406,6 +487,10 @@ class SlabCG:
         split = self.overlap and hasattr(self.e, "k1_part")
         # engines whose single-reduction form updates r INSIDE k1 (elasticity PCG): k1_pre, then the exchange, then the two parts
         pre = getattr(self.e, "k1_pre", None) if self.sr else None
+        if self.comm is not None and self.overlap and not self.force_collectives:
+            self.e.iterate_slab(self.comm, iters)      # the same sequence, issued from C
+            self.iterations += iters
+            return
         for _ in range(iters):
             if pre is not None:
                 pre()
@@ -440,7 +525,7 @@ class SlabCG:
         """x holds u^n on the owned planes: exchange its ghost planes, b = M (u^n + dt f), reference norm, r = P (b - A x).
         Returns ||P (b - A g)||^2 (host value; the one synchronisation of the step set-up)."""
         e = self.e
-        self.exchange_halos(getattr(e, "x_halo_tensors"))
+        self.exchange_halos(getattr(e, "x_halo_tensors"), x_planes=True)
         e.step_rhs()
         e.lift_norm()
         self.allreduce(1)
