@@ -328,6 +328,13 @@ int  pdegpu_session_k2(pdegpu_session* s);                  /* r-=alpha*q; rr_lo
  * nothing in part 0 and the whole k1 in part 1, so a driver may always call part 0 then part 1. */
 int  pdegpu_session_can_split_k1(const pdegpu_session* s);
 int  pdegpu_session_k1_part(pdegpu_session* s, int part);
+/* K2 in two steps, so that the NEXT iteration's exchange is posted as soon as its planes are final: part 0 = the one or two planes next to the
+ * ghosts (one launch) — after it the first / last owned plane of r belong to the new residual: post the exchange —, part 1 = the planes in between
+ * + k2's reduce (classic form).  The transfer then hides behind K2's bulk and the next K1's bulk (pdegpu_session_iterate_slab and pdegpu.dist.SlabCG do
+ * this inside a chunk of iterations).  can_split_k2 = 1 for marching sessions whose K2 is the stencil form, on a slab with a neighbour; other
+ * sessions run all of K2 in part 0 and nothing in part 1, so a driver may always call 0, post, 1. */
+int  pdegpu_session_can_split_k2(const pdegpu_session* s);
+int  pdegpu_session_k2_part(pdegpu_session* s, int part);
 /* The CG recurrences of the stepwise protocol.  variant 0 (default): classic CG — the host all-reduces pq_global after k1 and rr_global after
  * k2 (two 8-byte messages per iteration).  variant 1: single-reduction form (one message per iteration): k1 additionally sums
  * Ap.Ap, k2 leaves its r.r in per-workgroup partials, and k1 / k1_part(1) end with ONE reduce launch that fills scalars[2..4] =
@@ -395,6 +402,8 @@ int  pdegpu_comm_create(pdegpu_ctx* ctx, int rank, int world, const void* id128,
 void pdegpu_comm_destroy(pdegpu_comm* c);
 int  pdegpu_comm_rank(const pdegpu_comm* c);
 int  pdegpu_comm_world(const pdegpu_comm* c);
+/* one-GPU rehearsal (tools/slab_surrogate.py): on != 0 makes both slab neighbours this rank itself — real messages of the real size, meaningless iterates */
+int  pdegpu_comm_set_self_loop(pdegpu_comm* c, int on);
 int  pdegpu_comm_group_begin(pdegpu_comm* c);               /* comm stream waits for the context stream; ncclGroupStart */
 int  pdegpu_comm_group_end(pdegpu_comm* c);                 /* ncclGroupEnd; marks the end of the exchange for exchange_end */
 int  pdegpu_session_exchange_post(pdegpu_session* s, pdegpu_comm* c, int what, int x_planes, int lo_rank, int hi_rank);

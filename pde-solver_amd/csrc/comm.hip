@@ -77,6 +77,7 @@ struct pdegpu_comm {
     int rank = 0, world = 1;
     hipStream_t cstream = nullptr;          // the exchange runs here, beside the compute stream
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool self_loop = false;                 // one-GPU rehearsal: both slab neighbours are this rank itself
 };
 
 #define PG_NCCL(c, call)                                                                                         \
@@ -138,6 +139,14 @@ extern "C" void pdegpu_comm_destroy(pdegpu_comm* c) {
     delete c;
 }
 
+// One-GPU rehearsal of a rank's iteration (tools/slab_surrogate.py): with on != 0 a slab's two neighbours are this rank itself — its first / last
+// owned plane come back into its own ghost planes as real RCCL point-to-point messages of the real size, and iterate_slab exchanges although the
+// communicator has one rank.  The iterates mean nothing then; the launches, the stream protocol and the messages are those of a rank in the middle.
+extern "C" int pdegpu_comm_set_self_loop(pdegpu_comm* c, int on) {
+    if (!c) return PDEGPU_EINVAL;
+    c->self_loop = on != 0;
+    return PDEGPU_OK;
+}
 extern "C" int pdegpu_comm_rank(const pdegpu_comm* c) { return c ? c->rank : -1; }
 extern "C" int pdegpu_comm_world(const pdegpu_comm* c) { return c ? c->world : -1; }
 
@@ -157,6 +166,7 @@ extern "C" int pdegpu_comm_group_end(pdegpu_comm* c) {
 // ---- pieces the session code composes (heat.hip, elasticity.hip) ------------------------------------------------------------------------
 int comm_rank(const pdegpu_comm* c) { return c->rank; }
 int comm_world(const pdegpu_comm* c) { return c->world; }
+bool comm_self_loop(const pdegpu_comm* c) { return c->self_loop; }
 
 // the planes to send are final on `compute` from here on: the exchange stream may start
 int comm_ready(pdegpu_comm* c, hipStream_t compute) {

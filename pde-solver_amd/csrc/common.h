@@ -292,6 +292,7 @@ void persist2d_free(Persist2d* p);
 struct pdegpu_comm;
 int comm_rank(const pdegpu_comm* c);
 int comm_world(const pdegpu_comm* c);
+bool comm_self_loop(const pdegpu_comm* c);               // rehearsal on one GPU: the slab's neighbours are this rank itself
 int comm_ready(pdegpu_comm* c, hipStream_t compute);     // the planes to send are final: the exchange stream may start
 int comm_group_start(pdegpu_comm* c);
 int comm_group_end(pdegpu_comm* c);

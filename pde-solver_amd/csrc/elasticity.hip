@@ -2369,8 +2369,8 @@ namespace {
 int el_exchange_post(ElSession* s, pdegpu_comm* c, int what, int lo_rank, int hi_rank) {
     const GridDev& g = s->g;
     const bool lo = g.k0 > 0, hi = g.k0 + g.nkl < g.NZ;
-    if (lo_rank < 0) lo_rank = comm_rank(c) - 1;
-    if (hi_rank < 0) hi_rank = comm_rank(c) + 1;
+    if (lo_rank < 0) lo_rank = comm_rank(c) - (comm_self_loop(c) ? 0 : 1);
+    if (hi_rank < 0) hi_rank = comm_rank(c) + (comm_self_loop(c) ? 0 : 1);
     const size_t n = (size_t)g.PP;
     for (int comp = 0; comp < s->D; ++comp) {
         double* base = s->r + (long long)comp * s->stride;
@@ -2423,7 +2423,7 @@ extern "C" int pdegpu_el_session_iterate_slab(pdegpu_el_session* h, pdegpu_comm*
     if (!h || !c || iters < 0) return PDEGPU_EINVAL;
     ElSession* s = &h->s;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    const bool multi = comm_world(c) > 1;
+    const bool multi = comm_world(c) > 1 || comm_self_loop(c);
     for (int it = 0; it < iters; ++it) {
         PG_TRY(pdegpu_el_session_k1_pre(h));
         if (multi) PG_TRY(pdegpu_el_session_exchange_begin(h, c));

@@ -50,6 +50,7 @@ struct pdegpu_session {
     size_t tev_used = 0;
     long long timed_k1 = 0, timed_k2 = 0;
     int k1_parts = 0;              // workgroups (partials) launched by the parts of a split K1 so far
+    int k2_parts = 0;              // the same for a split K2
     // single-reduction form of the stepwise protocol (pdegpu_session_set_cg_variant 1): d_part = [p.Ap | r.r of K2 | Ap.Ap], npart each
     int variant = 0;
     bool sr_k2_pending = false;    // K2's r.r partials (d_part + npart) have not been summed into SC_RR yet: the next K1's reduce launch does
@@ -386,11 +387,18 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
 
 // K2: r -= alpha q, partial r.r   (fast path variant 1: q = A p recomputed by the marching stencil)
 // part_out: where this launch's r.r partials go (the lazy loop keeps them apart from K1's p.q partials)
-int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* part_out = nullptr) {
+// lk_lo < lk_hi: one part of a split K2 (marching sessions whose K2 is the stencil): local planes [lk_lo, lk_hi) and [lk_lo2, lk_hi2)
+int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* part_out = nullptr, int lk_lo = 0, int lk_hi = 0, int lk_lo2 = 0, int lk_hi2 = 0) {
     if (!part_out) part_out = s->d_part;
     if (k2_is_stencil(s)) {
         StencilArgs a{};
         a.di = di;
+        if (lk_hi > lk_lo) {
+            a.lk_lo = lk_lo;
+            a.lk_hi = lk_hi;
+            a.lk_lo2 = lk_lo2;
+            a.lk_hi2 = lk_hi2;
+        }
         a.g = s->g;
         a.in = s->p[s->pcur].v;
         a.rhs = s->r.v;
@@ -802,6 +810,10 @@ void timed_iteration(pdegpu_session* s) {
 }
 // a K1 that can be split into plane ranges: marching kernel alone (no boundary pass, no one-round tiles), 3-D
 bool k1_splittable(const pdegpu_session* s) { return s->fast && !s->hybrid && !s->tile3d && !s->plane2d && s->g.dim == 3 && !s->weighted; }
+// K2 on plane ranges: the marching stencil form of K2 (r -= alpha A p recomputed) on a slab with a neighbour
+bool k2_splittable(const pdegpu_session* s) {
+    return k1_splittable(s) && k2_is_stencil(s) && (s->g.k0 > 0 || s->g.k0 + s->g.nkl < s->g.NZ);
+}
 }  // namespace
 
 namespace {
@@ -911,6 +923,54 @@ extern "C" int pdegpu_session_k2(pdegpu_session* s) {
     timed_end(s, at);
     if (s->timing && s->timing_now) ++s->timed_k2;
     return empty_dot(s, li, 1);
+}
+
+// K2 in two steps so that the NEXT iteration's halo exchange can be posted as early as its planes are final: part 0 = the one or two planes next to
+// the ghosts (ONE launch) — after it the first / last owned plane of r are those of the new residual and the exchange may start —, part 1 = the planes
+// in between + what k2 does after its launch.  The transfer then has K2's bulk AND the next K1's bulk to hide behind (K1's alone: 99 us per rank of
+// 8 on 512^3, about what 2 x 2.2 MB over one xGMI link each take).  Sessions whose K2 cannot be split run all of it in part 0 and nothing in part 1,
+// so a driver may always call 0, post, 1.
+extern "C" int pdegpu_session_can_split_k2(const pdegpu_session* s) { return (s && k2_splittable(s)) ? 1 : 0; }
+extern "C" int pdegpu_session_k2_part(pdegpu_session* s, int part) {
+    if (!s || (part != 0 && part != 1)) return PDEGPU_EINVAL;
+    if (!k2_splittable(s)) return part == 0 ? pdegpu_session_k2(s) : PDEGPU_OK;
+    PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    const GridDev& g = s->g;
+    const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;
+    const DotIn di = s->variant ? sr_dot_in(s) : DotIn();
+    double* part_out = s->variant ? s->d_part + s->npart : s->d_part;
+    LaunchInfo li;
+    if (part == 0) {
+        int e0[2] = {0, lo ? 1 : 0}, e1[2] = {hi ? std::max(g.nkl - 1, lo ? 1 : 0) : 0, hi ? g.nkl : 0};
+        if (e0[1] <= e0[0]) { e0[0] = e1[0]; e0[1] = e1[1]; e1[0] = e1[1] = 0; }
+        s->k2_parts = 0;
+        if (e0[1] > e0[0]) {
+            const int at = timed_begin(s, 1);
+            PG_TRY(op_k2(s, &li, di, part_out, e0[0], e0[1], e1[0], e1[1]));
+            timed_end(s, at);
+            s->k2_parts = li.grid;
+        }
+        return PDEGPU_OK;
+    }
+    const int a0 = lo, a1 = g.nkl - hi;
+    if (a1 > a0) {
+        LaunchInfo dry;
+        dry.dry = true;
+        PG_TRY(op_k2(s, &dry, di, part_out + s->k2_parts, a0, a1));
+        if (s->k2_parts + dry.grid > s->npart)
+            return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "split K2: %d + %d workgroups exceed the %d partials of the session", s->k2_parts, dry.grid, s->npart);
+        const int at = timed_begin(s, 1);
+        PG_TRY(op_k2(s, &li, di, part_out + s->k2_parts, a0, a1));
+        timed_end(s, at);
+        s->k2_parts += li.grid;
+    }
+    if (s->timing && s->timing_now) ++s->timed_k2;
+    if (s->variant) {
+        s->sr_k2_pending = true;
+        s->sr_k2_grid = s->k2_parts;
+        return PDEGPU_OK;
+    }
+    return vec_reduce(s->ctx, s->d_part, s->k2_parts, s->d_scal, 1, 1);
 }
 
 // single-reduction form: r.r of the residual the last k2 left -> scalars[6] (this slab's sum; the multi-GPU host all-reduces that one slot, 8
@@ -1130,8 +1190,8 @@ namespace {
 int session_exchange_post(pdegpu_session* s, pdegpu_comm* c, int what, int x_planes, int lo_rank, int hi_rank) {
     const GridDev& g = s->g;
     const bool lo = g.k0 > 0, hi = g.k0 + g.nkl < g.NZ;
-    if (lo_rank < 0) lo_rank = comm_rank(c) - 1;
-    if (hi_rank < 0) hi_rank = comm_rank(c) + 1;
+    if (lo_rank < 0) lo_rank = comm_rank(c) - (comm_self_loop(c) ? 0 : 1);
+    if (hi_rank < 0) hi_rank = comm_rank(c) + (comm_self_loop(c) ? 0 : 1);
     double* vecs[2];
     int nv = 0;
     if (x_planes) {
@@ -1193,14 +1253,23 @@ extern "C" int pdegpu_session_allreduce(pdegpu_session* s, pdegpu_comm* c, int f
 extern "C" int pdegpu_session_iterate_slab(pdegpu_session* s, pdegpu_comm* c, int iters) {
     if (!s || !c || iters < 0) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    const bool multi = comm_world(c) > 1;
+    const bool multi = comm_world(c) > 1 || comm_self_loop(c);
+    bool posted = false;                     // the exchange this iteration's K1 needs went out in the middle of the previous K2
     for (int it = 0; it < iters; ++it) {
-        if (multi) PG_TRY(pdegpu_session_exchange_begin(s, c, 0));
+        if (multi && !posted) PG_TRY(pdegpu_session_exchange_begin(s, c, 0));
+        posted = false;
         PG_TRY(pdegpu_session_k1_part(s, 0));
         if (multi) PG_TRY(pdegpu_session_exchange_end(s, c));
         PG_TRY(pdegpu_session_k1_part(s, 1));
         PG_TRY(comm_allreduce(c, s->d_scal + SC_PQ, s->variant ? 3 : 1, s->ctx->stream));
-        PG_TRY(pdegpu_session_k2(s));
+        if (multi && it + 1 < iters) {       // (the last K2 of a chunk posts nothing: no exchange stays in flight across calls)
+            PG_TRY(pdegpu_session_k2_part(s, 0));
+            PG_TRY(pdegpu_session_exchange_begin(s, c, 0));
+            posted = true;
+            PG_TRY(pdegpu_session_k2_part(s, 1));
+        } else {
+            PG_TRY(pdegpu_session_k2(s));
+        }
         if (!s->variant) PG_TRY(comm_allreduce(c, s->d_scal + SC_RR, 1, s->ctx->stream));
     }
     return PDEGPU_OK;

@@ -120,6 +120,8 @@ SYMBOLS = {
     "pdegpu_session_k2": (C.c_int, [_vp]),
     "pdegpu_session_can_split_k1": (C.c_int, [_vp]),
     "pdegpu_session_k1_part": (C.c_int, [_vp, C.c_int]),
+    "pdegpu_session_can_split_k2": (C.c_int, [_vp]),
+    "pdegpu_session_k2_part": (C.c_int, [_vp, C.c_int]),
     "pdegpu_session_set_cg_variant": (C.c_int, [_vp, C.c_int]),
     "pdegpu_session_cg_variant": (C.c_int, [_vp]),
     "pdegpu_session_sr_poll": (C.c_int, [_vp]),
@@ -128,6 +130,7 @@ SYMBOLS = {
     "pdegpu_comm_destroy": (None, [_vp]),
     "pdegpu_comm_rank": (C.c_int, [_vp]),
     "pdegpu_comm_world": (C.c_int, [_vp]),
+    "pdegpu_comm_set_self_loop": (C.c_int, [_vp, C.c_int]),
     "pdegpu_comm_group_begin": (C.c_int, [_vp]),
     "pdegpu_comm_group_end": (C.c_int, [_vp]),
     "pdegpu_session_exchange_post": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -83,6 +83,10 @@ class NativeComm:
             self.lib.pdegpu_comm_destroy(self.h)
             self.h = None
 
+    def set_self_loop(self, on: bool):
+        """one-GPU rehearsal: the slab's two neighbours are this rank itself (real messages, meaningless iterates)"""
+        L.check(self.ctx, self.lib.pdegpu_comm_set_self_loop(self.h, 1 if on else 0))
+
     def group_begin(self):
         L.check(self.ctx, self.lib.pdegpu_comm_group_begin(self.h))
 
@@ -149,6 +153,13 @@ class GpuSlabEngine:
 
     def k2(self):
         self._ck(self.lib.pdegpu_session_k2(self.s))
+
+    def k2_part(self, part: int):
+        """part 0: the planes next to the ghosts (then the next exchange may be posted); part 1: the rest.  Unsplittable sessions: all in part 0."""
+        self._ck(self.lib.pdegpu_session_k2_part(self.s, part))
+
+    def can_split_k2(self) -> bool:
+        return bool(self.lib.pdegpu_session_can_split_k2(self.s))
 
     def flush(self):
         self._ck(self.lib.pdegpu_session_flush(self.s))
@@ -491,7 +502,11 @@ class SlabCG:
             self.e.iterate_slab(self.comm, iters)      # the same sequence, issued from C
             self.iterations += iters
             return
-        for _ in range(iters):
+        # engines that can run K2 in two parts: the NEXT iteration's exchange goes out between them, as soon as the planes it carries are final,
+        # and hides behind K2's bulk as well as K1's; nothing stays in flight across calls (the last K2 of a chunk posts nothing)
+        early = split and pre is None and self.world > 1 and hasattr(self.e, "k2_part")
+        posted = None
+        for i in range(iters):
             if pre is not None:
                 pre()
                 token = self.exchange_begin()
@@ -499,7 +514,8 @@ class SlabCG:
                 self.exchange_end(token)
                 self.e.k1_part(1)
             elif split:
-                token = self.exchange_begin()
+                token = posted if posted is not None else self.exchange_begin()
+                posted = None
                 self.e.k1_part(0)
                 self.exchange_end(token)
                 self.e.k1_part(1)
@@ -507,7 +523,12 @@ class SlabCG:
                 self.exchange_halos()
                 self.e.k1()
             self.allreduce(0)                 # sr: {p.Ap, r.r, Ap.Ap} in one message; classic: p.Ap
-            self.e.k2()
+            if early and i + 1 < iters:
+                self.e.k2_part(0)
+                posted = self.exchange_begin()
+                self.e.k2_part(1)
+            else:
+                self.e.k2()
             if not self.sr:
                 self.allreduce(1)
         self.iterations += iters

@@ -211,6 +211,27 @@ class NumpySlabEngine:
         else:
             self._reduce_rr(float((r[self.own] ** 2).sum()))
 
+    def k2_part(self, part):
+        """the split K2 of the HIP session: part 0 = the planes next to the ghosts (after it the driver posts the next exchange: what travels must be
+        final here), part 1 = the planes in between + the r.r sum"""
+        lo = 1 if self.k0 > 0 else 0
+        hi = 1 if self.k0 + self.nk < self.NZ else 0
+        edges = sorted(set(([0] if lo else []) + ([self.nk - 1] if hi else [])))
+        r, q = self.r.numpy(), self.q.numpy()
+        if part == 0:
+            pq, rr = float(self.scal[SC_PQ]), float(self.scal[SC_RR])
+            self._k2_alpha = rr / pq if pq > 0 else 0.0
+            for lk in edges:
+                r[1 + lk] -= self._k2_alpha * q[1 + lk]
+            return
+        for lk in range(self.nk):
+            if lk not in edges:
+                r[1 + lk] -= self._k2_alpha * q[1 + lk]
+        if self.sr:
+            self._k2_rr = float((r[self.own] ** 2).sum())
+        else:
+            self._reduce_rr(float((r[self.own] ** 2).sum()))
+
     def flush(self):
         pq, rr_prev = float(self.scal[SC_PQ]), float(self.scal[SC_RR if self.sr else SC_RR_PREV])
         alpha = rr_prev / pq if (pq > 0 and rr_prev > 0) else 0.0

@@ -461,8 +461,19 @@ def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs,
                     for e in engs:
                         e.k1()
                 allreduce(0, (SC_PQ, SC_QQ + 1) if sr else None)      # sr: {p.Ap, r.r, Ap.Ap} in ONE message
-                for e in engs:
-                    e.k2()
+                if split:
+                    # K2 in two parts (the next exchange is posted between them): after part 0 the planes that travel are final
+                    assert all(e.can_split_k2() == (fast == 1 and variant == 1) for e in engs)
+                    for e in engs:
+                        e.k2_part(0)
+                    sent = [(e, w, e.plane_tensor(VEC_R, w).clone()) for e in engs
+                            for w in ((0,) if e.k0 > 0 else ()) + ((e.nk - 1,) if e.k0 + e.nk < n[2] + 1 else ())] if it % 25 == 0 else []
+                    for e in engs:
+                        e.k2_part(1)
+                    assert all(torch.equal(t, e.plane_tensor(VEC_R, w)) for e, w, t in sent)
+                else:
+                    for e in engs:
+                        e.k2()
                 if not sr:
                     allreduce(1)
                 if it < 6:

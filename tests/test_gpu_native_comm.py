@@ -71,11 +71,14 @@ def test_comm_argument_checks(lib, gpu_ctx):
     lib.pdegpu_comm_destroy(None)
 
 
-def test_two_heat_slabs_exchanging_through_the_library_communicator(lib, gpu_ctx):
+@pytest.mark.parametrize("early", [False, True])
+def test_two_heat_slabs_exchanging_through_the_library_communicator(lib, gpu_ctx, early):
     """two slab sessions of ONE process, ghost planes as RCCL sends to self on the communicator's own stream (one ncclGroup per exchange, posted
     through pdegpu_session_exchange_post), the overlapped order of pdegpu_session_iterate_slab: exchange posted, K1 away from the ghosts, wait
     (stream-ordered), edge planes, the 24-byte block through the communicator's all-reduce, K2.  A receive that landed late, or early into planes
-    part 0 still reads, would change the iterates: the residual history must be the single slab's."""
+    part 0 still reads, would change the iterates: the residual history must be the single slab's.  early: the order inside a chunk of
+    pdegpu_session_iterate_slab — K2 in two parts, the NEXT iteration's exchange posted between them (after the planes next to the ghosts, while K2's
+    bulk still writes the planes in between), waited for in the middle of the next K1."""
     import torch
     from pdegpu.dist import GpuSlabEngine, NativeComm, SlabCG, slab_range, SC_PQ, SC_QQ, SC_RR, SC_RR_POLL
     n, grid, h = _heat_case()
@@ -114,9 +117,7 @@ def test_two_heat_slabs_exchanging_through_the_library_communicator(lib, gpu_ctx
             lo.plane_tensor(1, lo.nk).fill_(float("nan"))
             hi.plane_tensor(1, -1).fill_(float("nan"))
 
-        sum_over_slabs(SC_RR, SC_RR + 1)
-        hist = [rr_now()]
-        for it in range(40):
+        def post_exchange():
             poison_ghosts()                                      # only the exchange may make them finite again
             comm.group_begin()
             lo.comm_exchange_post(comm, 1, hi_rank=0)            # send order == receive order: sends to self match first-in first-out
@@ -124,14 +125,31 @@ def test_two_heat_slabs_exchanging_through_the_library_communicator(lib, gpu_ctx
             hi.comm_exchange_post(comm, 1, lo_rank=0)
             lo.comm_exchange_post(comm, 2, hi_rank=0)
             comm.group_end()
+
+        sum_over_slabs(SC_RR, SC_RR + 1)
+        hist = [rr_now()]
+        assert all(e.can_split_k2() for e in engs)
+        posted = False
+        for it in range(40):
+            if not posted:
+                post_exchange()
+            posted = False
             for e in engs:
                 e.k1_part(0)
             lo.comm_exchange_end(comm)                           # (both sessions enqueue on the same stream)
             for e in engs:
                 e.k1_part(1)
             sum_over_slabs(SC_PQ, SC_QQ + 1)
-            for e in engs:
-                e.k2()
+            if early and it % 5 != 4:                            # (a poll follows every 5th K2: nothing in flight across it, as at the end of a chunk)
+                for e in engs:
+                    e.k2_part(0)
+                post_exchange()
+                posted = True
+                for e in engs:
+                    e.k2_part(1)
+            else:
+                for e in engs:
+                    e.k2()
             if it % 5 == 4:
                 hist.append(rr_now())
         comm.close()
