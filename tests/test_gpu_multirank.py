@@ -63,3 +63,18 @@ def test_multi_process_elasticity_slabs(lib, gpu_ctx):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "REHEARSAL OK" in out.stdout
+
+
+def test_library_communicator_rendezvous_across_processes(lib, gpu_ctx):
+    """the multi-process side of csrc/comm.hip as far as one GPU lets it go: two processes make / carry the unique id and call pdegpu_comm_create(rank, 2)
+    on the same device — RCCL's bootstrap runs for real, then refuses the duplicate device: the refusal must come back as an error on BOTH ranks (no hang);
+    where a RCCL build accepts it, the slab CG runs over it and must reproduce the staged run (tools/rehearse_native_comm.py decides)"""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tools" / "rehearse_native_comm.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "RENDEZVOUS REFUSED (duplicate device) OK" in out.stdout or "RENDEZVOUS RAN OK" in out.stdout
