@@ -331,7 +331,8 @@ int  pdegpu_session_k1_part(pdegpu_session* s, int part);
 /* K2 in two steps, so that the NEXT iteration's exchange is posted as soon as its planes are final: part 0 = the one or two planes next to the
  * ghosts (one launch) — after it the first / last owned plane of r belong to the new residual: post the exchange —, part 1 = the planes in between
  * + k2's reduce (classic form).  The transfer then hides behind K2's bulk and the next K1's bulk (pdegpu_session_iterate_slab and pdegpu.dist.SlabCG do
- * this inside a chunk of iterations).  can_split_k2 = 1 for marching sessions whose K2 is the stencil form, on a slab with a neighbour; other
+ * this inside a chunk of iterations).  can_split_k2 = 1 for marching sessions whose K2 is the stencil form, on a slab with a neighbour, thin enough for the
+ * exchange to need more than K1's bulk to hide behind (K1 bulk estimate < 4 plane transfers: ranks of 4 and 8 on 512^3; the split costs a launch); other
  * sessions run all of K2 in part 0 and nothing in part 1, so a driver may always call 0, post, 1. */
 int  pdegpu_session_can_split_k2(const pdegpu_session* s);
 int  pdegpu_session_k2_part(pdegpu_session* s, int part);

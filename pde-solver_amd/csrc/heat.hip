@@ -810,9 +810,15 @@ void timed_iteration(pdegpu_session* s) {
 }
 // a K1 that can be split into plane ranges: marching kernel alone (no boundary pass, no one-round tiles), 3-D
 bool k1_splittable(const pdegpu_session* s) { return s->fast && !s->hybrid && !s->tile3d && !s->plane2d && s->g.dim == 3 && !s->weighted; }
-// K2 on plane ranges: the marching stencil form of K2 (r -= alpha A p recomputed) on a slab with a neighbour
+// K2 on plane ranges: the marching stencil form of K2 (r -= alpha A p recomputed) on a slab with a neighbour — where it pays: the split costs one
+// more launch (7 us) and buys the exchange K2's bulk to hide behind in addition to K1's.  A plane travels in about 8 B/node / 45 GB/s of one xGMI link
+// + 20 us; K1's bulk streams 40 B/node at about 6 TB/s.  Slabs whose K1 bulk is shorter than four such transfers split (ranks of 4 and 8 on 512^3 /
+// 1024x512x512: 128 and 64 planes), thicker ones hide the exchange behind K1 alone with room to spare and keep K2 in one launch.
 bool k2_splittable(const pdegpu_session* s) {
-    return k1_splittable(s) && k2_is_stencil(s) && (s->g.k0 > 0 || s->g.k0 + s->g.nkl < s->g.NZ);
+    if (!k1_splittable(s) || !k2_is_stencil(s) || !(s->g.k0 > 0 || s->g.k0 + s->g.nkl < s->g.NZ)) return false;
+    const double k1_bulk_us = (double)s->g.nkl * (double)s->g.PP * 40.0 / 6.0e6;
+    const double transfer_us = (double)s->g.PP * 8.0 / 45.0e3 + 20.0;
+    return k1_bulk_us < 4.0 * transfer_us;
 }
 }  // namespace
 

@@ -605,13 +605,16 @@ def longest_axis_last(n_cells, lengths):
 
 def solve_heat_slabs(n_cells, lengths, diffusivity: float, T_boundary: float, T_initial: float = 0.0, dt: float = 0.0,
                      num_steps: int = 0, steady: bool = False, source: float = 0.0, rtol: float = 1e-10, max_iter: int = 100000,
-                     snapshot_stride: int = 1, group=None, engine_factory=None, permute: bool = True):
+                     snapshot_stride: int = 1, group=None, engine_factory=None, permute: bool = True, transport: str = "torch"):
     """`_solve_heat_3d_raw` (box, uniform Dirichlet value; fenics_mcp_server.py:475-762) over the ranks of the default process
     group, one slab per GPU: the backward-Euler loop (:702-716) with one x-halo exchange per step, the CG of every step through
     SlabCG.  Rank 0 returns {"values": [n_snap, nz+1, ny+1, nx+1] in the caller's axis order, "times", "iterations"}; the other
     ranks the iteration counts only.  engine_factory(grid_n, grid_L, heat_kwargs, k0, nk) -> engine replaces the HIP session
-    (the CPU test-suite passes the numpy engine)."""
+    (the CPU test-suite passes the numpy engine).  transport: "torch" — exchange and all-reduces through torch.distributed on `group` — or "library": issued by
+    libpdegpu on its own RCCL communicator (NativeComm; HIP engines, backend nccl or a single rank)."""
     import numpy as np
+    if transport not in ("torch", "library"):
+        raise ValueError(f"transport must be torch or library, got {transport!r}")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     perm = [0, 1, 2]
@@ -638,7 +641,15 @@ def solve_heat_slabs(n_cells, lengths, diffusivity: float, T_boundary: float, T_
         eng = GpuSlabEngine(grid, heat, k0, nk, local, stream)
 
     def run():
-        cg = SlabCG(eng, rank, world, group)
+        comm = NativeComm(eng, rank, world, group) if transport == "library" else None
+        try:
+            return run_with(comm)
+        finally:
+            if comm is not None:
+                comm.close()
+
+    def run_with(comm):
+        cg = SlabCG(eng, rank, world, group, comm=comm)
         snaps, times, iters = [], [], []
 
         def snapshot(t):
@@ -678,11 +689,14 @@ def solve_heat_slabs(n_cells, lengths, diffusivity: float, T_boundary: float, T_
     return out
 
 
-def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int = 400000, group=None):
-    """3-D static elasticity (config 5) over the ranks of the default process group, one z-slab per GPU:
-    Jacobi-PCG with halo exchange of z, p and 8-/16-byte all-reduces; every rank returns the iteration count, rank 0
-    additionally the gathered displacement [N,3] and the projected von Mises field [N] (post-processing on its GPU)."""
+def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int = 400000, group=None, transport: str = "torch"):
+    """3-D static elasticity (config 5) over the ranks of the default process group, one z-slab per GPU: single-reduction Jacobi-PCG, halo
+    exchange of r (three component planes per neighbour) inside k1, ONE 32-byte all-reduce per iteration; every rank returns the iteration
+    count, rank 0 additionally the gathered displacement [N,3] and the projected von Mises field [N] (post-processing on its GPU).
+    transport: "torch" (torch.distributed on `group`) or "library" (libpdegpu's own RCCL communicator, see solve_heat_slabs)."""
     import numpy as np
+    if transport not in ("torch", "library"):
+        raise ValueError(f"transport must be torch or library, got {transport!r}")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     local = int(L.os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
@@ -693,7 +707,8 @@ def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int 
     stream = torch.cuda.Stream(device=local)
     with torch.cuda.stream(stream):
         eng = GpuElasticitySlabEngine(grid, el, k0, nk, local, stream)
-        cg = SlabCG(eng, rank, world, group)
+        comm = NativeComm(eng, rank, world, group) if transport == "library" else None
+        cg = SlabCG(eng, rank, world, group, comm=comm)
         cg.start(0.0)
         rr0 = eng.rr()
         it, chunk = 0, 16
@@ -713,5 +728,7 @@ def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int 
             ctx = eng.ctx
             L.check(ctx, eng.lib.pdegpu_elasticity_postprocess(ctx, grid, el, L.dptr(u), L.dptr(field)))
             out.update(displacement=u, field=field)
+        if comm is not None:
+            comm.close()
         eng.close()
     return out

@@ -222,8 +222,10 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split, sr):
     assert rel_err(field, ref.values[0]) < TOL
 
 
-def test_solve_elasticity_slabs_single_rank(lib, gpu_ctx):
-    """the rank-level driver (what each process runs under torch.distributed) with world size 1"""
+@pytest.mark.parametrize("transport", ["torch", "library"])
+def test_solve_elasticity_slabs_single_rank(lib, gpu_ctx, transport):
+    """the rank-level driver (what each process runs under torch.distributed) with world size 1; "library": the PCG chunks are single C calls
+    (pdegpu_el_session_iterate_slab) on a one-rank RCCL communicator of the library's own"""
     from pdegpu import _lib
     from pdegpu.dist import solve_elasticity_slabs
     n, Ls = (16, 4, 4), (1.0, 0.25, 0.25)
@@ -231,7 +233,7 @@ def test_solve_elasticity_slabs_single_rank(lib, gpu_ctx):
     el = _lib.Elasticity()
     el.E, el.nu = 210e9, 0.3
     el.body[2] = -76518.0
-    out = solve_elasticity_slabs(grid, el, n, rtol=1e-12)
+    out = solve_elasticity_slabs(grid, el, n, rtol=1e-12, transport=transport)
     ref = o.solve_elasticity_3d(*Ls, *n, 210e9, 0.3, 0.0, 0.0, -76518.0, "stress")
     assert rel_err(out["displacement"], ref.extra["displacement"]) < TOL and rel_err(out["field"], ref.values[0]) < TOL
 

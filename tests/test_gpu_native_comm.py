@@ -227,3 +227,19 @@ def test_two_elasticity_slabs_exchanging_through_the_library_communicator(lib, g
             e.close()
     ref = o.solve_elasticity_3d(*Ls, *n, E, nu, *body, "stress")
     assert rel_err(u, ref.extra["displacement"]) < 1e-8
+
+
+@pytest.mark.parametrize("steady", [True, False])
+def test_solve_heat_slabs_with_the_library_transport(lib, gpu_ctx, steady):
+    """the tool-level distributed solve on one rank with transport="library": chunks of CG iterations as single C calls, convergence polls and (transient)
+    the x-halo step set-up through the communicator; against the single-GPU tool.  The box's longest axis is x: the slabs cut it (axes relabelled)."""
+    from pdegpu import heat
+    from pdegpu.dist import solve_heat_slabs
+    m, Ls = (36, 12, 13), (1.5, 0.5, 0.6)
+    kw = dict(steady=True) if steady else dict(T_initial=20.0, dt=0.01, num_steps=3)
+    out = solve_heat_slabs(m, Ls, 1.3, 0.5, source=2.0, rtol=1e-12, transport="library", **kw)
+    one = heat._solve_heat_3d_raw(*Ls, *m, 1.3, 0.5, 20.0, 0.01, 3, steady=steady, source_type="constant", source_value=2.0, rtol=1e-12)
+    got = out["values"].reshape(one.values.shape)
+    assert rel_err(got, one.values) < 1e-9 and np.allclose(out["times"], one.times)
+    with pytest.raises(ValueError):
+        solve_heat_slabs(m, Ls, 1.3, 0.5, steady=True, transport="mpi")
