@@ -49,7 +49,8 @@ RcclApi* rccl_api() {
             if (api.handle) break;
         }
     if (!api.handle) {
-        api.error = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "unknown");
+        const char* why = dlerror();                          // (a second call would return NULL: dlerror clears its state)
+        api.error = std::string("librccl.so.1 cannot be loaded: ") + (why ? why : "unknown");
         return &api;
     }
     auto sym = [&](const char* n) {

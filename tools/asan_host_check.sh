@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../pde-solver_amd"
 rm -rf build_asan && mkdir -p build_asan
-for f in tridiag tables stencil vecops heat elasticity weighted persist2d; do
+for f in tridiag tables stencil vecops heat elasticity weighted persist2d comm; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address -fno-omit-frame-pointer -c csrc/$f.hip -o build_asan/$f.o
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address build_asan/*.o -o build_asan/libpdegpu_asan.so
@@ -44,6 +44,10 @@ g4 = (C.c_int32 * 4)()
 assert lib.pdegpu_marching_geometry(256, 513, 513, 513, 2, 3, g4) == 0
 h = L.Heat(); h.num_steps = 200; h.snapshot_stride = 7
 assert lib.pdegpu_heat_num_snapshots(h) == 30
+# the communicator's argument checks (no GPU: nothing is created)
+assert lib.pdegpu_comm_unique_id(None) == L.EINVAL and lib.pdegpu_comm_rank(None) == -1 and lib.pdegpu_comm_world(None) == -1
+assert lib.pdegpu_comm_set_self_loop(None, 1) == L.EINVAL and lib.pdegpu_session_iterate_slab(None, None, 1) == L.EINVAL
+lib.pdegpu_comm_destroy(None)
 ctx = C.c_void_p()
 assert lib.pdegpu_create(C.byref(ctx), 0, None) in (0, -4)
 print("ASan host pass OK")
