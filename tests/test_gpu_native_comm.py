@@ -243,3 +243,55 @@ def test_solve_heat_slabs_with_the_library_transport(lib, gpu_ctx, steady):
     assert rel_err(got, one.values) < 1e-9 and np.allclose(out["times"], one.times)
     with pytest.raises(ValueError):
         solve_heat_slabs(m, Ls, 1.3, 0.5, steady=True, transport="mpi")
+
+
+def test_exchange_begin_end_move_the_right_planes(lib, gpu_ctx):
+    """pdegpu_session_exchange_begin / _end as pdegpu_session_iterate_slab and SlabCG call them (default peers, one group, both directions), on an interior
+    slab in the communicator's rehearsal mode (both neighbours = this rank): the first / last owned plane must arrive in the slab's own lower / upper ghost
+    plane — r (CG exchange), x (the step set-up of a transient solve, x_planes) and the three component planes of the elasticity residual."""
+    import torch
+    from pdegpu import _lib
+    from pdegpu.dist import GpuSlabEngine, GpuElasticitySlabEngine, NativeComm, VEC_X, VEC_R
+    n, grid, h = _heat_case()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        eng = GpuSlabEngine(grid, h, 5, 9, 0, stream)                      # planes 5 .. 13 of 28: a neighbour on both sides
+        comm = NativeComm(eng, 0, 1)
+        comm.set_self_loop(True)
+        eng.begin(0.0)
+        eng.residual()
+        for vec, x_planes in ((VEC_R, False), (VEC_X, True)):
+            own = [eng.plane_tensor(vec, w) for w in (0, eng.nk - 1)]
+            ghost = [eng.plane_tensor(vec, w) for w in (-1, eng.nk)]
+            for k, t in enumerate(own):
+                t.copy_(torch.arange(t.numel(), dtype=torch.float64, device=t.device) * (k + 1) + 0.5)
+            for t in ghost:
+                t.fill_(float("nan"))
+            eng.comm_exchange_begin(comm, x_planes)
+            eng.comm_exchange_end(comm)
+            torch.cuda.synchronize()
+            assert torch.equal(ghost[0], own[0]) and torch.equal(ghost[1], own[1])
+        comm.close()
+        eng.close()
+        grid_e = _lib.make_grid(3, (14, 4, 13), (1.0, 0.3, 0.6))
+        el = _lib.Elasticity()
+        el.E, el.nu = 210e9, 0.3
+        el.body[2] = -76518.0
+        ee = GpuElasticitySlabEngine(grid_e, el, 4, 6, 0, stream)
+        comm = NativeComm(ee, 0, 1)
+        comm.set_self_loop(True)
+        ee.begin()
+        for c in range(3):
+            for k, w in enumerate((0, ee.nk - 1)):
+                t = ee.plane_tensor(1, c, w)
+                t.copy_(torch.arange(t.numel(), dtype=torch.float64, device=t.device) + 100.0 * c + 7.0 * k)
+            for w in (-1, ee.nk):
+                ee.plane_tensor(1, c, w).fill_(float("nan"))
+        ee.comm_exchange_begin(comm)
+        ee.comm_exchange_end(comm)
+        torch.cuda.synchronize()
+        for c in range(3):
+            assert torch.equal(ee.plane_tensor(1, c, -1), ee.plane_tensor(1, c, 0))
+            assert torch.equal(ee.plane_tensor(1, c, ee.nk), ee.plane_tensor(1, c, ee.nk - 1))
+        comm.close()
+        ee.close()
