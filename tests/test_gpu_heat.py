@@ -390,6 +390,18 @@ def test_fast_and_general_sessions_agree(lib, gpu_ctx):
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("sr", [False, True])
 def test_slabs_on_one_gpu_match_single_slab(lib, gpu_ctx, fast, variant, nslabs, split, sr):
+    _slab_case(lib, fast, variant, nslabs, split, sr)
+
+
+@pytest.mark.parametrize("nslabs", [6, 14])
+@pytest.mark.parametrize("sr", [False, True])
+def test_thin_slabs_of_one_to_three_planes(lib, gpu_ctx, nslabs, sr):
+    """14 planes over 6 (3, 3, 2, 2, 2, 2 planes) and 14 slabs (ONE plane each: a plane next to both ghosts): K1 and K2 in two parts where one part is
+    empty, the same plane the first and the last of its slab"""
+    _slab_case(lib, 1, 1, nslabs, True, sr)
+
+
+def _slab_case(lib, fast, variant, nslabs, split, sr):
     """slab sessions (k0 > 0, ghost planes, global boundary classes) with the halo exchange / all-reduce done by
     plain device copies on ONE GPU: same order of operations as pdegpu.dist.SlabCG.iterate, no RCCL needed.
     Must reproduce the single-slab CG iterates and the oracle's solution.  sr: the single-reduction recurrences — ONE message
