@@ -144,6 +144,17 @@ def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("sr", [True, False])
 def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split, sr):
+    _el_slab_case(lib, gpu_ctx, nslabs, split, sr)
+
+
+@pytest.mark.parametrize("nslabs,split", [(7, False), (14, False), (3, True)])
+def test_elasticity_thin_slabs(lib, gpu_ctx, nslabs, split):
+    """14 planes as 7 slabs of two planes and 14 slabs of ONE plane (a plane next to both ghosts; slabs that own nothing but a face of the box), and the
+    split apply on slabs of 4-5 planes (the smallest it accepts)"""
+    _el_slab_case(lib, gpu_ctx, nslabs, split, True)
+
+
+def _el_slab_case(lib, gpu_ctx, nslabs, split, sr):
     """the multi-GPU elasticity path on ONE GPU: slab sessions (ghost planes, global boundary classes), halo exchange of r (3 component
     planes; p on the ghost planes is maintained by k1) and the scalar all-reduces done by device copies in the order pdegpu.dist.SlabCG
     uses — split: k1 in two parts with the exchange in between (the overlapped order), the ghost planes of r poisoned while part 0 runs;
@@ -187,7 +198,7 @@ def test_elasticity_slab_sessions_on_one_gpu(lib, gpu_ctx, nslabs, split, sr):
         it = 0
         while it < 6000:
             for _ in range(50):
-                assert all(e.can_split_k1() == (split and nslabs > 1) for e in engs)
+                assert all(e.can_split_k1() == (split and nslabs > 1 and e.nk >= 4) for e in engs)
                 if sr or split:
                     for e in engs:                        # the receives have not landed yet: nothing before the exchange may read a ghost plane of r
                         e.k1_pre()                        # (sr: the update pass of the owned planes — r changes here; classic: nothing)
