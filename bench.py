@@ -187,6 +187,8 @@ class Runner:
         grid = L.make_grid(3, (nx, ny, nz), case["L"])
         heat = L.Heat()
         heat.kappa, heat.dt, heat.steady, heat.source = 1.0, 0.0, 1, 1.0
+        if case.get("transient_dt"):                       # the system of one backward-Euler step: A = M + dt kappa K (15-point on the Kuhn split)
+            heat.dt, heat.steady = float(case["transient_dt"]), 0
         heat.bc_mode, heat.fast_path = L.BC_UNIFORM, 0 if self.args.general else 1
         heat.bc_present[0] = 1
         unknowns = (nx - 1) * (ny - 1) * (nz - 1)
@@ -207,6 +209,10 @@ class Runner:
                 ms = C.c_double()
                 L.check(eng.ctx, eng.lib.pdegpu_session_time_apply(eng.s, max(50, 2 * self.args.ceiling_reps), C.byref(ms)))
                 res["ceilings"], res["spmv_ms"] = ceil, ms.value
+            elif case.get("spmv"):
+                ms = C.c_double()
+                L.check(eng.ctx, eng.lib.pdegpu_session_time_apply(eng.s, max(50, 2 * self.args.ceiling_reps), C.byref(ms)))
+                res["spmv_ms"] = ms.value
             cg.start(0.0)
             cg.iterate(warmup)
             self.fence()
@@ -469,6 +475,25 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             R.dist.destroy_process_group()
         except Exception as e:
             extras["collective_calls_one_rank"] = {"failed": repr(e)}
+    if world == 1:
+        # the system of a backward-Euler step (fenics_mcp_server.py:702-716): A = M + dt kappa K, 15-point on the Kuhn split — bare SpMV and the CG
+        # iteration (K1 stores q there: 72 B/DoF; the second stencil pass of the 64-byte form costs more than it saves with 15 points)
+        try:
+            c5 = dict(case)
+            c5.update(transient_dt=0.0025, spmv=True)
+            st5 = max(20, args.steps // 2)
+            r5 = R.run_case(c5, st5, max(5, args.warmup // 2))
+            sp = r5["spmv_ms"]
+            extras["transient_step_system"] = {
+                "what": "same grid, A = M + dt kappa K with dt = 0.0025 (one backward-Euler step of the reference's default transient solve): "
+                        "15-point stencil; CG iteration = K1 (48 B/DoF, q stored) + K2 (24 B/DoF)",
+                "steps": st5, "value": r5["unknowns"] * st5 / r5["elapsed"], "unit": "DoF/s", "ms_per_step": r5["elapsed"] / st5 * 1e3,
+                "k1_ms": r5["k1_ms"], "k2_ms": r5["k2_ms"], "k1_bytes_per_dof": r5["k1_per_dof"],
+                "k1_frac": float(r5["k1_per_dof"]) * r5["unknowns"] / (r5["k1_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "spmv_15pt": {"avg_ms": sp, "achieved": 16.0 * r5["unknowns"] / (sp * 1e-3) / 1e9,
+                              "frac": 16.0 * r5["unknowns"] / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS}, "rr_after": r5["rr_after"]}
+        except Exception as e:
+            extras["transient_step_system"] = {"failed": repr(e)}
     if world == 1 and not args.no_tool_extras:
         # end-to-end cost of the tool boundary at BASELINE's sizes: wall time of the reference-named solver (_solve_heat_3d_raw: kwargs in,
         # numpy field out) against the device time of its solve, then the pickle hand-off and the plot tool
