@@ -1104,11 +1104,11 @@ int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* 
     int nt = ctx->fast_nt;
     if (nt < 0) nt = ((long long)a.g.nkl * a.g.PP * 8 > (64LL << 20)) ? 3 : 0;
     const ModeCfg mc = mode_cfg(ctx, mode);
-    // deeper prefetch: one-vector modes of the 7- and the 15-point operator, RY <= 4 (15 points, 512^3 bare apply, one box, interleaved: 0.433-0.449 ->
-    // 0.403-0.407 ms with 4 rows per thread; 2 rows: 0.556 -> 0.444)
-    const bool pf = mc.pf && (NPT == 7 || NPT == 15) && RY <= 4;
+    // deeper prefetch: one-vector modes of every operator, RY <= 4 (512^3 bare apply, one box, interleaved, 4 rows per thread: 15 points 0.433-0.449 ->
+    // 0.403-0.407 ms; 27 points (Q1) 0.535-0.560 -> 0.414-0.418 ms; no spill: 117-119 / 149-173 VGPRs)
+    const bool pf = mc.pf && RY <= 4;
     if (mc.ex) {
-        if constexpr ((NPT == 7 || NPT == 15) && RY <= 4) {
+        if constexpr (RY <= 4) {
             if (pf) return (nt & 3) == 3 ? launch_fast<NPT, RY, 3, 1, 1>(ctx, a, mode, li) : launch_fast<NPT, RY, 0, 1, 1>(ctx, a, mode, li);
         }
         switch (nt & 3) {
@@ -1116,7 +1116,7 @@ int launch_fast_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* 
             default: return launch_fast<NPT, RY, 0, 1, 0>(ctx, a, mode, li);
         }
     }
-    if constexpr ((NPT == 7 || NPT == 15) && RY <= 4) {
+    if constexpr (RY <= 4) {
         if (pf) return (nt & 3) == 3 ? launch_fast<NPT, RY, 3, 0, 1>(ctx, a, mode, li) : launch_fast<NPT, RY, 0, 0, 1>(ctx, a, mode, li);
     }
     switch (nt & 3) {

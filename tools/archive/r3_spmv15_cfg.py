@@ -12,11 +12,16 @@ grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0))
 stream = torch.cuda.Stream(device=0)
 unk = (n - 1) ** 3
 with torch.cuda.stream(stream):
-    for dt, label in ((0.0025, "15-point"), (0.0, "7-point")):
+    for dt, label in ((-1.0, "27-point (Q1)"), (0.0025, "15-point"), (0.0, "7-point")):
+        if dt < 0:
+            grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0), L.ELEM_Q1)
+            dt = 0.0
+        else:
+            grid = L.make_grid(3, (n, n, n), (1.0, 1.0, 1.0))
         h = L.Heat(); h.kappa, h.dt, h.steady, h.source = 1.0, dt, 0 if dt else 1, 1.0
         h.bc_mode, h.fast_path = L.BC_UNIFORM, 1; h.bc_present[0] = 1
         for rep in range(2):
-            for word in (-1, 4, 516, 2, 514, 1, 513):
+            for word in (-1, 4, 516, 2, 514):
                 eng = GpuSlabEngine(grid, h, 0, n + 1, 0, stream)
                 L.check(eng.ctx, eng.lib.pdegpu_set_tunable(eng.ctx, b"fast_cfg_plain", word))
                 ms = C.c_double()
