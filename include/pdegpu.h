@@ -162,6 +162,8 @@ const char* pdegpu_version(void);
  * hybrid_k2          | 1       | ... steady sessions on one slab use the 64 B/DoF form
  * direct_1d          | 1       | 1-D grids: Thomas recurrence inside one launch (0 = CG, diagnostic)
  * elasticity
+ * ell_compact        | 1       | weighted (curvilinear / composite) 3-D operators whose weight does not depend on one coordinate store the coefficient
+ *                    |         | rows of three representative planes / columns instead of one row per node (0 = one row per node)
  * el_fast            | 1       | 3-D: z-marching block stencil (0 = thread-per-node class-table kernel)
  * el_fast_ry         | 2       | rows per wavefront column (1|2)
  * el_fast_yx         | 1       | y-halo rows handed between the workgroup's waves through LDS

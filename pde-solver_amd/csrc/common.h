@@ -39,6 +39,8 @@ struct pdegpu_ctx {
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
+    int ell_compact = 1;        // weighted operators whose weight does not depend on one coordinate keep the coefficient rows of three representative
+                                // planes / columns instead of one row per node (0: always one row per node)
     int el_fast = 1;            // 3-D elasticity: 1 = z-marching block stencil (k_el_fast); 0 = thread-per-node class-table kernel
     int el_fast_yx = 1;         // k_el_fast: 1 = the 4 waves of a workgroup are y-neighbours and hand their y-halo rows through LDS
     int el_fast_xface = 1;      // k_el_fast: 1 = the x-face nodes (interior in y, z) are computed by the marching part (edge lanes carry the
@@ -232,6 +234,8 @@ struct StencilArgs {
     int lk_lo2 = 0, lk_hi2 = 0;   // ... and a second, disjoint plane range in the SAME launch (the two edge planes of a slab: one launch, not two)
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
+    int ell_mode;             // 0: one row per node; 1: rows of three planes only (slowest index 0 | interior | last: the weight does not depend on that
+                              // coordinate); 2: three rows per grid row (x index 0 | interior | last: the weight does not depend on x) — weighted.hip
 };
 
 struct LaunchInfo { int grid = 0; int block = 256; bool dry = false; /* marching kernels: report the grid, launch nothing */ };
@@ -266,7 +270,7 @@ int vec_reduce_slot(pdegpu_ctx* ctx, const double* partials, int n, double* scal
 int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partials, LaunchInfo* li);
 // weighted.hip
 int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, const double* lengths, double cM,
-                      double cK, double* ellA, double* ellM, double* dinv, long long stride);
+                      double cK, double* ellA, double* ellM, double* dinv, long long stride, int ell_mode);
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
               double* partials, int use_alpha, LaunchInfo* li);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);

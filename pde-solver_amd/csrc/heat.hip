@@ -64,6 +64,7 @@ struct pdegpu_session {
     double *ell_base[3] = {nullptr, nullptr, nullptr};
     DevVec z;
     long long ell_stride = 0;
+    int ell_mode = 0;              // StencilArgs.ell_mode of the coefficient arrays
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -264,6 +265,7 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     if (s->weighted) {
         a.ell = which == 0 ? s->ellA : s->ellM;
         a.ell_stride = s->ell_stride;
+        a.ell_mode = s->ell_mode;
     }
     if (s->tile3d && mask && s->ctx->tile3d_plain) {            // bare SpMV of a tile session (masked: Dirichlet rows give 0)
         a.g = s->g;
@@ -299,6 +301,7 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     if (s->weighted) {
         a.ell = s->ellA;
         a.ell_stride = s->ell_stride;
+        a.ell_mode = s->ell_mode;
     }
     if (s->fast) {
         a.g = s->gk;
@@ -343,6 +346,7 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
     if (s->weighted) {
         a.ell = s->ellA;
         a.ell_stride = s->ell_stride;
+        a.ell_mode = s->ell_mode;
     }
     a.p_old = s->p[s->pcur].v;
     a.p_new = s->p[1 - s->pcur].v;
@@ -466,7 +470,7 @@ extern "C" const char* pdegpu_version(void) { return "pdegpu 0.1 (gfx950)"; }
 
 // every tunable of a context: PDEGPU_<KEY> in the environment at pdegpu_create, pdegpu_set_tunable afterwards (table in include/pdegpu.h)
 static const char* const kTunableKeys[] = {
-    "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
+    "ell_compact", "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
     "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
@@ -503,6 +507,7 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
 
 namespace {
 int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
+    if (!strcmp(key, "ell_compact")) return &ctx->ell_compact;
     if (!strcmp(key, "fast_ry")) return &ctx->fast_ry;
     if (!strcmp(key, "fast_nt")) return &ctx->fast_nt;
     if (!strcmp(key, "fast_ex")) return &ctx->fast_ex;
@@ -1510,19 +1515,33 @@ namespace {
 int session_make_weighted(pdegpu_session* s, const pdegpu_weight* w) {
     pdegpu_ctx* ctx = s->ctx;
     const long long n = (long long)s->g.nkl * s->g.PP;
-    const size_t sizes[3] = {(size_t)15 * n, (size_t)15 * n, (size_t)n};
+    // 3-D grids whose weight does not depend on one coordinate keep three representative rows along it instead of one per node: r^2 sin(theta) does
+    // not depend on phi (the slowest index), the cylinder fallback's sqrt(y^2 + z^2), the composite core's factor and the plain weight 1 not on x —
+    // 120 B per node and kernel less to read (the weighted K1 moves 168 B per node otherwise), and nz / nx times less memory
+    s->ell_mode = 0;
+    const bool whole = s->g.k0 == 0 && s->g.nkl == s->g.NZ;
+    if (ctx->ell_compact && s->grid.dim == 3 && whole) {
+        if (w->kind == PDEGPU_WEIGHT_R2SIN) s->ell_mode = 1;
+        else if (w->kind == PDEGPU_WEIGHT_RCYL || w->kind == PDEGPU_WEIGHT_ONE) s->ell_mode = 2;
+    }
+    const long long ne = s->ell_mode == 1 ? 3LL * s->g.PP : (s->ell_mode == 2 ? 3LL * s->g.NY * s->g.nkl : n);
+    const size_t sizes[3] = {(size_t)15 * ne, (size_t)15 * ne, (size_t)n};
     for (int i = 0; i < 3; ++i) PG_HIP(ctx, hipMalloc(&s->ell_base[i], sizes[i] * sizeof(double)));
+    if (s->ell_mode) {                         // (entries no representative node writes — plane class 1 of a two-plane grid — must still be finite)
+        PG_HIP(ctx, hipMemsetAsync(s->ell_base[0], 0, sizes[0] * sizeof(double), ctx->stream));
+        PG_HIP(ctx, hipMemsetAsync(s->ell_base[1], 0, sizes[1] * sizeof(double), ctx->stream));
+    }
     s->ellA = s->ell_base[0];
     s->ellM = s->ell_base[1];
     s->dinv = s->ell_base[2];
-    s->ell_stride = n;
+    s->ell_stride = ne;
     PG_TRY(vec_alloc(ctx, s->g, &s->z));
     double h[3] = {1, 1, 1}, lengths[3] = {0, 0, 0};
     for (int r = 0; r < s->grid.dim; ++r) {
         h[r] = s->grid.L[r] / s->grid.n[r];
         lengths[r] = s->grid.L[r];
     }
-    PG_TRY(weighted_assemble(ctx, s->g, w, h, lengths, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride));
+    PG_TRY(weighted_assemble(ctx, s->g, w, h, lengths, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride, s->ell_mode));
     s->weighted = true;
     return PDEGPU_OK;
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
 
     double acc = 0.0, acc2 = 0.0;                              // acc2 (K1): (A p).(A p) of the single-reduction form
     for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += (long long)gridDim.x * 256) {
-        long long idx = e0;
+        long long idx = e0, row_idx = 0;                      // row_idx: j + NY * lk (the non-boundary enumeration; weighted operators)
         int i, j, lk;
         if (bnd) {
             // boundary node e0 of the slab: the full planes z = 0 / NZ-1 first, then the ring of every other plane
@@ -98,11 +98,20 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
                 }
             }
             idx = (long long)lk * g.PP + (long long)j * g.PX + i;
+        } else if (total <= 0x7fffffffLL) {
+            // 32-bit index arithmetic (two 64-bit divisions with remainders cost ~600 instructions per node on this ISA — more than the rest of the loop body)
+            const unsigned e = (unsigned)idx;
+            const unsigned row = e / (unsigned)g.PX;
+            i = (int)(e - row * (unsigned)g.PX);
+            lk = (int)(row / (unsigned)g.NY);
+            j = (int)(row - (unsigned)lk * (unsigned)g.NY);
+            row_idx = (long long)row;
         } else {
             i = (int)(idx % g.PX);
             const long long row = idx / g.PX;
             j = (int)(row % g.NY);
             lk = (int)(row / g.NY);
+            row_idx = row;
         }
         const int kg = g.k0 + lk;
         const bool real = i < g.NX;
@@ -128,13 +137,21 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
         double s = 0.0;
         if (ELL) {
             double wq[15], vi[15], vp[15];
+            // where the weight does not depend on one coordinate the coefficient rows repeat along it: three representative planes (mode 1: 1 / nz of
+            // the 120 B per node, cache-resident) or three entries per grid row (mode 2: one address per wave, a broadcast) stand for all of them
+            long long eidx = idx;
+            if (a.ell_mode == 1) {
+                eidx = (long long)(kg == 0 ? 0 : (kg == g.NZ - 1 ? 2 : 1)) * g.PP + (idx - (long long)lk * g.PP);
+            } else if (a.ell_mode == 2) {
+                eidx = 3 * row_idx + (i == 0 ? 0 : (i >= g.NX - 1 ? 2 : 1));
+            }
 #pragma unroll
             for (int q = 0; q < 15; ++q) {
                 constexpr int kOff[15] = {13, 12, 14, 10, 16, 4, 22, 9, 17, 3, 23, 1, 25, 0, 26};
                 const int o = kOff[q];
                 const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
                 const long long nb = idx + (long long)dz * g.PP + (long long)dy * g.PX + dx;
-                wq[q] = a.ell[q * a.ell_stride + idx];
+                wq[q] = a.ell[q * a.ell_stride + eidx];
                 vi[q] = a.in[nb];
                 vp[q] = (MODE == APPLY_CG_K1) ? a.p_old[nb] : 0.0;
             }

@@ -53,6 +53,52 @@ __global__ __launch_bounds__(256) void k_weighted_assemble(GridDev g, WeightGeom
     }
 }
 
+// Compact forms (StencilArgs.ell_mode; 3-D, a slab that owns every plane): only representative nodes are integrated.  mode 1: entry e = pc * PP + j * PX + i
+// for the plane classes pc = 0 | 1 | 2 = slowest index 0 | interior (plane 1 stands for all) | NZ-1; mode 2: e = 3 * (j + NY * k) + ic for the column classes
+// ic = x index 0 | interior (column 1) | NX-1.  A class without a node (the interior one of a two-plane / two-column grid) keeps the zeros of the memset.
+__global__ __launch_bounds__(256) void k_weighted_assemble_compact(GridDev g, WeightGeom wg, int kind, double cM, double cK, double* __restrict__ ellA,
+                                                                    double* __restrict__ ellM, long long stride, int ell_mode) {
+    const int nn[3] = {g.NX, g.NY, g.NZ};
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < stride; e += (long long)gridDim.x * 256) {
+        int i, j, k, cls;
+        if (ell_mode == 1) {
+            cls = (int)(e / g.PP);
+            const int rem = (int)(e - (long long)cls * g.PP);
+            j = rem / g.PX;
+            i = rem - j * g.PX;
+            k = cls == 0 ? 0 : (cls == 2 ? g.NZ - 1 : 1);
+            if (i >= g.NX || j >= g.NY || (cls == 1 && g.NZ < 3)) continue;
+        } else {
+            const long long row = e / 3;
+            cls = (int)(e - 3 * row);
+            k = (int)(row / g.NY);
+            j = (int)(row - (long long)k * g.NY);
+            i = cls == 0 ? 0 : (cls == 2 ? g.NX - 1 : 1);
+            if (cls == 1 && g.NX < 3) continue;
+        }
+        double rowK[PG_NOFF15], rowM[PG_NOFF15], ld = 0.0;
+        weighted_row(g.dim, nn, wg.origin, wg.h, wg.lengths, kind, wg.core_radius, wg.core_ratio, i, j, k, rowK, rowM, &ld);
+        for (int q = 0; q < PG_NOFF15; ++q) {
+            ellA[q * stride + e] = cM * rowM[q] + cK * rowK[q];
+            ellM[q * stride + e] = rowM[q];
+        }
+    }
+}
+// Jacobi diagonal of every node from the compact rows (q = 0 is the centre entry); row pads get 0 as in the one-row-per-node form
+__global__ __launch_bounds__(256) void k_weighted_dinv_compact(GridDev g, const double* __restrict__ ellA, double* __restrict__ dinv, int ell_mode) {
+    const long long total = (long long)g.nkl * g.PP;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long row = idx / g.PX;
+        const int i = (int)(idx - row * g.PX);
+        const int k = (int)(row / g.NY);
+        long long e;
+        if (ell_mode == 1) e = (long long)(k == 0 ? 0 : (k == g.NZ - 1 ? 2 : 1)) * g.PP + (idx - (long long)k * g.PP);
+        else e = 3 * row + (i == 0 ? 0 : (i >= g.NX - 1 ? 2 : 1));
+        const double d = i < g.NX ? ellA[e] : 0.0;
+        dinv[idx] = d > 0.0 ? 1.0 / d : 0.0;
+    }
+}
+
 // r -= alpha q;  z = D^-1 r;  partial r.z    (use_alpha == 0: z and the sum only)
 __global__ __launch_bounds__(256) void k_k2_pc(double* __restrict__ r, const double* __restrict__ q, double* __restrict__ z,
                                                 const double* __restrict__ dinv, long long n, double* scal,
@@ -90,13 +136,21 @@ inline int flat_grid(const pdegpu_ctx* ctx, long long n) {
 }  // namespace
 
 int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, const double* lengths, double cM,
-                      double cK, double* ellA, double* ellM, double* dinv, long long stride) {
+                      double cK, double* ellA, double* ellM, double* dinv, long long stride, int ell_mode) {
     WeightGeom wg{};
     for (int r = 0; r < 3; ++r) { wg.origin[r] = w->origin[r]; wg.h[r] = h[r]; wg.lengths[r] = lengths[r]; }
     wg.core_radius = w->core_radius;
     wg.core_ratio = w->core_ratio;
     const int kind = w->kind;
     const long long total = (long long)g.nkl * g.PP;
+    if (ell_mode) {
+        hipLaunchKernelGGL(k_weighted_assemble_compact, dim3(flat_grid(ctx, stride)), dim3(256), 0, ctx->stream, g, wg, kind, cM, cK, ellA, ellM, stride,
+                           ell_mode);
+        PG_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_weighted_dinv_compact, dim3(flat_grid(ctx, total)), dim3(256), 0, ctx->stream, g, ellA, dinv, ell_mode);
+        PG_HIP(ctx, hipGetLastError());
+        return PDEGPU_OK;
+    }
     hipLaunchKernelGGL(k_weighted_assemble, dim3(flat_grid(ctx, total)), dim3(256), 0, ctx->stream, g, wg, kind, cM, cK, ellA, ellM,
                        dinv, stride);
     PG_HIP(ctx, hipGetLastError());

@@ -63,7 +63,8 @@ def _meta(coord_sys, geom, r_inner, r_outer, source_type, source_value, steady, 
          "r_inner": r_inner, "r_outer": r_outer}
     m.update(extra)
     m.update({"source_type": source_type, "source_value": source_value, "steady": steady})
-    m.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"])})
+    m.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"]),
+              "solver_path": st.get("path", "weighted"), "solve_ms": float(st.get("solve_ms", 0.0))})
     m.update(st.get("snapshot_meta", {"snapshot_stride": 1}))
     return m
 
@@ -203,7 +204,8 @@ def solve_heat_3d_box_core(Lx, Ly, Lz, nx, ny, nz, diffusivity, T_boundary, T_in
     else:
         meta["T_boundary"] = T_boundary
     meta.update({"core_radius": core_radius, "core_diffusivity": core_diffusivity, "base_diffusivity": diffusivity})   # :747-750
-    meta.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"])})
+    meta.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"]),
+                 "solver_path": st.get("path", "general"), "solve_ms": float(st.get("solve_ms", 0.0))})
     meta.update(st.get("snapshot_meta", {"snapshot_stride": 1}))
     return TimeSeriesField(coords=coords, values=values, times=times, dim=3, meta=meta)
 

@@ -149,3 +149,33 @@ def test_cylinder_through_the_tool_and_params(lib, gpu_ctx, tmp_path):
                                             kw["dt"], kw["num_steps"], kw["cylinder_radius"], T_left=kw["T_left"], T_right=kw["T_right"],
                                             core_radius=kw["core_radius"], core_diffusivity=kw["core_diffusivity"])
     assert rel_err(f.values, ref.values) < TOL
+
+
+@pytest.mark.parametrize("case", ["spherical", "spherical_two_planes", "cylinder", "core_box", "core_box_one_cell_in_x"])
+def test_compact_coefficient_rows_equal_one_row_per_node(lib, gpu_ctx, case):
+    """Where the weight does not depend on one coordinate (r^2 sin(theta): not on phi; the cylinder fallback's sqrt(y^2 + z^2), the composite core and the plain
+    weight: not on x) the weighted operators store the coefficient rows of three representative planes / columns (ell_compact = 1, the default).
+    Same arithmetic on the same numbers: the fields must equal those of the one-row-per-node form bit for bit — incl. grids with only two planes /
+    two columns, where no interior representative exists."""
+    from pdegpu import _lib, curvilinear as cv, heat
+    outs = []
+    try:
+        for compact in (1, 0):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"ell_compact", compact))
+            if case.startswith("spherical"):
+                nphi = 1 if case.endswith("two_planes") else 9
+                f = cv._solve_heat_3d_spherical_raw(0.1, 1.0, 8, 7, nphi, 1.0, 20.0, 60.0, 0.01, 3, source_type="constant", source_value=10.0, rtol=1e-12)
+            elif case == "cylinder":
+                f = heat._solve_heat_3d_raw(Lx=1.0, Ly=1.0, Lz=1.0, nx=7, ny=8, nz=6, diffusivity=1.0, T_boundary=20.0, T_initial=60.0, dt=0.01, num_steps=3,
+                                            geometry_type="cylinder", cylinder_radius=0.5, core_radius=0.3, core_diffusivity=40.0, T_left=80.0, rtol=1e-12)
+            else:
+                nx = 1 if case.endswith("one_cell_in_x") else 7
+                f = heat._solve_heat_3d_raw(Lx=1.0, Ly=0.8, Lz=0.9, nx=nx, ny=8, nz=9, diffusivity=1.0, T_boundary=20.0, T_initial=70.0, dt=0.005,
+                                            num_steps=3, core_radius=0.45, core_diffusivity=35.0, initial_type="cosine", initial_amplitude=25.0,
+                                            initial_wavenumber=1.7, rtol=1e-12, **(dict(T_left=50.0) if nx == 1 else {}))   # (one cell in x: only x = 0 clamped, or no unknown is left)
+            outs.append(f)
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"ell_compact", 1))
+    assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"]
+    assert (outs[0].meta["cg_iterations"] > 0) == (case != "spherical_two_planes")      # (one cell in phi under a uniform boundary value: no unknowns)
+    assert np.array_equal(outs[0].values, outs[1].values)
