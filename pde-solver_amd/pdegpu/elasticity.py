@@ -35,7 +35,8 @@ def run_elasticity(dim, n, Ls, *, E, nu=0.3, area=1.0, body=(0.0, 0.0, 0.0), pla
 
 
 def _extra(st):
-    return {"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"])}
+    return {"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"]),
+            "solver_path": st.get("path", "general"), "solve_ms": float(st.get("solve_ms", 0.0))}
 
 
 def _solve_elasticity_1d_static(L_: float, nx: int, E: float, area: float, body_force: float,
