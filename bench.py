@@ -291,6 +291,54 @@ class Runner:
         return res
 
 
+def run_config5(R, steps, warmup, native):
+    """BASELINE configs[4]: 256 x 64 x 64 elasticity (E = 210 GPa, nu = 0.3, gravity), the PCG iteration of _solve_elasticity_3d_static
+    (fenics_mcp_server.py:1808-1838) through SlabCG on z-slabs (65 planes over the ranks): us per iteration and DoF/s, with both transports at N > 1"""
+    torch, dist, L = R.torch, R.dist, R.L
+    from pdegpu.dist import GpuElasticitySlabEngine, NativeComm, SlabCG, slab_range
+    world, rank = R.world, R.rank
+    n = (256, 64, 64)
+    grid = L.make_grid(3, n, (1.0, 0.25, 0.25))
+    el = L.Elasticity()
+    el.E, el.nu = 210e9, 0.3
+    el.body[2] = -9.81 * 7800.0
+    k0, nk = slab_range(n[2] + 1, world, rank)
+    dof = 3 * (n[0] + 1) * (n[1] + 1) * (n[2] + 1)
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=f"cuda:{R.local_rank}" if R.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    out = {"workload": "config 5: 256 x 64 x 64 elasticity, single-reduction Jacobi-PCG, z-slabs", "dof": dof, "planes_rank0": nk, "steps": steps}
+    with torch.cuda.stream(R.stream):
+        eng = GpuElasticitySlabEngine(grid, el, k0, nk, R.local_rank, R.stream)
+        cg = SlabCG(eng, rank, world)
+        cg.start(0.0)
+        comm = NativeComm(eng, rank, world) if native else None
+        legs = [("torch_distributed" if world > 1 else "stepwise_driver", None)] + ([("library_rccl", comm)] if comm is not None else [])
+        us = {}
+        for label, c in legs + legs:
+            cg.comm = c
+            cg.iterate(warmup)
+            R.fence()
+            t0 = time.perf_counter()
+            cg.iterate(steps)
+            R.fence()
+            us.setdefault(label, []).append(max_over_ranks(time.perf_counter() - t0) / steps * 1e6)
+        cg.comm = None
+        out["us_per_iteration"] = us
+        best = min(min(v) for v in us.values())
+        out["value"], out["unit"] = dof * 1e6 / best, "DoF/s (best leg)"
+        out["rr_after"] = cg.rr()
+        if comm is not None:
+            comm.close()
+        eng.close()
+    return out
+
+
 def roofline_of(res, general):
     """K1 (the SpMV-bearing fused kernel) and K2 of rank 0's slab, algorithmic bytes over the HIP-event time of the timed region"""
     unk = res["unknowns_rank0"]
@@ -475,6 +523,11 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             R.dist.destroy_process_group()
         except Exception as e:
             extras["collective_calls_one_rank"] = {"failed": repr(e)}
+    if R.backend == "nccl" or world == 1:
+        try:                                            # BASELINE configs[4] ("1 -> 8 MI355X"): the elasticity PCG on z-slabs
+            extras["config5_elasticity"] = run_config5(R, max(100, args.steps), max(20, args.warmup), world > 1 and not args.no_native_comm)
+        except Exception as e:
+            extras["config5_elasticity"] = {"failed": repr(e)}
     if world == 1:
         # the system of a backward-Euler step (fenics_mcp_server.py:702-716): A = M + dt kappa K, 15-point on the Kuhn split — bare SpMV and the CG
         # iteration (K1 stores q there: 72 B/DoF; the second stencil pass of the 64-byte form costs more than it saves with 15 points)
