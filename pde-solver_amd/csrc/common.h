@@ -272,7 +272,7 @@ int vec_norm2(pdegpu_ctx* ctx, const GridDev& g, const double* a, double* partia
 int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w, const double* h, const double* lengths, double cM,
                       double cK, double* ellA, double* ellM, double* dinv, long long stride, int ell_mode);
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
-              double* partials, int use_alpha, LaunchInfo* li);
+              double* partials, int use_alpha, LaunchInfo* li, const DotIn& di = DotIn());
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense

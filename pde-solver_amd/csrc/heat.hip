@@ -435,7 +435,7 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         if (li) *li = lf;
         return PDEGPU_OK;
     }
-    if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 1, li);
+    if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, part_out, 1, li, di);
     return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, part_out, li, di);
 }
 
@@ -1129,7 +1129,7 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
     // end of the chunk leaves the canonical layout (SC_RR current, SC_RR_PREV previous) for the host and for flush.
     const int64_t nslow = s->grid.dim == 3 ? (int64_t)s->grid.n[2] + 1 : 1;
     // (every workgroup of the consuming launch sums ALL partials: only sensible while they are a few thousand)
-    const bool lazy = ctx->lazy_dot && !s->weighted && s->g.k0 == 0 && s->g.nkl == nslow &&
+    const bool lazy = ctx->lazy_dot && s->g.k0 == 0 && s->g.nkl == nslow &&
                       done < iters && !(s->tile3d && stencil_tile3d_grid(s->g) > stencil_max_partials(ctx));
     if (lazy) {
         int cur = SC_RR;

@@ -102,13 +102,10 @@ __global__ __launch_bounds__(256) void k_weighted_dinv_compact(GridDev g, const 
 // r -= alpha q;  z = D^-1 r;  partial r.z    (use_alpha == 0: z and the sum only)
 __global__ __launch_bounds__(256) void k_k2_pc(double* __restrict__ r, const double* __restrict__ q, double* __restrict__ z,
                                                 const double* __restrict__ dinv, long long n, double* scal,
-                                                double* __restrict__ partials, int use_alpha) {
+                                                double* __restrict__ partials, int use_alpha, DotIn di) {
     __shared__ double sRed[4];
     double alpha = 0.0;
-    if (use_alpha) {
-        const double pq = scal[SC_PQ], rr = scal[SC_RR];
-        alpha = (pq > 0.0) ? rr / pq : 0.0;
-    }
+    if (use_alpha) alpha = cg_alpha_in(di, scal, sRed);      // (lazy loop: K1's p.q partials are summed here, the r.z slot is di.s_rr)
     double acc = 0.0;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
         double rv = r[e];
@@ -158,11 +155,11 @@ int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w,
 }
 
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
-              double* partials, int use_alpha, LaunchInfo* li) {
+              double* partials, int use_alpha, LaunchInfo* li, const DotIn& di) {
     const long long n = (long long)g.nkl * g.PP;
     const int nb = flat_grid(ctx, n);
     if (li) { li->grid = nb; li->block = 256; }
-    hipLaunchKernelGGL(k_k2_pc, dim3(nb), dim3(256), 0, ctx->stream, r, q, z, dinv, n, scal, partials, use_alpha);
+    hipLaunchKernelGGL(k_k2_pc, dim3(nb), dim3(256), 0, ctx->stream, r, q, z, dinv, n, scal, partials, use_alpha, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

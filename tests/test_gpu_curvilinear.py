@@ -179,3 +179,24 @@ def test_compact_coefficient_rows_equal_one_row_per_node(lib, gpu_ctx, case):
     assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"]
     assert (outs[0].meta["cg_iterations"] > 0) == (case != "spherical_two_planes")      # (one cell in phi under a uniform boundary value: no unknowns)
     assert np.array_equal(outs[0].values, outs[1].values)
+
+
+@pytest.mark.parametrize("case", ["spherical", "cylinder"])
+def test_weighted_pcg_without_reduce_launches_is_bitwise_the_eager_one(lib, gpu_ctx, case):
+    """lazy_dot = 1 (default): inside a chunk K2's prologue sums K1's p.q partials and the next K1's prologue K2's r.z partials — no reduce launches, the
+    same summation order; the weighted Jacobi-PCG (class-table K1 with per-node coefficients, k_k2_pc) must give the fields of the eager loop bit for bit"""
+    from pdegpu import _lib, curvilinear as cv, heat
+    outs = []
+    try:
+        for lazy in (1, 0):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", lazy))
+            if case == "spherical":
+                f = cv._solve_heat_3d_spherical_raw(0.1, 1.0, 10, 9, 11, 1.0, 20.0, 60.0, 0.01, 3, source_type="constant", source_value=10.0, rtol=1e-12)
+            else:
+                f = heat._solve_heat_3d_raw(Lx=1.0, Ly=1.0, Lz=1.0, nx=9, ny=8, nz=7, diffusivity=1.0, T_boundary=20.0, T_initial=60.0, dt=0.01, num_steps=3,
+                                            geometry_type="cylinder", cylinder_radius=0.5, core_radius=0.3, core_diffusivity=40.0, rtol=1e-12)
+            outs.append(f)
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", 1))
+    assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"] > 0
+    assert np.array_equal(outs[0].values, outs[1].values)
