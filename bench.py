@@ -291,6 +291,27 @@ class Runner:
         return res
 
 
+def single_gpu_rr(R, case, iters):
+    """rank 0 alone: the same global problem as `case` on ONE GPU (one slab), `iters` CG iterations from the same start — the r.r the N-slab
+    run must reproduce (same recurrences in exact arithmetic; rounding differs only through the summation order of the dot products)"""
+    torch, L = R.torch, R.L
+    from pdegpu.dist import GpuSlabEngine, SlabCG
+    nx, ny, nz = case["cells"]
+    grid = L.make_grid(3, (nx, ny, nz), case["L"])
+    heat = L.Heat()
+    heat.kappa, heat.dt, heat.steady, heat.source = 1.0, 0.0, 1, 1.0
+    heat.bc_mode, heat.fast_path = L.BC_UNIFORM, 0 if R.args.general else 1
+    heat.bc_present[0] = 1
+    with torch.cuda.stream(R.stream):
+        eng = GpuSlabEngine(grid, heat, 0, nz + 1, R.local_rank, R.stream)
+        cg = SlabCG(eng, 0, 1, variant=R.args.cg_variant)
+        cg.start(0.0)
+        cg.iterate(iters)
+        rr = cg.rr()
+        eng.close()
+    return rr
+
+
 def run_config5(R, steps, warmup, native):
     """BASELINE configs[4]: 256 x 64 x 64 elasticity (E = 210 GPa, nu = 0.3, gravity), the PCG iteration of _solve_elasticity_3d_static
     (fenics_mcp_server.py:1808-1838) through SlabCG on z-slabs (65 planes over the ranks): us per iteration and DoF/s, with both transports at N > 1"""
@@ -483,6 +504,15 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
                 "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
                 "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
                 "k1_ms": r2["k1_ms"], "k2_ms": r2["k2_ms"], "planes_rank0": r2["planes_rank0"], "rr_after": r2["rr_after"]}
+            if world > 1 and wl == "config3" and c2["scaling"] == "strong":
+                # parity of the distributed loop on this hardware: the same 512^3 system, the same number of iterations, on rank 0's GPU alone
+                w2 = max(5, args.warmup // 2)
+                ref = single_gpu_rr(R, c2, w2 + st2) if R.rank == 0 else None
+                R.fence()
+                if ref is not None:
+                    extras[f"{wl}_{c2['scaling']}"]["single_gpu_check"] = {
+                        "what": f"r.r after {w2 + st2} iterations of the same system on ONE GPU (rank 0, one slab) against the {world}-slab run above",
+                        "rr_single_gpu": ref, "rel_diff": abs(r2["rr_after"] - ref) / ref if ref > 0 else None}
         except Exception as e:                          # an extra must never void the main number
             extras[f"{wl}_{sc}"] = {"failed": repr(e)}
             break

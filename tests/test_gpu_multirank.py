@@ -49,6 +49,9 @@ def test_bench_line_of_the_multi_rank_path(lib, gpu_ctx):
         assert k in d
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["unknowns"] == 47 * 47 * 95
     assert d["value"] > 0 and abs(d["value"] - d["config"]["unknowns"] * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+    # the strong-scaling extra carries its own parity check: the same system, the same iterations, on one GPU alone
+    chk = d["extras"]["config3_strong"]["single_gpu_check"]
+    assert chk["rr_single_gpu"] > 0 and chk["rel_diff"] < 1e-9, chk
 
 
 def test_multi_process_elasticity_slabs(lib, gpu_ctx):
