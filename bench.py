@@ -504,8 +504,8 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
                 "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
                 "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
                 "k1_ms": r2["k1_ms"], "k2_ms": r2["k2_ms"], "planes_rank0": r2["planes_rank0"], "rr_after": r2["rr_after"]}
-            if world > 1 and wl == "config3" and c2["scaling"] == "strong":
-                # parity of the distributed loop on this hardware: the same 512^3 system, the same number of iterations, on rank 0's GPU alone
+            if world > 1 and c2["scaling"] == "strong":
+                # parity of the distributed loop on this hardware: the same global system, the same number of iterations, on rank 0's GPU alone
                 w2 = max(5, args.warmup // 2)
                 ref = single_gpu_rr(R, c2, w2 + st2) if R.rank == 0 else None
                 R.fence()
