@@ -338,6 +338,22 @@ def run_config5(R, steps, warmup, native):
         eng = GpuElasticitySlabEngine(grid, el, k0, nk, R.local_rank, R.stream)
         cg = SlabCG(eng, rank, world)
         cg.start(0.0)
+        if world > 1:
+            # parity on this hardware: 60 iterations on the slabs against the same 60 on rank 0's GPU alone (one slab)
+            cg.iterate(60)
+            rr_n = cg.rr()
+            ref = None
+            if rank == 0:
+                one = GpuElasticitySlabEngine(grid, el, 0, n[2] + 1, R.local_rank, R.stream)
+                c1 = SlabCG(one, 0, 1)
+                c1.start(0.0)
+                c1.iterate(60)
+                ref = c1.rr()
+                one.close()
+            R.fence()
+            if ref is not None:
+                out["single_gpu_check"] = {"what": "r.r after 60 PCG iterations: the slabs against one GPU alone (rank 0)", "rr_slabs": rr_n, "rr_single_gpu": ref,
+                                           "rel_diff": abs(rr_n - ref) / ref if ref > 0 else None}
         comm = NativeComm(eng, rank, world) if native else None
         legs = [("torch_distributed" if world > 1 else "stepwise_driver", None)] + ([("library_rccl", comm)] if comm is not None else [])
         us = {}
@@ -553,11 +569,11 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             R.dist.destroy_process_group()
         except Exception as e:
             extras["collective_calls_one_rank"] = {"failed": repr(e)}
-    if R.backend == "nccl" or world == 1:
-        try:                                            # BASELINE configs[4] ("1 -> 8 MI355X"): the elasticity PCG on z-slabs
-            extras["config5_elasticity"] = run_config5(R, max(100, args.steps), max(20, args.warmup), world > 1 and not args.no_native_comm)
-        except Exception as e:
-            extras["config5_elasticity"] = {"failed": repr(e)}
+    try:                                                # BASELINE configs[4] ("1 -> 8 MI355X"): the elasticity PCG on z-slabs
+        extras["config5_elasticity"] = run_config5(R, max(100, args.steps), max(20, args.warmup),
+                                                   world > 1 and R.backend == "nccl" and not args.no_native_comm)
+    except Exception as e:
+        extras["config5_elasticity"] = {"failed": repr(e)}
     if world == 1:
         # the system of a backward-Euler step (fenics_mcp_server.py:702-716): A = M + dt kappa K, 15-point on the Kuhn split — bare SpMV and the CG
         # iteration (K1 stores q there: 72 B/DoF; the second stencil pass of the 64-byte form costs more than it saves with 15 points)

@@ -52,6 +52,8 @@ def test_bench_line_of_the_multi_rank_path(lib, gpu_ctx):
     # the strong-scaling extra carries its own parity check: the same system, the same iterations, on one GPU alone
     chk = d["extras"]["config3_strong"]["single_gpu_check"]
     assert chk["rr_single_gpu"] > 0 and chk["rel_diff"] < 1e-9, chk
+    chk5 = d["extras"]["config5_elasticity"]["single_gpu_check"]                    # BASELINE config 5 on two slabs against one
+    assert chk5["rr_single_gpu"] > 0 and chk5["rel_diff"] < 1e-8, chk5
 
 
 def test_multi_process_elasticity_slabs(lib, gpu_ctx):
