@@ -249,6 +249,20 @@ class Runner:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 return float(t.item())
 
+            if case.get("overlap_ab") and world > 1:
+                # does the exchange hide behind K1's bulk (and K2's) on this hardware?  The same session, alternating: the overlapped order against
+                # "exchange first, then K1 whole" — through torch.distributed, the transport of `value`
+                ab = {}
+                for label, ov in (("overlapped", True), ("exchange_first", False), ("overlapped_2", True), ("exchange_first_2", False)):
+                    cg.overlap = ov
+                    cg.iterate(max(5, warmup // 2))
+                    self.fence()
+                    t0 = time.perf_counter()
+                    cg.iterate(steps)
+                    self.fence()
+                    ab[label] = max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+                cg.overlap = not self.args.no_overlap
+                res["overlap_ab_ms"] = ab
             if case.get("native_comm"):
                 # the same session again with the exchange and the all-reduce(s) issued by the library itself on its own RCCL communicator
                 # (csrc/comm.hip; a chunk of iterations = ONE C call), alternating with the torch.distributed-driven loop
@@ -511,6 +525,7 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
         try:
             if world > 1 and R.backend == "nccl" and not args.no_native_comm:
                 c2["native_comm"] = True
+            c2["overlap_ab"] = world > 1
             r2 = R.run_case(c2, max(20, args.steps // 2), max(5, args.warmup // 2))
             st2 = max(20, args.steps // 2)
             if "native_comm_ms" in r2:
@@ -520,6 +535,8 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
                 "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
                 "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
                 "k1_ms": r2["k1_ms"], "k2_ms": r2["k2_ms"], "planes_rank0": r2["planes_rank0"], "rr_after": r2["rr_after"]}
+            if "overlap_ab_ms" in r2:
+                extras[f"{wl}_{c2['scaling']}"]["overlap_ab_ms_per_step"] = r2["overlap_ab_ms"]
             if world > 1 and c2["scaling"] == "strong":
                 # parity of the distributed loop on this hardware: the same global system, the same number of iterations, on rank 0's GPU alone
                 w2 = max(5, args.warmup // 2)

@@ -52,6 +52,7 @@ def test_bench_line_of_the_multi_rank_path(lib, gpu_ctx):
     # the strong-scaling extra carries its own parity check: the same system, the same iterations, on one GPU alone
     chk = d["extras"]["config3_strong"]["single_gpu_check"]
     assert chk["rr_single_gpu"] > 0 and chk["rel_diff"] < 1e-9, chk
+    assert set(d["extras"]["config3_strong"]["overlap_ab_ms_per_step"]) == {"overlapped", "exchange_first", "overlapped_2", "exchange_first_2"}
     chk5 = d["extras"]["config5_elasticity"]["single_gpu_check"]                    # BASELINE config 5 on two slabs against one
     assert chk5["rr_single_gpu"] > 0 and chk5["rel_diff"] < 1e-8, chk5
 
