@@ -162,6 +162,11 @@ const char* pdegpu_version(void);
  * hybrid_k2          | 1       | ... steady sessions on one slab use the 64 B/DoF form
  * direct_1d          | 1       | 1-D grids: Thomas recurrence inside one launch (0 = CG, diagnostic)
  * elasticity
+ * wfast              | 1       | weighted 3-D operators on a box whose boundary nodes are all constrained, compact rows: z-marching kernels with the weights
+ *                    |         | in registers (weight independent of the marching coordinate) or SGPRs (independent of x), 72 B/DoF per PCG
+ *                    |         | iteration (csrc/wmarch.hip); 0 = class-table kernels reading the rows (88 B/DoF, 45 loads per node)
+ * wfast_ry           | 1       | rows per wavefront column of those kernels where the weights are wave-uniform (1|2)
+ * wfast_wg_per_cu    | 0       | workgroups per CU their z-chunking aims for (0 = occupancy API)
  * ell_compact        | 1       | weighted (curvilinear / composite) 3-D operators whose weight does not depend on one coordinate store the coefficient
  *                    |         | rows of three representative planes / columns instead of one row per node (0 = one row per node)
  * el_fast            | 1       | 3-D: z-marching block stencil (0 = thread-per-node class-table kernel)
@@ -213,6 +218,13 @@ typedef struct pdegpu_weight {
 } pdegpu_weight;
 int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,
                                const pdegpu_heat* heat, double* values_out, double* times_out, pdegpu_stats* stats);
+/* y = (cM M_w + cK K_w) x — the weighted forms `w*u*v*dx`, `w*dot(grad(u), grad(v))*dx` of :805-806, :968-969, :1103-1104, :1233-1234,
+ * :1374-1375 and of the box / cylinder branch :702-703 with r_expr and the DG0 kappa — applied matrix-free (operator tests, timing).
+ * marching = 1: the z-marching kernels (csrc/wmarch.hip) on the box with every boundary node constrained: interior rows only, the rest of y is 0;
+ * PDEGPU_EUNSUPPORTED where they do not apply (2-D / 1-D grids, weights depending on all coordinates, fewer than 2 cells on an axis).
+ * marching = 0: every row, class-table kernels reading one coefficient row per node. */
+int pdegpu_heat_apply_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight, double cM, double cK,
+                               const double* x, double* y, int marching);
 /* the same with a nodal initial field u0 [N] (heat->ic_type == PDEGPU_IC_NODAL): the projected sine / cosine initial conditions
  * of solve_heat_3D on its cylinder (BoxMesh fallback) and composite-core branches (:672-687) */
 int pdegpu_heat_solve_weighted_ic(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight,

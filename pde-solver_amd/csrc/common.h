@@ -39,6 +39,10 @@ struct pdegpu_ctx {
     int grid_mult = 8;          // flat kernels: workgroups per CU
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
+    int wfast = 1;              // weighted 3-D operators whose coefficient rows are compact (ell_compact) on an all-Dirichlet box: 1 = z-marching kernels with the
+                                // weights in registers / SGPRs (wmarch.hip, 72 B/DoF per PCG iteration); 0 = class-table kernels reading the rows (88 B/DoF)
+    int wfast_ry = 1;           // rows per wavefront column of the weighted marching kernels whose weights are wave-uniform (1 | 2); per-lane weights: 1
+    int wfast_wg_per_cu = 0;    // workgroups per CU their z-chunking aims for; 0 = what the occupancy API reports
     int ell_compact = 1;        // weighted operators whose weight does not depend on one coordinate keep the coefficient rows of three representative
                                 // planes / columns instead of one row per node (0: always one row per node)
     int el_fast = 1;            // 3-D elasticity: 1 = z-marching block stencil (k_el_fast); 0 = thread-per-node class-table kernel
@@ -234,6 +238,7 @@ struct StencilArgs {
     int lk_lo2 = 0, lk_hi2 = 0;   // ... and a second, disjoint plane range in the SAME launch (the two edge planes of a slab: one launch, not two)
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
+    const double* wdinv = nullptr;   // weighted marching kernels, per-lane weights: Jacobi diagonal^-1 of the interior plane class, [j * PX + i]
     int ell_mode;             // 0: one row per node; 1: rows of three planes only (slowest index 0 | interior | last: the weight does not depend on that
                               // coordinate); 2: three rows per grid row (x index 0 | interior | last: the weight does not depend on x) — weighted.hip
 };
@@ -273,6 +278,12 @@ int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w,
                       double cK, double* ellA, double* ellM, double* dinv, long long stride, int ell_mode);
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
               double* partials, int use_alpha, LaunchInfo* li, const DotIn& di = DotIn());
+// wmarch.hip: z-marching kernels of the weighted 3-D operators
+bool wmarch_supported(const GridDev& g);
+int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
+int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, double* scal, double* partials, LaunchInfo* li,
+              const DotIn& di = DotIn());
+int wmarch_rowtab(pdegpu_ctx* ctx, const GridDev& g, const double* ellA, const double* ellM, long long stride, double* rowA, double* rowM);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense

@@ -65,6 +65,9 @@ struct pdegpu_session {
     DevVec z;
     long long ell_stride = 0;
     int ell_mode = 0;              // StencilArgs.ell_mode of the coefficient arrays
+    // weighted operators on an all-Dirichlet 3-D box with compact coefficient rows: z-marching kernels (wmarch.hip), no z vector
+    bool wfast = false;
+    double *rowA = nullptr, *rowM = nullptr;   // ell_mode 2: row tables [NZ * NY][16] (15 weights of the interior column class + D^-1)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -249,6 +252,20 @@ int hybrid_boundary(pdegpu_session* s, StencilArgs a, int mode, LaunchInfo* li_f
     return PDEGPU_OK;
 }
 
+// weighted marching sessions: where the kernels of wmarch.hip find the coefficients of A (which == 0) or M (which == 1)
+void wfast_args(const pdegpu_session* s, int which, StencilArgs* a) {
+    a->g = s->g;
+    a->ell_mode = s->ell_mode;
+    a->ell_stride = s->ell_stride;
+    if (s->ell_mode == 1) {                    // compact rows of the plane class "interior" (entry e = PP + j * PX + i), D^-1 of plane 1
+        a->ell = (which == 0 ? s->ellA : s->ellM) + s->g.PP;
+        a->wdinv = s->dinv + s->g.PP;
+    } else {
+        a->ell = which == 0 ? s->rowA : s->rowM;
+        a->wdinv = nullptr;
+    }
+}
+
 // out = T (in + shift)   with T = A (which==0) or M (which==1); unmasked unless mask
 int op_plain(pdegpu_session* s, int which, const double* in, double shift, double* out, int mask) {
     StencilArgs a{};
@@ -262,6 +279,10 @@ int op_plain(pdegpu_session* s, int which, const double* in, double shift, doubl
     const double* htab = which == 0 ? s->hA : s->tabs.h_tabM;
     a.tabA = which == 0 ? s->tabs.d_tabA : s->tabs.d_tabM;
     a.off_mask = table_mask(htab);
+    if (s->wfast) {                            // interior rows only: every other node is Dirichlet and no consumer reads its entry
+        wfast_args(s, which, &a);
+        return wmarch_apply(s->ctx, a, APPLY_PLAIN, nullptr);
+    }
     if (s->weighted) {
         a.ell = which == 0 ? s->ellA : s->ellM;
         a.ell_stride = s->ell_stride;
@@ -298,6 +319,10 @@ int op_residual(pdegpu_session* s, const double* in, const double* rhs, double* 
     a.mask_dirichlet = 1;
     a.tabA = s->tabs.d_tabA;
     a.off_mask = table_mask(s->hA);
+    if (s->wfast) {                            // the partials are those of r . D^-1 r already
+        wfast_args(s, 0, &a);
+        return wmarch_apply(s->ctx, a, APPLY_RESIDUAL, li);
+    }
     if (s->weighted) {
         a.ell = s->ellA;
         a.ell_stride = s->ell_stride;
@@ -365,7 +390,12 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
         a.lk_hi2 = lk_hi2;
     }
     int rc;
-    if (s->plane2d) {
+    if (s->wfast) {                            // p = D^-1 r + beta p formed in the kernel: no z vector
+        a.in = s->r.v;
+        a.out = s->q.v;
+        wfast_args(s, 0, &a);
+        rc = wmarch_apply(s->ctx, a, APPLY_CG_K1, li);
+    } else if (s->plane2d) {
         a.g = s->g;
         plane2d_weights(s->hA, a.w);
         rc = stencil_plane2d(s->ctx, a, APPLY_CG_K1, li);
@@ -435,6 +465,7 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         if (li) *li = lf;
         return PDEGPU_OK;
     }
+    if (s->wfast) return wmarch_k2(s->ctx, s->g, s->ell_mode, s->r.v, s->q.v, s->ell_mode == 1 ? s->dinv + s->g.PP : s->rowA, s->d_scal, part_out, li, di);
     if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, part_out, 1, li, di);
     return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, part_out, li, di);
 }
@@ -446,7 +477,7 @@ int empty_dot(pdegpu_session* s, const LaunchInfo& li, int which) {
     return vec_reduce(s->ctx, s->d_part, li.grid, s->d_scal, which, 1);
 }
 int residual_finish(pdegpu_session* s, LaunchInfo* li) {
-    if (s->weighted) PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 0, li));
+    if (s->weighted && !s->wfast) PG_TRY(vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, s->d_part, 0, li));
     return empty_dot(s, *li, 1);
 }
 
@@ -470,7 +501,7 @@ extern "C" const char* pdegpu_version(void) { return "pdegpu 0.1 (gfx950)"; }
 
 // every tunable of a context: PDEGPU_<KEY> in the environment at pdegpu_create, pdegpu_set_tunable afterwards (table in include/pdegpu.h)
 static const char* const kTunableKeys[] = {
-    "ell_compact", "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
+    "ell_compact", "wfast", "wfast_ry", "wfast_wg_per_cu", "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
     "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
@@ -508,6 +539,9 @@ extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
 namespace {
 int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "ell_compact")) return &ctx->ell_compact;
+    if (!strcmp(key, "wfast")) return &ctx->wfast;
+    if (!strcmp(key, "wfast_ry")) return &ctx->wfast_ry;
+    if (!strcmp(key, "wfast_wg_per_cu")) return &ctx->wfast_wg_per_cu;
     if (!strcmp(key, "fast_ry")) return &ctx->fast_ry;
     if (!strcmp(key, "fast_nt")) return &ctx->fast_nt;
     if (!strcmp(key, "fast_ex")) return &ctx->fast_ex;
@@ -595,6 +629,8 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     persist2d_free(s->p2d);
     for (double* b0 : s->ell_base)
         if (b0) (void)hipFree(b0);
+    if (s->rowA) (void)hipFree(s->rowA);
+    if (s->rowM) (void)hipFree(s->rowM);
     vec_free(&s->z);
     vec_free(&s->xprev);
     delete s;
@@ -1543,6 +1579,13 @@ int session_make_weighted(pdegpu_session* s, const pdegpu_weight* w) {
     }
     PG_TRY(weighted_assemble(ctx, s->g, w, h, lengths, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride, s->ell_mode));
     s->weighted = true;
+    s->wfast = ctx->wfast != 0 && s->ell_mode != 0 && wmarch_supported(s->g);
+    if (s->wfast && s->ell_mode == 2) {
+        const size_t nt = (size_t)16 * s->g.NZ * s->g.NY * sizeof(double);
+        PG_HIP(ctx, hipMalloc(&s->rowA, nt));
+        PG_HIP(ctx, hipMalloc(&s->rowM, nt));
+        PG_TRY(wmarch_rowtab(ctx, s->g, s->ellA, s->ellM, s->ell_stride, s->rowA, s->rowM));
+    }
     return PDEGPU_OK;
 }
 
@@ -1670,7 +1713,7 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
     }
     const size_t N = (size_t)pdegpu_grid_num_nodes(grid);
     st.n_nodes = (int64_t)N;
-    st.path = s->hybrid ? 3 : (s->fast ? 1 : 0);
+    st.path = s->wfast ? 4 : (s->hybrid ? 3 : (s->fast ? 1 : 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PDEGPU_OK;
     auto fail = [&](int code) {
@@ -1757,6 +1800,39 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
     return fail(rc);
 }
 }  // namespace
+
+// y = (cM M_w + cK K_w) x for the weighted forms of the curvilinear / composite tools (operator tests, timing).  marching = 1: the z-marching
+// kernels of wmarch.hip on the all-Dirichlet box — the free (interior) rows only, every other entry of y is 0; PDEGPU_EUNSUPPORTED where that path
+// does not apply (see wmarch_supported).  marching = 0: every row through the class-table kernels reading the per-node rows.
+extern "C" int pdegpu_heat_apply_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight, double cM, double cK, const double* x,
+                                          double* y, int marching) {
+    if (!ctx) return PDEGPU_EINVAL;
+    if (!x || !y || !weight) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    PG_TRY(validate_grid(ctx, grid));
+    if (weight->kind < PDEGPU_WEIGHT_ONE || weight->kind > PDEGPU_WEIGHT_RCYL) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
+    if (grid->element_mode != PDEGPU_ELEM_P1SPLIT) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted forms use the P1 split only");
+    if ((weight->kind == PDEGPU_WEIGHT_R2SIN && grid->dim < 2) || ((weight->kind == PDEGPU_WEIGHT_RCYL || weight->kind == PDEGPU_WEIGHT_ONE) && grid->dim < 3))
+        return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weight kind %d on a %d-D grid", weight->kind, grid->dim);
+    pdegpu_heat heat{};
+    heat.kappa = 1.0;
+    heat.dt = 1.0;
+    heat.fast_path = 0;
+    heat.bc_mode = marching ? PDEGPU_BC_UNIFORM : PDEGPU_BC_DIRECTIONAL;
+    heat.bc_present[0] = marching ? 1 : 0;
+    const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
+    pdegpu_session* s = nullptr;
+    PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));
+    s->cM = cM;
+    s->cK = cK;
+    int rc = session_make_weighted(s, weight);
+    if (rc == PDEGPU_OK && marching && !s->wfast) rc = pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted marching kernels: 3-D grid with >= 2 cells per axis and a weight that does not depend on one coordinate");
+    if (rc == PDEGPU_OK) rc = put_vec(s, x, s->x.v);
+    if (rc == PDEGPU_OK) rc = vec_zero(ctx, s->g, &s->q);
+    if (rc == PDEGPU_OK) rc = op_plain(s, 0, s->x.v, 0.0, s->q.v, marching ? 1 : 0);
+    if (rc == PDEGPU_OK) rc = get_vec(s, s->q.v, y);
+    pdegpu_session_destroy(s);
+    return rc;
+}
 
 // ---------------------------------------------------------------------------------------------
 // project(): consistent-mass solve M s = rhs, no Dirichlet rows

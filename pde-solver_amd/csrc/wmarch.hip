@@ -1,0 +1,440 @@
+// wmarch.hip — z-marching kernels for the weighted 3-D heat operators (gfx950).
+//
+// The reference's curvilinear and composite tools (_solve_heat_3d_spherical_raw, fenics_mcp_server.py:1333-1464; the BoxMesh fallback of
+// geometry_type="cylinder", :523-529, :645; the composite core, :537-572) multiply mass and stiffness by a coordinate weight / a per-cell
+// diffusivity, so every node has its own 15 coupling weights (weighted.hip integrates them).  In all of them the weight does NOT depend on
+// one grid coordinate, and that decides where a marching wavefront keeps its coefficients:
+//   CM = 1  r^2 sin(theta): independent of phi, the slowest index = the marching direction.  A lane loads the 15 weights of its two nodes ONCE
+//           per z-chunk (plane class "interior" of the compact rows) and keeps them in registers for the whole march.
+//   CM = 2  sqrt(y^2 + z^2), the unit weight, the core factor: independent of x = the lane direction.  The 15 weights of a grid row are
+//           wave-uniform: scalar loads (constant address space -> s_load into SGPRs) from a row table [NZ * NY][16], one 128-byte line per row
+//           and plane step; entry 15 of the line is the row's Jacobi diagonal^-1.
+// Otherwise the kernel is the plain 15-point marching kernel of stencil.hip: a wavefront owns 128 nodes x RY rows, keeps three planes in
+// registers, takes x-neighbours by DPP wave shifts (shifted ONCE per plane and row: the shifted value is part of the rotating plane state, because
+// with per-node weights the constant-coefficient trick of shifting weighted sums is gone), reads every input plane once.
+// Jacobi-PCG without a z vector: K1 forms z = D^-1 r on the fly wherever it forms p = z + beta p (D^-1 sits in registers / SGPRs like the
+// weights), so an iteration moves  K1: read r, p, x; write p, x, q (48 B/DoF)  +  K2: read r, q; write r (24 B/DoF, D^-1 from the compact table
+// for the r.z sum)  =  72 B/DoF instead of the 88 of the class-table form (k_general<..., ELL> + k_k2_pc, which also costs 45 load instructions
+// per node).  Sessions: one slab owning every plane, every boundary node Dirichlet (the uniform boundary value of the tools).
+#include "common.h"
+#include "dot_finish.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+#define PG_CONSTANT __attribute__((address_space(4)))
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// lane l receives the value of lane l-1 / l+1 (v_mov_b32_dpp wave_shr:1 / wave_shl:1; the end lanes receive 0)
+__device__ __forceinline__ double dpp_from_lower(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_upper(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct WGeom {
+    int ntx, nty;        // 128-node x-tiles, RY-row y-tiles of the interior rows 1 .. NY-2
+    int nwg_xy;          // workgroups per z-chunk (four consecutive tiles of the row-major tile order each)
+    int nzc, zlen;       // z-chunks of zlen planes over the interior planes 1 .. NZ-2
+};
+
+// one row of one held plane: the two nodes of the lane and their x-neighbours (l = node i0-1, r = node i0+2)
+struct WRow { double l, x, y, r; };
+
+template <int CM, int RY, int MODE>
+__global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
+    __shared__ double sRed[4];
+    constexpr bool K1 = (MODE == APPLY_CG_K1), RES = (MODE == APPLY_RESIDUAL);
+    constexpr bool DI = K1 || RES;             // the pass needs the Jacobi diagonal^-1
+    constexpr int RH = RY + 2;
+    const GridDev& g = a.g;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD-aware order (workgroups b and b + 8 share an XCD): XCD x sweeps the contiguous range [x G/8, (x+1) G/8) — y-neighbouring tiles of one z-chunk
+    const int G = gridDim.x;
+    int wid = blockIdx.x;
+    if ((G & 7) == 0) wid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int zc = wid / wgm.nwg_xy;
+    const int w = (wid - zc * wgm.nwg_xy) * 4 + wv;
+    const int yt = w / wgm.ntx, xt = w - yt * wgm.ntx;
+    const int i0 = xt * 128 + 2 * lane;
+    const int j0 = 1 + yt * RY;
+    const int jmax = g.NY - 2;
+    const int lk0 = 1 + zc * wgm.zlen;
+    const int lk1 = min(lk0 + wgm.zlen, g.NZ - 1);
+    const bool active = yt < wgm.nty && zc < wgm.nzc && lk0 < lk1;          // wave-uniform
+
+    double alpha_prev = 0.0, beta = 0.0;
+    if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);          // (every thread of every workgroup: the prologue sum has barriers)
+    double acc = 0.0;
+    if (active) {
+        const double shift = a.in_shift;
+        const bool lane_ok = i0 < g.PX;
+        const bool ma = (i0 >= 1) && (i0 <= g.NX - 2);                      // node a = i0 is a free node
+        const bool mb = (i0 + 1 <= g.NX - 2);                               // node b = i0 + 1
+        const bool elane = (lane == 0 && i0 >= 1) || (lane == 63 && i0 + 2 < g.PX);
+        const long long eoff = (lane == 0) ? -1 : 2;
+        auto row_ok = [&](int j) { return j < g.NY; };
+        auto load2 = [&](const double* v, long long off) { return *reinterpret_cast<const double2*>(v + off); };
+        const double PG_CONSTANT* tab = (const double PG_CONSTANT*)a.ell;    // CM 2: the row table
+
+        // ---- coefficients -------------------------------------------------------------------------------------------------------------------
+        // CM 1: cA / cB = the 15 weights of node a / b of every own row, D / DE = diagonal^-1 of every held row (own nodes / the tile-edge neighbour)
+        double cA[CM == 1 ? RY : 1][15], cB[CM == 1 ? RY : 1][15];
+        double2 D[(CM == 1 && DI) ? RH : 1];
+        double DE[(CM == 1 && DI) ? RH : 1];
+        if (CM == 1) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const int j = j0 + r;
+                const long long off = (j <= jmax && lane_ok) ? (long long)j * g.PX + i0 : 0;
+#pragma unroll
+                for (int q = 0; q < 15; ++q) {
+                    const double2 c = load2(a.ell + (long long)q * a.ell_stride, off);
+                    cA[r][q] = c.x;
+                    cB[r][q] = c.y;
+                }
+            }
+            if (DI) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const int j = j0 - 1 + r;
+                    const bool rok = row_ok(j);
+                    D[r] = load2(a.wdinv, (rok && lane_ok) ? (long long)j * g.PX + i0 : 0);
+                    DE[r] = a.wdinv[(rok && elane) ? (long long)j * g.PX + i0 + eoff : 0];
+                }
+            }
+        }
+
+        // ---- one plane of the marched vector into registers ---------------------------------------------------------------------------------
+        // Loads are unconditional and unmasked (see k_fast::value_row): a lane / row outside the grid reads offset 0 of the vector and what it reads
+        // only reaches outputs that are masked or never stored.  K1: value = p_n = D^-1 r + beta p_{n-1}; PLAIN: in + shift; RESIDUAL: in.
+        auto load_plane = [&](int lk, WRow* rows, double2* po_out) {
+            double2 vin[RH], vp[RH];
+            double ein[RH], ep[RH];
+            double dsc[RH];                      // CM 2: D^-1 of the held rows of this plane (scalar loads, requested ahead of the vector loads)
+            if (CM == 2 && K1) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) dsc[r] = tab[((long long)lk * g.NY + min(j0 - 1 + r, g.NY - 1)) * 16 + 15];
+            }
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                const int j = j0 - 1 + r;
+                const bool rok = row_ok(j);
+                const long long off = (rok && lane_ok) ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0;
+                const long long offe = (rok && elane) ? (long long)lk * g.PP + (long long)j * g.PX + i0 + eoff : 0;
+                vin[r] = load2(a.in, off);
+                ein[r] = a.in[offe];
+                if (K1) {
+                    vp[r] = load2(a.p_old, off);
+                    ep[r] = a.p_old[offe];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                double2 val;
+                double e;
+                if (K1) {
+                    double dx, dy, de;
+                    if (CM == 1) {
+                        dx = D[r].x; dy = D[r].y; de = DE[r];
+                    } else {
+                        dx = dy = de = dsc[r];
+                    }
+                    val.x = dx * vin[r].x + beta * vp[r].x;
+                    val.y = dy * vin[r].y + beta * vp[r].y;
+                    e = de * ein[r] + beta * ep[r];
+                    if (po_out) po_out[r] = vp[r];
+                } else {
+                    val.x = vin[r].x + shift;
+                    val.y = vin[r].y + shift;
+                    e = ein[r] + shift;
+                }
+                const double lv = dpp_from_lower(val.y), rv = dpp_from_upper(val.x);
+                rows[r].x = val.x;
+                rows[r].y = val.y;
+                rows[r].l = (lane == 0) ? e : lv;
+                rows[r].r = (lane == 63) ? e : rv;
+            }
+        };
+        auto own_xload = [&](int lk, int j) {
+            const bool ok = j <= jmax && lane_ok;
+            return load2(a.x, ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0);
+        };
+        // K1: store p_n and x += alpha_{n-1} p_{n-1} of an owned row (every node of the row pair: Dirichlet nodes and pads hold p = 0, r = 0)
+        auto own_update = [&](int lk, int j, const WRow& pn, const double2& po, double2 xv) {
+            if (K1 && j <= jmax && lane_ok) {
+                const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
+                *reinterpret_cast<double2*>(a.p_new + off) = make_double2(pn.x, pn.y);
+                if (alpha_prev != 0.0) {
+                    xv.x += alpha_prev * po.x;
+                    xv.y += alpha_prev * po.y;
+                    *reinterpret_cast<double2*>(a.x + off) = xv;
+                }
+            }
+        };
+
+        WRow P[RH], C[RH], N[RH];
+        double2 PO[RH];
+        load_plane(lk0 - 1, P, nullptr);
+        load_plane(lk0, C, PO);
+        if (K1) {
+#pragma unroll
+            for (int r = 1; r <= RY; ++r) own_update(lk0, j0 - 1 + r, C[r], PO[r], own_xload(lk0, j0 - 1 + r));
+        }
+
+        for (int lk = lk0; lk < lk1; ++lk) {
+            // CM 2: the 128-byte line of every own row of this plane (15 weights + D^-1), requested before the plane's vector loads
+            double CS[CM == 2 ? RY : 1][16];
+            if (CM == 2) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    const long long e = ((long long)lk * g.NY + min(j0 + r, jmax)) * 16;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) CS[r][q] = tab[e + q];
+                }
+            }
+            double2 XV[RY];
+            if (K1 && lk + 1 < lk1) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) XV[r] = own_xload(lk + 1, j0 + r);
+            }
+            double2 RHS[RY];
+            if (RES) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    const int j = j0 + r;
+                    RHS[r] = make_double2(a.rhs_const, a.rhs_const);
+                    if (a.rhs) RHS[r] = load2(a.rhs, (j <= jmax && lane_ok) ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0);
+                }
+            }
+            load_plane(lk + 1, N, PO);
+
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                // (no branch around the stencil: a row beyond jmax — the second row of the last tile when RY = 2 — is computed on whatever its registers hold and
+                // neither stored nor summed; in one basic block the scalar loads of the weights are scheduled ahead of the waits for the plane)
+                const int c = r + 1;
+                const int j = j0 + r;
+                const bool jok = j <= jmax;                                  // wave-uniform
+                double ca[15], cb[15], da = 0.0, db = 0.0;
+                if (CM == 1) {
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) { ca[q] = cA[r][q]; cb[q] = cB[r][q]; }
+                    if (DI) { da = D[c].x; db = D[c].y; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) ca[q] = cb[q] = CS[r][q];
+                    if (DI) da = db = CS[r][15];
+                }
+                // 15-offset list (tables_math.h pg_off15): 0 centre, 1/2 -+x, 3/4 -+y, 5/6 -+z, 7/8 -+(1,1,0), 9/10 -+(1,0,1), 11/12 -+(0,1,1), 13/14 -+(1,1,1)
+                const double qa = ca[0] * C[c].x + ca[1] * C[c].l + ca[2] * C[c].y + ca[3] * C[c - 1].x + ca[4] * C[c + 1].x + ca[5] * P[c].x +
+                                  ca[6] * N[c].x + ca[7] * C[c - 1].l + ca[8] * C[c + 1].y + ca[9] * P[c].l + ca[10] * N[c].y + ca[11] * P[c - 1].x +
+                                  ca[12] * N[c + 1].x + ca[13] * P[c - 1].l + ca[14] * N[c + 1].y;
+                const double qb = cb[0] * C[c].y + cb[1] * C[c].x + cb[2] * C[c].r + cb[3] * C[c - 1].y + cb[4] * C[c + 1].y + cb[5] * P[c].y +
+                                  cb[6] * N[c].y + cb[7] * C[c - 1].x + cb[8] * C[c + 1].r + cb[9] * P[c].x + cb[10] * N[c].r + cb[11] * P[c - 1].y +
+                                  cb[12] * N[c + 1].y + cb[13] * P[c - 1].x + cb[14] * N[c + 1].r;
+                double2 o;
+                if (RES) {
+                    o.x = (ma && jok) ? RHS[r].x - qa : 0.0;
+                    o.y = (mb && jok) ? RHS[r].y - qb : 0.0;
+                    acc += da * o.x * o.x + db * o.y * o.y;                  // r . D^-1 r
+                } else {
+                    o.x = (ma && jok) ? qa : 0.0;
+                    o.y = (mb && jok) ? qb : 0.0;
+                    acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
+                }
+                if (lane_ok && jok) *reinterpret_cast<double2*>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0) = o;
+            }
+            if (K1 && lk + 1 < lk1) {
+#pragma unroll
+                for (int r = 1; r <= RY; ++r) own_update(lk + 1, j0 - 1 + r, N[r], PO[r], XV[r - 1]);
+            }
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                P[r] = C[r];
+                C[r] = N[r];
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, sRed);
+    dot_finish(tot, a.partials);
+}
+
+// K2 of the weighted PCG: r -= alpha q on the interior planes, partial r . D^-1 r with D^-1 from the compact table (CM 1: the interior plane
+// class [j * PX + i]; CM 2: entry 15 of the row's line).  Dirichlet nodes and pads hold r = q = 0: whatever diagonal they meet, they add 0.
+template <int CM>
+__global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const double* __restrict__ q, const double* __restrict__ dtab, GridDev g,
+                                              unsigned ppairs, unsigned total, double* scal, double* __restrict__ partials, DotIn di) {
+    __shared__ double sRed[4];
+    const double alpha = cg_alpha_in(di, scal, sRed);
+    double acc = 0.0;
+    const unsigned px2 = (unsigned)g.PX / 2;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned k = e / ppairs, rem = e - k * ppairs;
+        const long long off = (long long)(k + 1) * g.PP + 2LL * rem;
+        double2 rv = *reinterpret_cast<const double2*>(r + off);
+        const double2 qv = *reinterpret_cast<const double2*>(q + off);
+        double2 d;
+        if (CM == 1) {
+            d = *reinterpret_cast<const double2*>(dtab + 2LL * rem);
+        } else {
+            const unsigned j = rem / px2;
+            const double dd = dtab[((long long)(k + 1) * g.NY + j) * 16 + 15];
+            d = make_double2(dd, dd);
+        }
+        rv.x -= alpha * qv.x;
+        rv.y -= alpha * qv.y;
+        *reinterpret_cast<double2*>(r + off) = rv;
+        acc += d.x * rv.x * rv.x + d.y * rv.y * rv.y;
+    }
+    const double tot = block_sum_256(acc, sRed);
+    __syncthreads();
+    dot_finish(tot, partials);
+}
+
+// CM 2: the row tables [NZ * NY][16] from the compact rows of the column class "interior" (entry e = 3 * row + 1 of the q-major arrays):
+// 15 weights + (table of A) the Jacobi diagonal^-1
+__global__ __launch_bounds__(256) void k_wrowtab(const double* __restrict__ ellA, const double* __restrict__ ellM, long long stride, long long rows,
+                                                  double* __restrict__ rowA, double* __restrict__ rowM) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < rows * 16; t += (long long)gridDim.x * 256) {
+        const long long row = t >> 4;
+        const int q = (int)(t & 15);
+        const long long e = 3 * row + 1;
+        if (q < 15) {
+            rowA[t] = ellA[q * stride + e];
+            rowM[t] = ellM[q * stride + e];
+        } else {
+            const double d = ellA[e];
+            rowA[t] = d > 0.0 ? 1.0 / d : 0.0;
+            rowM[t] = 0.0;
+        }
+    }
+}
+
+WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
+    WGeom w{};
+    w.ntx = (g.NX - 1 + 127) / 128;
+    w.nty = (g.NY - 2 + RY - 1) / RY;
+    w.nwg_xy = (int)(((long long)w.ntx * w.nty + 3) / 4);
+    const int planes = g.NZ - 2;
+    // z-chunks: as few resident rounds of as short marches as possible (every chunk marches a two-plane prologue; CM 1 also loads its weights)
+    const int target = std::max(1, wg_per_cu * ctx->num_cu);
+    const int pcap = stencil_max_partials(const_cast<pdegpu_ctx*>(ctx));
+    int best_c = 1;
+    long long best = -1;
+    const int maxc = std::max(1, planes / 4);
+    for (int c = 1; c <= maxc; ++c) {
+        if ((long long)w.nwg_xy * c > pcap && c > 1) break;
+        const long long rounds = ((long long)w.nwg_xy * c + target - 1) / target;
+        const long long cost = rounds * ((planes + c - 1) / c + 3);
+        if (best < 0 || cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
+    if (ctx->fast_zlen > 0) best_c = std::max(1, (planes + ctx->fast_zlen - 1) / ctx->fast_zlen);
+    w.zlen = (planes + best_c - 1) / best_c;
+    w.nzc = (planes + w.zlen - 1) / w.zlen;
+    return w;
+}
+
+template <int CM, int RY>
+int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    static int occ[4] = {0, 0, 0, 0};
+    if (occ[mode & 3] == 0) {
+        int nb = 0;
+        hipError_t e;
+        switch (mode) {
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1>, 256, 0); break;
+        }
+        if (e != hipSuccess || nb < 1) nb = 2;
+        occ[mode & 3] = std::min(nb, 8);
+    }
+    const int wg = ctx->wfast_wg_per_cu > 0 ? ctx->wfast_wg_per_cu : occ[mode & 3];
+    const WGeom wgm = wmarch_geom(ctx, a.g, RY, wg);
+    const int G = (wgm.nwg_xy * wgm.nzc + 7) / 8 * 8;      // a multiple of 8: the XCD-aware order always applies (surplus workgroups idle)
+    if (li) { li->grid = G; li->block = 256; }
+    {
+        static const bool dbg = getenv("PDEGPU_DEBUG_GEOM") != nullptr;
+        static int last[4] = {-1, -1, -1, -1};
+        if (dbg && last[mode & 3] != G) {
+            last[mode & 3] = G;
+            fprintf(stderr, "[pdegpu wmarch] cm %d ry %d mode %d: %d x %d x %d nodes, %d x %d tiles, %d workgroups per chunk, %d chunks of %d planes, occ %d -> grid %d\n", CM, RY,
+                    mode, a.g.NX, a.g.NY, a.g.NZ, wgm.ntx, wgm.nty, wgm.nwg_xy, wgm.nzc, wgm.zlen, occ[mode & 3], G);
+        }
+    }
+    if (G == 0 || (li && li->dry)) return PDEGPU_OK;
+    switch (mode) {
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+    }
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+}  // namespace
+
+// a weighted session whose operator applications can march: 3-D, one slab owning every plane, every boundary node Dirichlet, at least one interior
+// node per axis, and an index range the 32-bit arithmetic of K2 covers
+bool wmarch_supported(const GridDev& g) {
+    if (g.dim != 3 || g.k0 != 0 || g.nkl != g.NZ || g.flat2d) return false;
+    if (g.NX < 3 || g.NY < 3 || g.NZ < 3) return false;
+    if (!(g.bc_mode == PDEGPU_BC_UNIFORM && g.bc_present[0])) return false;
+    return (long long)(g.NZ - 2) * (g.PP / 2) < 0x7fffffffLL;
+}
+
+// a.ell / a.ell_stride / a.ell_mode (= CM) / a.wdinv describe the coefficients (see the header comment); mode: PLAIN, RESIDUAL, CG_K1
+int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    if (mode != APPLY_PLAIN && mode != APPLY_RESIDUAL && mode != APPLY_CG_K1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weighted marching: PLAIN, RESIDUAL or K1");
+    const int ry = ctx->wfast_ry;
+    if (a.ell_mode == 1) return launch_wmarch<1, 1>(ctx, a, mode, li);
+    if (ry == 2) return launch_wmarch<2, 2>(ctx, a, mode, li);
+    return launch_wmarch<2, 1>(ctx, a, mode, li);
+}
+
+int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, double* scal, double* partials, LaunchInfo* li,
+              const DotIn& di) {
+    const unsigned ppairs = (unsigned)(g.PP / 2);
+    const unsigned total = (unsigned)(g.NZ - 2) * ppairs;
+    long long nb = ((long long)total + 255) / 256;
+    const long long cap = (long long)ctx->k2_grid_mult * ctx->num_cu;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    if (li) { li->grid = (int)nb; li->block = 256; }
+    if (cm == 1) hipLaunchKernelGGL((k_wk2<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, g, ppairs, total, scal, partials, di);
+    else hipLaunchKernelGGL((k_wk2<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, g, ppairs, total, scal, partials, di);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}
+
+int wmarch_rowtab(pdegpu_ctx* ctx, const GridDev& g, const double* ellA, const double* ellM, long long stride, double* rowA, double* rowM) {
+    const long long rows = (long long)g.NZ * g.NY;
+    long long nb = (rows * 16 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_wrowtab, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ellA, ellM, stride, rows, rowA, rowM);
+    PG_HIP(ctx, hipGetLastError());
+    return PDEGPU_OK;
+}

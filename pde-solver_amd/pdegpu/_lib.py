@@ -63,7 +63,7 @@ class Stats(C.Structure):
                 "linear_solves": self.linear_solves, "converged": bool(self.converged),
                 "final_rel_residual": self.final_rel_residual, "solve_ms": self.solve_ms, "cg_ms": self.cg_ms,
                 "kernel_ms": list(self.kernel_ms), "kernel_launches": list(self.kernel_launches),
-                "alg_bytes": list(self.alg_bytes), "path": {1: "fast", 2: "tridiagonal-direct", 3: "fast+boundary"}.get(self.path, "general")}
+                "alg_bytes": list(self.alg_bytes), "path": {1: "fast", 2: "tridiagonal-direct", 3: "fast+boundary", 4: "weighted-marching"}.get(self.path, "general")}
 
 
 _dp = C.POINTER(C.c_double)
@@ -82,6 +82,7 @@ SYMBOLS = {
     "pdegpu_heat_solve": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_heat_solve_weighted": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.POINTER(Heat), _dp, _dp, C.POINTER(Stats)]),
     "pdegpu_heat_solve_weighted_ic": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.POINTER(Heat), _dp, _dp, _dp, C.POINTER(Stats)]),
+    "pdegpu_heat_apply_weighted": (C.c_int, [_vp, C.POINTER(Grid), C.POINTER(Weight), C.c_double, C.c_double, _dp, _dp, C.c_int]),
     "pdegpu_weighted_rows_host": (C.c_int, [C.POINTER(Grid), C.POINTER(Weight), _dp, _dp, _dp]),
     "pdegpu_mass_solve": (C.c_int, [_vp, C.POINTER(Grid), _dp, _dp, C.c_double, C.c_int, C.POINTER(Stats)]),
     "pdegpu_heat_apply": (C.c_int, [_vp, C.POINTER(Grid), C.c_double, C.c_double, _dp, _dp, _dp, C.c_int]),

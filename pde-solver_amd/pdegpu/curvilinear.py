@@ -255,5 +255,5 @@ def solve_heat_3d_cylinder_fallback(Lx, nx, ny, nz, diffusivity, T_boundary, T_i
     else:
         meta["diffusivity"] = diffusivity
     meta.update({"backend": "pdegpu-hip-gfx950", "element_mode": "p1split", "cg_iterations": int(st["cg_iterations"]),
-                 "mesh": "BoxMesh fallback (no mshr)"})
+                 "solver_path": st.get("path", "general"), "solve_ms": float(st.get("solve_ms", 0.0)), "mesh": "BoxMesh fallback (no mshr)"})
     return TimeSeriesField(coords=coords, values=values, times=times, dim=3, meta=meta)

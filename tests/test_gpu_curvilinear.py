@@ -160,6 +160,7 @@ def test_compact_coefficient_rows_equal_one_row_per_node(lib, gpu_ctx, case):
     from pdegpu import _lib, curvilinear as cv, heat
     outs = []
     try:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast", 0))        # (the class-table kernels: the marching ones have tests of their own)
         for compact in (1, 0):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"ell_compact", compact))
             if case.startswith("spherical"):
@@ -176,18 +177,22 @@ def test_compact_coefficient_rows_equal_one_row_per_node(lib, gpu_ctx, case):
             outs.append(f)
     finally:
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"ell_compact", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast", 1))
     assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"]
     assert (outs[0].meta["cg_iterations"] > 0) == (case != "spherical_two_planes")      # (one cell in phi under a uniform boundary value: no unknowns)
     assert np.array_equal(outs[0].values, outs[1].values)
 
 
 @pytest.mark.parametrize("case", ["spherical", "cylinder"])
-def test_weighted_pcg_without_reduce_launches_is_bitwise_the_eager_one(lib, gpu_ctx, case):
+@pytest.mark.parametrize("wfast", [0, 1])
+def test_weighted_pcg_without_reduce_launches_is_bitwise_the_eager_one(lib, gpu_ctx, case, wfast):
     """lazy_dot = 1 (default): inside a chunk K2's prologue sums K1's p.q partials and the next K1's prologue K2's r.z partials — no reduce launches, the
-    same summation order; the weighted Jacobi-PCG (class-table K1 with per-node coefficients, k_k2_pc) must give the fields of the eager loop bit for bit"""
+    same summation order; the weighted Jacobi-PCG (wfast 0: class-table K1 with per-node coefficients, k_k2_pc; 1: the marching kernels) must give the
+    fields of the eager loop bit for bit"""
     from pdegpu import _lib, curvilinear as cv, heat
     outs = []
     try:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast", wfast))
         for lazy in (1, 0):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", lazy))
             if case == "spherical":
@@ -198,5 +203,6 @@ def test_weighted_pcg_without_reduce_launches_is_bitwise_the_eager_one(lib, gpu_
             outs.append(f)
     finally:
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"lazy_dot", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast", 1))
     assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"] > 0
     assert np.array_equal(outs[0].values, outs[1].values)
