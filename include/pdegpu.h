@@ -165,8 +165,9 @@ const char* pdegpu_version(void);
  * wfast              | 1       | weighted 3-D operators on a box whose boundary nodes are all constrained, compact rows: z-marching kernels with the weights
  *                    |         | in registers (weight independent of the marching coordinate) or SGPRs (independent of x), 72 B/DoF per PCG
  *                    |         | iteration (csrc/wmarch.hip); 0 = class-table kernels reading the rows (88 B/DoF, 45 loads per node)
- * wfast_ry           | 1       | rows per wavefront column of those kernels where the weights are wave-uniform (1|2)
+ * wfast_ry           | 2       | rows per wavefront column of those kernels where the weights are wave-uniform (1|2)
  * wfast_wg_per_cu    | 0       | workgroups per CU their z-chunking aims for (0 = occupancy API)
+ * wfast_k2_mult      | 4       | workgroups per CU of their K2 (a wavefront per grid row)
  * ell_compact        | 1       | weighted (curvilinear / composite) 3-D operators whose weight does not depend on one coordinate store the coefficient
  *                    |         | rows of three representative planes / columns instead of one row per node (0 = one row per node)
  * el_fast            | 1       | 3-D: z-marching block stencil (0 = thread-per-node class-table kernel)

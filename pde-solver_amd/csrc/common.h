@@ -41,7 +41,9 @@ struct pdegpu_ctx {
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
     int wfast = 1;              // weighted 3-D operators whose coefficient rows are compact (ell_compact) on an all-Dirichlet box: 1 = z-marching kernels with the
                                 // weights in registers / SGPRs (wmarch.hip, 72 B/DoF per PCG iteration); 0 = class-table kernels reading the rows (88 B/DoF)
-    int wfast_ry = 1;           // rows per wavefront column of the weighted marching kernels whose weights are wave-uniform (1 | 2); per-lane weights: 1
+    int wfast_ry = 2;           // rows per wavefront column of the weighted marching kernels whose weights are wave-uniform (1 | 2; 192^3 composite core 53.7 -> 62.3 GDoF/s
+                                // with 2); per-lane weights: always 1 (the 30 weights of a row pair leave no registers for a second row)
+    int wfast_k2_mult = 4;      // K2 of those sessions: workgroups per CU (a wavefront per grid row; 192^3 composite core: 57 -> 60 GDoF/s from 2 to 4)
     int wfast_wg_per_cu = 0;    // workgroups per CU their z-chunking aims for; 0 = what the occupancy API reports
     int ell_compact = 1;        // weighted operators whose weight does not depend on one coordinate keep the coefficient rows of three representative
                                 // planes / columns instead of one row per node (0: always one row per node)
@@ -281,8 +283,8 @@ int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, dou
 // wmarch.hip: z-marching kernels of the weighted 3-D operators
 bool wmarch_supported(const GridDev& g);
 int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
-int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, double* scal, double* partials, LaunchInfo* li,
-              const DotIn& di = DotIn());
+int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, double* scal, double* partials,
+              LaunchInfo* li, const DotIn& di = DotIn());
 int wmarch_rowtab(pdegpu_ctx* ctx, const GridDev& g, const double* ellA, const double* ellM, long long stride, double* rowA, double* rowM);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);

@@ -12,10 +12,11 @@
 // Otherwise the kernel is the plain 15-point marching kernel of stencil.hip: a wavefront owns 128 nodes x RY rows, keeps three planes in
 // registers, takes x-neighbours by DPP wave shifts (shifted ONCE per plane and row: the shifted value is part of the rotating plane state, because
 // with per-node weights the constant-coefficient trick of shifting weighted sums is gone), reads every input plane once.
-// Jacobi-PCG without a z vector: K1 forms z = D^-1 r on the fly wherever it forms p = z + beta p (D^-1 sits in registers / SGPRs like the
-// weights), so an iteration moves  K1: read r, p, x; write p, x, q (48 B/DoF)  +  K2: read r, q; write r (24 B/DoF, D^-1 from the compact table
-// for the r.z sum)  =  72 B/DoF instead of the 88 of the class-table form (k_general<..., ELL> + k_k2_pc, which also costs 45 load instructions
-// per node).  Sessions: one slab owning every plane, every boundary node Dirichlet (the uniform boundary value of the tools).
+// Jacobi-PCG with ONE residual vector: the session's r holds z = D^-1 r, the only form K1 needs (p = z + beta p, exactly the plain kernel's
+// recurrence, no diagonal in K1); the residual pass stores z = D^-1 (b - A x), K2 updates z -= alpha D^-1 q and sums r.z = sum D z^2 with D^-1 from
+// the compact table (a flat pass with registers to spare).  An iteration moves  K1: read z, p, x; write p, x, q (48 B/DoF)  +  K2: read z, q; write
+// z (24 B/DoF)  =  72 B/DoF instead of the 88 of the class-table form (k_general<..., ELL> + k_k2_pc, which also costs 45 load instructions per
+// node).  Sessions: one slab owning every plane, every boundary node Dirichlet (the uniform boundary value of the tools).
 #include "common.h"
 #include "dot_finish.h"
 #include <algorithm>
@@ -64,7 +65,7 @@ template <int CM, int RY, int MODE>
 __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     __shared__ double sRed[4];
     constexpr bool K1 = (MODE == APPLY_CG_K1), RES = (MODE == APPLY_RESIDUAL);
-    constexpr bool DI = K1 || RES;             // the pass needs the Jacobi diagonal^-1
+    constexpr bool DI = RES;                   // the pass needs the Jacobi diagonal^-1 (of its own rows)
     constexpr int RH = RY + 2;
     const GridDev& g = a.g;
     const int lane = threadIdx.x & 63;
@@ -98,10 +99,9 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
         const double PG_CONSTANT* tab = (const double PG_CONSTANT*)a.ell;    // CM 2: the row table
 
         // ---- coefficients -------------------------------------------------------------------------------------------------------------------
-        // CM 1: cA / cB = the 15 weights of node a / b of every own row, D / DE = diagonal^-1 of every held row (own nodes / the tile-edge neighbour)
+        // CM 1: cA / cB = the 15 weights of node a / b of every own row, D = diagonal^-1 of the own rows (residual pass)
         double cA[CM == 1 ? RY : 1][15], cB[CM == 1 ? RY : 1][15];
-        double2 D[(CM == 1 && DI) ? RH : 1];
-        double DE[(CM == 1 && DI) ? RH : 1];
+        double2 D[(CM == 1 && DI) ? RY : 1];
         if (CM == 1) {
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
@@ -116,26 +116,19 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
             }
             if (DI) {
 #pragma unroll
-                for (int r = 0; r < RH; ++r) {
-                    const int j = j0 - 1 + r;
-                    const bool rok = row_ok(j);
-                    D[r] = load2(a.wdinv, (rok && lane_ok) ? (long long)j * g.PX + i0 : 0);
-                    DE[r] = a.wdinv[(rok && elane) ? (long long)j * g.PX + i0 + eoff : 0];
+                for (int r = 0; r < RY; ++r) {
+                    const int j = j0 + r;
+                    D[r] = load2(a.wdinv, (j <= jmax && lane_ok) ? (long long)j * g.PX + i0 : 0);
                 }
             }
         }
 
         // ---- one plane of the marched vector into registers ---------------------------------------------------------------------------------
         // Loads are unconditional and unmasked (see k_fast::value_row): a lane / row outside the grid reads offset 0 of the vector and what it reads
-        // only reaches outputs that are masked or never stored.  K1: value = p_n = D^-1 r + beta p_{n-1}; PLAIN: in + shift; RESIDUAL: in.
+        // only reaches outputs that are masked or never stored.  K1: value = p_n = z + beta p_{n-1}; PLAIN: in + shift; RESIDUAL: in.
         auto load_plane = [&](int lk, WRow* rows, double2* po_out) {
             double2 vin[RH], vp[RH];
             double ein[RH], ep[RH];
-            double dsc[RH];                      // CM 2: D^-1 of the held rows of this plane (scalar loads, requested ahead of the vector loads)
-            if (CM == 2 && K1) {
-#pragma unroll
-                for (int r = 0; r < RH; ++r) dsc[r] = tab[((long long)lk * g.NY + min(j0 - 1 + r, g.NY - 1)) * 16 + 15];
-            }
 #pragma unroll
             for (int r = 0; r < RH; ++r) {
                 const int j = j0 - 1 + r;
@@ -154,15 +147,9 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                 double2 val;
                 double e;
                 if (K1) {
-                    double dx, dy, de;
-                    if (CM == 1) {
-                        dx = D[r].x; dy = D[r].y; de = DE[r];
-                    } else {
-                        dx = dy = de = dsc[r];
-                    }
-                    val.x = dx * vin[r].x + beta * vp[r].x;
-                    val.y = dy * vin[r].y + beta * vp[r].y;
-                    e = de * ein[r] + beta * ep[r];
+                    val.x = vin[r].x + beta * vp[r].x;
+                    val.y = vin[r].y + beta * vp[r].y;
+                    e = ein[r] + beta * ep[r];
                     if (po_out) po_out[r] = vp[r];
                 } else {
                     val.x = vin[r].x + shift;
@@ -240,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                 if (CM == 1) {
 #pragma unroll
                     for (int q = 0; q < 15; ++q) { ca[q] = cA[r][q]; cb[q] = cB[r][q]; }
-                    if (DI) { da = D[c].x; db = D[c].y; }
+                    if (DI) { da = D[r].x; db = D[r].y; }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 15; ++q) ca[q] = cb[q] = CS[r][q];
@@ -254,10 +241,10 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                                   cb[6] * N[c].y + cb[7] * C[c - 1].x + cb[8] * C[c + 1].r + cb[9] * P[c].x + cb[10] * N[c].r + cb[11] * P[c - 1].y +
                                   cb[12] * N[c + 1].y + cb[13] * P[c - 1].x + cb[14] * N[c + 1].r;
                 double2 o;
-                if (RES) {
-                    o.x = (ma && jok) ? RHS[r].x - qa : 0.0;
-                    o.y = (mb && jok) ? RHS[r].y - qb : 0.0;
-                    acc += da * o.x * o.x + db * o.y * o.y;                  // r . D^-1 r
+                if (RES) {                                                   // z = D^-1 (rhs - A in);  r.z = D z^2
+                    o.x = (ma && jok) ? da * (RHS[r].x - qa) : 0.0;
+                    o.y = (mb && jok) ? db * (RHS[r].y - qb) : 0.0;
+                    acc += ca[0] * o.x * o.x + cb[0] * o.y * o.y;            // (the centre weight IS the diagonal)
                 } else {
                     o.x = (ma && jok) ? qa : 0.0;
                     o.y = (mb && jok) ? qb : 0.0;
@@ -280,32 +267,56 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     dot_finish(tot, a.partials);
 }
 
-// K2 of the weighted PCG: r -= alpha q on the interior planes, partial r . D^-1 r with D^-1 from the compact table (CM 1: the interior plane
-// class [j * PX + i]; CM 2: entry 15 of the row's line).  Dirichlet nodes and pads hold r = q = 0: whatever diagonal they meet, they add 0.
+// K2 of the weighted PCG on z = D^-1 r: z -= alpha D^-1 q on the free rows, partial r.z = sum D z^2.  A wavefront takes whole grid rows (j, k), so the
+// diagonal comes without index arithmetic: CM 1 from the interior plane class of the compact rows (D = centre weight, D^-1: [j * PX + i]), CM 2 as two
+// scalars of the row's line (entry 0 = D, entry 15 = D^-1).  Dirichlet nodes and pads of a free row hold z = q = 0 and add 0.
 template <int CM>
-__global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const double* __restrict__ q, const double* __restrict__ dtab, GridDev g,
-                                              unsigned ppairs, unsigned total, double* scal, double* __restrict__ partials, DotIn di) {
+__global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const double* __restrict__ q, const double* __restrict__ dtab, const double* __restrict__ ditab,
+                                              GridDev g, int nrows, double* scal, double* __restrict__ partials, DotIn di) {
     __shared__ double sRed[4];
     const double alpha = cg_alpha_in(di, scal, sRed);
     double acc = 0.0;
-    const unsigned px2 = (unsigned)g.PX / 2;
-    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
-        const unsigned k = e / ppairs, rem = e - k * ppairs;
-        const long long off = (long long)(k + 1) * g.PP + 2LL * rem;
-        double2 rv = *reinterpret_cast<const double2*>(r + off);
-        const double2 qv = *reinterpret_cast<const double2*>(q + off);
-        double2 d;
-        if (CM == 1) {
-            d = *reinterpret_cast<const double2*>(dtab + 2LL * rem);
-        } else {
-            const unsigned j = rem / px2;
-            const double dd = dtab[((long long)(k + 1) * g.NY + j) * 16 + 15];
-            d = make_double2(dd, dd);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ny2 = g.NY - 2, px2 = g.PX / 2;
+    const double PG_CONSTANT* tab = (const double PG_CONSTANT*)dtab;
+    for (int row = blockIdx.x * 4 + wv; row < nrows; row += gridDim.x * 4) {       // wave-uniform
+        const int k = row / ny2, j = row - k * ny2 + 1;
+        const long long base = (long long)(k + 1) * g.PP + (long long)j * g.PX;
+        double ds = 0.0, dis = 0.0;
+        if (CM == 2) {
+            const long long e = ((long long)(k + 1) * g.NY + j) * 16;
+            ds = tab[e];
+            dis = tab[e + 15];
         }
-        rv.x -= alpha * qv.x;
-        rv.y -= alpha * qv.y;
-        *reinterpret_cast<double2*>(r + off) = rv;
-        acc += d.x * rv.x * rv.x + d.y * rv.y * rv.y;
+        for (int s0 = 0; s0 < px2; s0 += 128) {
+            // two 64-pair segments per round: their loads are in flight together
+            const int sa = s0 + lane, sb = s0 + 64 + lane;
+            const bool oka = sa < px2, okb = sb < px2;
+            const long long offa = base + 2LL * (oka ? sa : 0), offb = base + 2LL * (okb ? sb : 0);
+            double2 ra = *reinterpret_cast<const double2*>(r + offa), rb = *reinterpret_cast<const double2*>(r + offb);
+            const double2 qa = *reinterpret_cast<const double2*>(q + offa), qb = *reinterpret_cast<const double2*>(q + offb);
+            double2 da = make_double2(ds, ds), db = da, ia = make_double2(dis, dis), ib = ia;
+            if (CM == 1) {
+                const long long ta = (long long)j * g.PX + 2LL * (oka ? sa : 0), tb = (long long)j * g.PX + 2LL * (okb ? sb : 0);
+                da = *reinterpret_cast<const double2*>(dtab + ta);
+                db = *reinterpret_cast<const double2*>(dtab + tb);
+                ia = *reinterpret_cast<const double2*>(ditab + ta);
+                ib = *reinterpret_cast<const double2*>(ditab + tb);
+            }
+            ra.x -= alpha * (ia.x * qa.x);
+            ra.y -= alpha * (ia.y * qa.y);
+            rb.x -= alpha * (ib.x * qb.x);
+            rb.y -= alpha * (ib.y * qb.y);
+            if (oka) {
+                *reinterpret_cast<double2*>(r + offa) = ra;
+                acc += da.x * ra.x * ra.x + da.y * ra.y * ra.y;
+            }
+            if (okb) {
+                *reinterpret_cast<double2*>(r + offb) = rb;
+                acc += db.x * rb.x * rb.x + db.y * rb.y * rb.y;
+            }
+        }
     }
     const double tot = block_sum_256(acc, sRed);
     __syncthreads();
@@ -398,12 +409,12 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
 }  // namespace
 
 // a weighted session whose operator applications can march: 3-D, one slab owning every plane, every boundary node Dirichlet, at least one interior
-// node per axis, and an index range the 32-bit arithmetic of K2 covers
+// node per axis
 bool wmarch_supported(const GridDev& g) {
     if (g.dim != 3 || g.k0 != 0 || g.nkl != g.NZ || g.flat2d) return false;
     if (g.NX < 3 || g.NY < 3 || g.NZ < 3) return false;
     if (!(g.bc_mode == PDEGPU_BC_UNIFORM && g.bc_present[0])) return false;
-    return (long long)(g.NZ - 2) * (g.PP / 2) < 0x7fffffffLL;
+    return (long long)(g.NZ - 2) * (g.NY - 2) < 0x7fffffffLL;
 }
 
 // a.ell / a.ell_stride / a.ell_mode (= CM) / a.wdinv describe the coefficients (see the header comment); mode: PLAIN, RESIDUAL, CG_K1
@@ -411,21 +422,21 @@ int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li
     if (mode != APPLY_PLAIN && mode != APPLY_RESIDUAL && mode != APPLY_CG_K1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weighted marching: PLAIN, RESIDUAL or K1");
     const int ry = ctx->wfast_ry;
     if (a.ell_mode == 1) return launch_wmarch<1, 1>(ctx, a, mode, li);
-    if (ry == 2) return launch_wmarch<2, 2>(ctx, a, mode, li);
-    return launch_wmarch<2, 1>(ctx, a, mode, li);
+    if (ry == 1) return launch_wmarch<2, 1>(ctx, a, mode, li);
+    return launch_wmarch<2, 2>(ctx, a, mode, li);
 }
 
-int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, double* scal, double* partials, LaunchInfo* li,
-              const DotIn& di) {
-    const unsigned ppairs = (unsigned)(g.PP / 2);
-    const unsigned total = (unsigned)(g.NZ - 2) * ppairs;
-    long long nb = ((long long)total + 255) / 256;
-    const long long cap = (long long)ctx->k2_grid_mult * ctx->num_cu;
+// CM 1: dtab = the diagonal (compact rows of A, interior plane class, weight 0), ditab = its inverse, both [j * PX + i]; CM 2: dtab = the row table of A
+int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, double* scal, double* partials,
+              LaunchInfo* li, const DotIn& di) {
+    const int nrows = (g.NZ - 2) * (g.NY - 2);
+    long long nb = ((long long)nrows + 3) / 4;
+    const long long cap = (long long)(ctx->wfast_k2_mult > 0 ? ctx->wfast_k2_mult : 4) * ctx->num_cu;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     if (li) { li->grid = (int)nb; li->block = 256; }
-    if (cm == 1) hipLaunchKernelGGL((k_wk2<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, g, ppairs, total, scal, partials, di);
-    else hipLaunchKernelGGL((k_wk2<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, g, ppairs, total, scal, partials, di);
+    if (cm == 1) hipLaunchKernelGGL((k_wk2<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, scal, partials, di);
+    else hipLaunchKernelGGL((k_wk2<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, scal, partials, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

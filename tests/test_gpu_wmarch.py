@@ -57,7 +57,7 @@ def test_marching_weighted_operator_matches_the_assembled_matrix(lib, gpu_ctx, c
     try:
         L.check(gpu_ctx, lib.pdegpu_heat_apply_weighted(gpu_ctx, grid, w, cM, cK, L.dptr(x), L.dptr(y), 1))
     finally:
-        L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", 1))
+        L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", 2))
     scale = np.abs(A).dot(np.abs(x)).max()
     assert np.abs(y - ref).max() <= 1e-13 * scale
     assert np.abs(ref).max() > 1e-3 * scale                                  # (the comparison is not one of zeros)
@@ -115,7 +115,7 @@ def test_x_independent_weights_march_and_match_the_oracle(lib, gpu_ctx, case, ry
             ref = o.solve_heat_3d(**kw)
             got = heat._solve_heat_3d_raw(rtol=1e-12, **kw)
     finally:
-        L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", 1))
+        L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", 2))
     assert got.meta.get("solver_path", "weighted-marching") == "weighted-marching"
     assert np.abs(got.values - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
 
