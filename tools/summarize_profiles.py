@@ -1,5 +1,5 @@
 """Condense gpurun_out/prof (rocprofv3 --kernel-trace --stats and separate --pmc FETCH_SIZE / WRITE_SIZE passes)
-into the small, committed files under profiles/.   usage: python tools/summarize_profiles.py r01 [tag]
+into the small, committed files under profiles/.   usage: python tools/summarize_profiles.py r01 [tag [profile-folder under gpurun_out]]
 
 HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE reports exactly half the bytes of a wide (16 B/lane) coalesced streaming read, so the
@@ -16,7 +16,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 tag = ("_" + sys.argv[2]) if len(sys.argv) > 2 else ""
-prof = ROOT / "gpurun_out" / "prof"
+prof = ROOT / "gpurun_out" / (sys.argv[3] if len(sys.argv) > 3 else "prof")
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 
