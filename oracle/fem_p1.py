@@ -197,14 +197,18 @@ def _initial_condition(coords, cells, M, initial_type, T_initial, A, k):
 
 def _heat_core(coords, cells, dir_mask, dir_vals, kappa, T_initial, dt, num_steps, steady,
                source_type, source_value, initial_type, initial_amplitude, initial_wavenumber,
-               refactor_each_step=True):
-    """Shared body of the three Cartesian heat solvers (:259-318, :391-447, :653-716)."""
-    K, M, load = assemble_scalar(coords, cells)
+               refactor_each_step=True, matrices=None):
+    """Shared body of the three Cartesian heat solvers (:259-318, :391-447, :653-716).  matrices = (K, M, load) of another element on the
+    same nodes (oracle.fem_q1) runs the identical loops on them; constant / zero initial conditions only in that case."""
+    K, M, load = assemble_scalar(coords, cells) if matrices is None else matrices
     f = float(source_value) if source_type == "constant" else 0.0
     if steady:
         u = solve_dirichlet(kappa * K, f * load, dir_mask, dir_vals)
         return u[None, :], np.array([0.0])
-    u_n = _initial_condition(coords, cells, M, initial_type, T_initial, initial_amplitude, initial_wavenumber)
+    if matrices is None:
+        u_n = _initial_condition(coords, cells, M, initial_type, T_initial, initial_amplitude, initial_wavenumber)
+    else:
+        u_n = np.zeros(load.shape[0]) if initial_type == "zero" else np.full(load.shape[0], float(T_initial))
     u_n = np.where(dir_mask, dir_vals, u_n)               # bc.apply(u_n.vector())
     snaps, times = [u_n.copy()], [0.0]
     A = (M + dt * kappa * K).tocsr()
