@@ -154,8 +154,10 @@ const char* pdegpu_version(void);
  * plane2d            | 1       | 2-D grids: K1 / K2 as one-round tiles (0 = flat view of the marching kernels)
  * plane2d_ry         | 4       | rows per wavefront tile of that form (2|4|8)
  * persist2d          | 1       | 2-D grids up to 1024 cells wide: the whole CG loop in ONE cooperative launch, state in registers
- *                    |         | (2 / 3 = other grid-barrier forms).  Traced by rocprofv3, whose exit handler then faults inside
- *                    |         | libhsa-runtime64 AFTER the stats files are written (profiles/r03_rocprofv3_exit_abort.log)
+ *                    |         | (2 / 3 = other grid-barrier forms)
+ * persist2d_launch   | 0       | 1 = that kernel is launched as an ordinary kernel on the same occupancy-sized grid (its own barriers have a spin
+ *                    |         | limit and a fail flag): for runs under rocprofv3, whose exit handler faults inside libhsa-runtime64 after a
+ *                    |         | cooperative launch (profiles/r03_rocprofv3_exit_abort.log)
  * persist2d_sr       | 1       | that launch uses the single-reduction recurrences (one grid barrier + one neighbour hand-off)
  * hybrid_bc          | 1       | natural faces: marching kernel on the interior + class-table kernel on the boundary nodes
  * hybrid_fx          | 1       | ... with the natural x-face rows inside the marching kernel

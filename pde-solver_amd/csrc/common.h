@@ -66,6 +66,7 @@ struct pdegpu_ctx {
                                 // the same iteration counts, config 2: 13.3 -> 11.7 us per iteration); 0 = classic recurrences
     int persist2d = 1;          // 2-D grids up to 1024 cells wide and 8 rows per CU: the whole CG loop in ONE cooperative launch with the state
                                 // in registers (persist2d.hip); 0 = one launch per kernel
+    int persist2d_launch = 0;   // that launch: 0 = hipLaunchCooperativeKernel (the runtime checks co-residency), 1 = ordinary launch of the same grid (profiling runs)
     int plane2d = 1;            // 2-D grids: 1 = the two CG kernels load their tile in one round (k_plane2d); 0 = flat view of the marching kernels
     int hybrid_k2 = 1;          // hybrid sessions: 1 = 64 B/DoF variant as on Dirichlet grids (K1 stores no q, K2 applies the operator again: marching + boundary launch)
     int hybrid_fx = 1;          // hybrid sessions: 1 = the marching kernel computes the x-face rows too (the class-table pass keeps the y / z faces)

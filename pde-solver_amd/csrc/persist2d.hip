@@ -658,7 +658,12 @@ int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double*
             default: fn = reinterpret_cast<const void*>(k_cg2d_persistent<8>); break;
         }
     }
-    PG_HIP(ctx, hipLaunchCooperativeKernel(fn, dim3(p->G), dim3(kNW * 64), args, 0, ctx->stream));
+    // persist2d_launch = 1: an ordinary launch of the same grid.  The cooperative launch only adds the runtime's co-residency check (G <= num_cu
+    // workgroups, one per CU: resident on an otherwise idle device); the kernel's own barriers carry a spin limit and a fail flag, so a grid that
+    // is not resident ends in the error below instead of a hang.  For runs under rocprofv3, whose exit handler faults in libhsa-runtime64 after a
+    // cooperative launch (profiles/r03_rocprofv3_exit_abort.log).
+    if (ctx->persist2d_launch == 1) PG_HIP(ctx, hipLaunchKernel(fn, dim3(p->G), dim3(kNW * 64), args, 0, ctx->stream));
+    else PG_HIP(ctx, hipLaunchCooperativeKernel(fn, dim3(p->G), dim3(kNW * 64), args, 0, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(p->h_sync, p->sync, 16, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (p->h_sync[1] != 0u) return pdegpu_set_err(ctx, PDEGPU_EHIP, "persistent 2-D CG: a grid barrier timed out (the grid was not co-resident?)");

@@ -830,6 +830,20 @@ def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib,
             assert rel_err(a.values, o.solve_heat_2d(**{**kw, **extra}).values) < TOL
 
 
+def test_persistent_2d_cg_as_an_ordinary_launch_is_bitwise_the_cooperative_one(lib, gpu_ctx):
+    """persist2d_launch = 1 (profiling runs): the same kernel on the same occupancy-sized grid without the cooperative-launch API — same fields, same counts"""
+    from pdegpu import heat, _lib
+    kw = dict(Lx=1.0, Ly=0.6, nx=300, ny=513, diffusivity=0.9, T_boundary=1.5, T_initial=20.0, dt=0.002, num_steps=2, rtol=1e-12)
+    outs = []
+    try:
+        for mode in (0, 1):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_launch", mode))
+            outs.append(heat._solve_heat_2d_raw(**kw))
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_launch", 0))
+    assert outs[0].meta["cg_iterations"] == outs[1].meta["cg_iterations"] > 0 and np.array_equal(outs[0].values, outs[1].values)
+
+
 def test_persistent_2d_cg_at_a_tight_tolerance_single_reduction_vs_classic(lib, gpu_ctx):
     """an ill-conditioned 2-D system (stretched cells, steady) at rtol = 1e-13: the single-reduction recurrences of the cooperative
     launch may lose positivity near the tolerance; the solve then retries with the classic recurrences instead of reporting

@@ -1,5 +1,9 @@
+"""configs 2 and 5 end to end for rocprofv3 --kernel-trace --stats.  The persistent 2-D kernel is launched as an ordinary kernel here (tunable
+persist2d_launch = 1): after a cooperative launch the profiler's exit handler faults inside libhsa-runtime64 (profiles/r03_rocprofv3_exit_abort.log)."""
+import os
 import sys, time
 from pathlib import Path
+os.environ.setdefault("PDEGPU_PERSIST2D_LAUNCH", "1")
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "pde-solver_amd")]
 from pdegpu import heat, elasticity, _lib
