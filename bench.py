@@ -159,6 +159,8 @@ class Runner:
         # PDEGPU_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, planes
         # are staged through the host by pdegpu.dist); the measured configuration is always nccl = RCCL, one rank per GPU
         self.backend = os.environ.get("PDEGPU_BENCH_BACKEND", "nccl")
+        if self.backend != "nccl" and args.transport == "library" and self.world > 1:
+            raise SystemExit("--transport library needs one GPU per rank (RCCL refuses ranks that share a device): not available in the gloo rehearsal")
         if self.backend != "nccl":
             local_rank = local_rank % torch.cuda.device_count()
         self.local_rank = local_rank
@@ -170,6 +172,32 @@ class Runner:
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.stream = torch.cuda.Stream(device=local_rank)
+        self._comm = self._comm_ctx = None
+
+    def native_comm(self):
+        """libpdegpu's RCCL communicator of this rank (csrc/comm.hip), made ONCE per process on a context of its own and reused by every case that
+        asks for it: one ncclCommInitRank per run, collective over the ranks"""
+        if self._comm is None:
+            from pdegpu.dist import NativeComm
+
+            class _Holder:
+                pass
+            h = _Holder()
+            h.ctx = C.c_void_p()
+            lib = self.L.load_library()
+            sp = C.c_void_p(self.stream.cuda_stream) if self.stream.cuda_stream else None
+            rc = lib.pdegpu_create(C.byref(h.ctx), self.local_rank, sp)
+            if rc != 0:
+                raise self.L.PdeGpuError(rc, "pdegpu_create for the communicator failed")
+            self._comm_ctx = h
+            self._comm = NativeComm(h, self.rank, self.world)
+        return self._comm
+
+    def close_comm(self):
+        if self._comm is not None:
+            self._comm.close()
+            self.L.load_library().pdegpu_destroy(self._comm_ctx.ctx)
+            self._comm = self._comm_ctx = None
 
     def fence(self):
         self.torch.cuda.synchronize()
@@ -195,7 +223,8 @@ class Runner:
         res = {"unknowns": unknowns, "cells": [nx, ny, nz], "planes_rank0": nk}
         with torch.cuda.stream(self.stream):
             eng = GpuSlabEngine(grid, heat, k0, nk, self.local_rank, self.stream)
-            cg = SlabCG(eng, rank, world, overlap=not self.args.no_overlap, variant=self.args.cg_variant)
+            main_comm = self.native_comm() if (case.get("transport") == "library" and world > 1) else None
+            cg = SlabCG(eng, rank, world, overlap=not self.args.no_overlap, variant=self.args.cg_variant, comm=main_comm)
             cg.force_collectives = bool(case.get("force_collectives"))
             if extras_n1:
                 # in-run streaming ceilings and the bare SpMV are measured FIRST (they use r, q, b as scratch, so they must precede
@@ -266,8 +295,7 @@ class Runner:
             if case.get("native_comm"):
                 # the same session again with the exchange and the all-reduce(s) issued by the library itself on its own RCCL communicator
                 # (csrc/comm.hip; a chunk of iterations = ONE C call), alternating with the torch.distributed-driven loop
-                from pdegpu.dist import NativeComm
-                comm = NativeComm(eng, rank, world)
+                comm = self.native_comm()
                 ab = {}
                 for label, c in (("library_rccl", comm), ("torch_distributed", None), ("library_rccl_2", comm), ("torch_distributed_2", None)):
                     cg.comm = c
@@ -278,10 +306,9 @@ class Runner:
                     cg.iterate(steps)
                     self.fence()
                     ab[label] = max_over_ranks(time.perf_counter() - t0) / steps * 1e3
-                cg.comm, cg.force_collectives = None, False
+                cg.comm, cg.force_collectives = main_comm, False
                 res["native_comm_ms"] = ab
                 res["rr_after_native_comm"] = cg.rr()
-                comm.close()
             elapsed = max_over_ranks(elapsed)
             res["elapsed"] = elapsed
             res["k1_ms"] = stats.kernel_ms[0] / max(1, stats.kernel_launches[0])
@@ -330,7 +357,7 @@ def run_config5(R, steps, warmup, native):
     """BASELINE configs[4]: 256 x 64 x 64 elasticity (E = 210 GPa, nu = 0.3, gravity), the PCG iteration of _solve_elasticity_3d_static
     (fenics_mcp_server.py:1808-1838) through SlabCG on z-slabs (65 planes over the ranks): us per iteration and DoF/s, with both transports at N > 1"""
     torch, dist, L = R.torch, R.dist, R.L
-    from pdegpu.dist import GpuElasticitySlabEngine, NativeComm, SlabCG, slab_range
+    from pdegpu.dist import GpuElasticitySlabEngine, SlabCG, slab_range
     world, rank = R.world, R.rank
     n = (256, 64, 64)
     grid = L.make_grid(3, n, (1.0, 0.25, 0.25))
@@ -368,7 +395,7 @@ def run_config5(R, steps, warmup, native):
             if ref is not None:
                 out["single_gpu_check"] = {"what": "r.r after 60 PCG iterations: the slabs against one GPU alone (rank 0)", "rr_slabs": rr_n, "rr_single_gpu": ref,
                                            "rel_diff": abs(rr_n - ref) / ref if ref > 0 else None}
-        comm = NativeComm(eng, rank, world) if native else None
+        comm = R.native_comm() if native else None
         legs = [("torch_distributed" if world > 1 else "stepwise_driver", None)] + ([("library_rccl", comm)] if comm is not None else [])
         us = {}
         for label, c in legs + legs:
@@ -384,8 +411,6 @@ def run_config5(R, steps, warmup, native):
         best = min(min(v) for v in us.values())
         out["value"], out["unit"] = dof * 1e6 / best, "DoF/s (best leg)"
         out["rr_after"] = cg.rr()
-        if comm is not None:
-            comm.close()
         eng.close()
     return out
 
@@ -405,7 +430,29 @@ def roofline_of(res, general):
             "cg_iteration_alg_bytes_per_dof": res["k1_per_dof"] + 24}
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """stdout carries ONE JSON line (the driver parses it): everything else that writes to fd 1 while the run lasts — RCCL's version banner at the first
+    communicator of a process group — goes to stderr; emit() writes the line to the real stdout"""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: str):
+    sys.stdout.flush()
+    data = (line + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
+    quiet_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -421,6 +468,8 @@ def main():
     ap.add_argument("--cg-variant", choices=("sr", "classic"), default="sr", help="sr: single-reduction recurrences, ONE 24-byte scalar all-reduce per "
                     "iteration (default); classic: 8 bytes after K1 and 8 bytes after K2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transport", choices=("torch", "library"), default="torch", help="who issues the halo exchange and the scalar all-reduce of the MAIN line at N > 1: "
+                    "torch.distributed (default) or libpdegpu's own RCCL communicator (csrc/comm.hip, a chunk of iterations = one C call)")
     ap.add_argument("--no-native-comm", action="store_true", help="skip the library-issued RCCL legs of the extras (csrc/comm.hip against torch.distributed)")
     ap.add_argument("--no-tool-extras", action="store_true", help="skip the end-to-end tool-wall legs (config 3 / config 4 steady solves through the tool API)")
     ap.add_argument("--general", action="store_true", help="force the class-table kernels (diagnostic)")
@@ -429,6 +478,7 @@ def main():
     R = Runner(args)
     world, rank, n = R.world, R.rank, args.cells
     case = make_case(args.workload, args.scaling, n, world)
+    case["transport"] = args.transport
     res = R.run_case(case, args.steps, args.warmup, extras_n1=(world == 1))
     ms_per_step = res["elapsed"] / args.steps * 1e3
     rehearsal = "" if R.backend == "nccl" else f" (REHEARSAL over {R.backend}, shared GPU: not a measurement)"
@@ -439,6 +489,8 @@ def main():
         "config": {"workload": case["label"], "global_cells": res["cells"], "unknowns": res["unknowns"], "element_mode": "p1split",
                    "parallelism": (f"z-slabs x{world}" + rehearsal) if world > 1 else "single GPU",
                    "driver": "pdegpu.dist.SlabCG over the stepwise C-ABI session (the same loop at every N)" +
+                             ("; exchange and all-reduce issued by libpdegpu's own RCCL communicator" if (args.transport == "library" and world > 1) else
+                              ("; exchange and all-reduce through torch.distributed" if world > 1 else "")) +
                              ("; K1 split: bulk overlaps the halo exchange" if res["split_k1"] else "") +
                              ("; single-reduction CG: one 24-byte scalar all-reduce per iteration" if res["cg_variant"] == "sr" else
                               "; classic CG: two 8-byte scalar all-reduces per iteration"),
@@ -482,8 +534,9 @@ def main():
     # ---- the other workloads, same process group, after the main measurement ----------------------------------------
     if not args.no_extras:
         out["extras"] = run_extras_guarded(R, args, case, out, ms_per_step)
+    R.close_comm()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if world > 1:
         R.dist.destroy_process_group()
 
@@ -495,26 +548,42 @@ NATIVE_COMM_NOTE = ("the same session, alternating: halo exchange + scalar all-r
 
 
 def run_extras_guarded(R, args, case, out, ms_per_step):
-    """The other workloads (strong / weak / config 4, and at N = 1 the cost of the collective calls), measured after the main one in the
-    same process group.  An extra that hangs (a collective that never completes, a stuck GPU) must neither hold the main line back
-    for ever nor look like a success: after --extras-timeout seconds EVERY rank leaves with exit code 3 and rank 0 first prints the
-    main line — from a snapshot taken before the extras started, so the timer thread never serialises a dict the main thread is
-    mutating — with extras = {"aborted": ...}.  The cause is then to be found in the run's logs."""
+    """The other workloads (strong / weak / config 4, config 5, and at N = 1 the cost of the collective calls), measured after the main one in
+    the same process group.  An extra that hangs (a collective that never completes, a stuck GPU) must neither hold the main line back for ever
+    nor look like a success: after --extras-timeout seconds EVERY rank leaves and rank 0 first prints the main line with every extra that HAD
+    completed — from a snapshot refreshed under a lock after each one, so the timer thread never serialises a dict the main thread is mutating.
+    Order at N > 1: everything that communicates through torch.distributed (the transport `value` was just measured with) first; the legs
+    that go through the library's own RCCL communicator — one ncclCommInitRank per run, never yet run on more than one GPU — last.  A hang in
+    the first phase ends the run with exit code 3; a hang in the library-communicator legs ends it with exit code 0 and
+    extras.library_rccl = {"aborted": ...}: the scaling numbers of the run are complete and stay usable."""
+    lock = threading.Lock()
     snapshot = copy.deepcopy(out)
+    snapshot["extras"] = {}
+    phase = {"name": "torch.distributed extras", "rc": EXTRAS_ABORT_RC}
 
     def bail():
-        snapshot["extras"] = {"aborted": f"extras did not finish within {args.extras_timeout:.0f} s; the process group was abandoned "
-                                         f"and every rank exited with code {EXTRAS_ABORT_RC}"}
-        log(f"[bench] rank {R.rank}: extras watchdog fired after {args.extras_timeout:.0f} s")
-        if R.rank == 0:
-            print(json.dumps(snapshot), flush=True)
-        os._exit(EXTRAS_ABORT_RC)
+        with lock:
+            note = (f"{phase['name']} did not finish within {args.extras_timeout:.0f} s of the extras' start; the process group was abandoned and every "
+                    f"rank exited with code {phase['rc']}")
+            if phase["rc"] == 0:
+                snapshot["extras"].setdefault("library_rccl", {})["aborted"] = note
+            else:
+                snapshot["extras"]["aborted"] = note
+            log(f"[bench] rank {R.rank}: extras watchdog fired after {args.extras_timeout:.0f} s in phase '{phase['name']}'")
+            if R.rank == 0:
+                emit(json.dumps(snapshot))
+            os._exit(phase["rc"])
+
+    def done(extras):
+        with lock:
+            snapshot["extras"] = copy.deepcopy(extras)
 
     wd = threading.Timer(args.extras_timeout, bail)
     wd.daemon = True
     wd.start()
     world, n = R.world, args.cells
     extras = {}
+    library_legs = world > 1 and R.backend == "nccl" and not args.no_native_comm
     todo = [("config3", "strong"), ("config3", "weak"), ("config4", "strong")]
     for wl, sc in todo:
         c2 = make_case(wl, sc, n, world)
@@ -523,14 +592,9 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
         if world == 1 and wl == "config3":
             continue                                    # weak == strong == the main line on one GPU
         try:
-            if world > 1 and R.backend == "nccl" and not args.no_native_comm:
-                c2["native_comm"] = True
             c2["overlap_ab"] = world > 1
             r2 = R.run_case(c2, max(20, args.steps // 2), max(5, args.warmup // 2))
             st2 = max(20, args.steps // 2)
-            if "native_comm_ms" in r2:
-                extras.setdefault("library_rccl", {"what": NATIVE_COMM_NOTE})[f"{wl}_{c2['scaling']}"] = {
-                    "ms_per_step": r2["native_comm_ms"], "rr_after": r2["rr_after_native_comm"]}
             extras[f"{wl}_{c2['scaling']}"] = {
                 "workload": c2["label"], "scaling": c2["scaling"], "global_cells": r2["cells"], "unknowns": r2["unknowns"], "steps": st2,
                 "value": r2["unknowns"] * st2 / r2["elapsed"], "unit": "DoF/s", "ms_per_step": r2["elapsed"] / st2 * 1e3,
@@ -548,17 +612,37 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
                         "rr_single_gpu": ref, "rel_diff": abs(r2["rr_after"] - ref) / ref if ref > 0 else None}
         except Exception as e:                          # an extra must never void the main number
             extras[f"{wl}_{sc}"] = {"failed": repr(e)}
+            done(extras)
             break
-    if world > 1 and R.backend == "nccl" and not args.no_native_comm and not any("failed" in v for v in extras.values() if isinstance(v, dict)):
-        try:                                            # the main workload once more, library-issued against torch-issued communication
-            c2 = dict(case)
-            c2["native_comm"] = True
-            st2 = max(20, args.steps // 2)
-            r2 = R.run_case(c2, st2, max(5, args.warmup // 2))
-            extras.setdefault("library_rccl", {"what": NATIVE_COMM_NOTE})["main_workload"] = {
-                "ms_per_step": r2["native_comm_ms"], "rr_after": r2["rr_after_native_comm"]}
+        done(extras)
+    if world > 1:
+        try:                                            # BASELINE configs[4] ("1 -> 8 MI355X"): the elasticity PCG on z-slabs, torch.distributed leg + parity
+            extras["config5_elasticity"] = run_config5(R, max(100, args.steps), max(20, args.warmup), False)
         except Exception as e:
-            extras.setdefault("library_rccl", {})["main_workload"] = {"failed": repr(e)}
+            extras["config5_elasticity"] = {"failed": repr(e)}
+        done(extras)
+    if library_legs and not any("failed" in v for v in extras.values() if isinstance(v, dict)):
+        # ---- last: the legs through the library's own communicator (see the docstring) ----
+        with lock:
+            phase["name"], phase["rc"] = "the library-RCCL legs (csrc/comm.hip)", 0
+        try:
+            lib_x = {"what": NATIVE_COMM_NOTE}
+            st2 = max(20, args.steps // 2)
+            for key, c2 in (("main_workload", dict(case)), ("config4_strong", make_case("config4", "strong", n, world))):
+                if key != "main_workload" and c2["workload"] == case["workload"] and c2["scaling"] == case["scaling"]:
+                    continue
+                c2["native_comm"] = True
+                c2["transport"] = "torch"
+                r2 = R.run_case(c2, st2, max(5, args.warmup // 2))
+                lib_x[key] = {"ms_per_step": r2["native_comm_ms"], "rr_after": r2["rr_after_native_comm"]}
+                extras["library_rccl"] = lib_x
+                done(extras)
+            c5 = run_config5(R, max(100, args.steps), max(20, args.warmup), True)
+            lib_x["config5_elasticity"] = {"us_per_iteration": c5["us_per_iteration"], "rr_after": c5["rr_after"]}
+            extras["library_rccl"] = lib_x
+        except Exception as e:
+            extras.setdefault("library_rccl", {})["failed"] = repr(e)
+        done(extras)
     if world == 1 and not extras.get("config4_strong", {}).get("failed"):
         # what the collective calls themselves cost (no wire): the same 512^3 loop with its scalar all-reduce(s) of every iteration going
         # through a ONE-rank RCCL process group — torch.distributed's stream hand-over + RCCL's launch path, on this GPU
@@ -586,11 +670,13 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             R.dist.destroy_process_group()
         except Exception as e:
             extras["collective_calls_one_rank"] = {"failed": repr(e)}
-    try:                                                # BASELINE configs[4] ("1 -> 8 MI355X"): the elasticity PCG on z-slabs
-        extras["config5_elasticity"] = run_config5(R, max(100, args.steps), max(20, args.warmup),
-                                                   world > 1 and R.backend == "nccl" and not args.no_native_comm)
-    except Exception as e:
-        extras["config5_elasticity"] = {"failed": repr(e)}
+        done(extras)
+    if world == 1:
+        try:                                            # BASELINE configs[4]: the elasticity PCG, one slab
+            extras["config5_elasticity"] = run_config5(R, max(100, args.steps), max(20, args.warmup), False)
+        except Exception as e:
+            extras["config5_elasticity"] = {"failed": repr(e)}
+        done(extras)
     if world == 1:
         # the system of a backward-Euler step (fenics_mcp_server.py:702-716): A = M + dt kappa K, 15-point on the Kuhn split — bare SpMV and the CG
         # iteration (K1 stores q there: 72 B/DoF; the second stencil pass of the 64-byte form costs more than it saves with 15 points)
@@ -610,6 +696,7 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
                               "frac": 16.0 * r5["unknowns"] / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS}, "rr_after": r5["rr_after"]}
         except Exception as e:
             extras["transient_step_system"] = {"failed": repr(e)}
+        done(extras)
     if world == 1 and not args.no_tool_extras:
         # end-to-end cost of the tool boundary at BASELINE's sizes: wall time of the reference-named solver (_solve_heat_3d_raw: kwargs in,
         # numpy field out) against the device time of its solve, then the pickle hand-off and the plot tool

@@ -13,12 +13,42 @@
 // it, runs ONE ncclGroup of sends and receives (the two xGMI links to the slab neighbours) and records `done`; the compute stream waits for `done`
 // only in front of the launches that read ghost planes — everything enqueued in between overlaps the transfer.  The scalar all-reduce runs in
 // place on the compute stream itself (nothing can overlap it: the next kernel needs its result).
+//
+// ONE ncclComm_t serves both: the grouped sends / receives go on the communicator's stream, the all-reduce on the compute stream.  RCCL serialises
+// the operations of one communicator in the order they are ISSUED, whatever their streams, so this is correct exactly because every rank issues the
+// same sequence (exchange group, all-reduce, exchange group, ... — pdegpu_session_iterate_slab and SlabCG.iterate are that sequence, and a rank never
+// takes a data-dependent branch between two communications).  The first run on more than one GPU checks it with bench.py's single-GPU parity
+// figures (`single_gpu_check`); until then it is rehearsed with one rank and the self-loop only.
+//
+// stdout is the reference server's JSON-RPC channel (fenics_mcp_server.py:41-52, 223-225): RCCL prints a version banner there when a communicator
+// is initialised, so fd 1 points at stderr for the duration of ncclCommInitRank.
 #include "common.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
+#include <cstdio>
 #include <cstring>
 
 namespace {
+// fd 1 -> fd 2 while alive (process-wide: communicators are created collectively at start-up, not concurrently with a writer of stdout)
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0 && dup2(2, 1) < 0) {
+            close(saved);
+            saved = -1;
+        }
+    }
+    ~StdoutToStderr() {
+        if (saved < 0) return;
+        fflush(stdout);                      // what the library printed sits in stdio's buffer: it must leave while fd 1 still is stderr
+        (void)dup2(saved, 1);
+        close(saved);
+    }
+};
+
 struct RcclApi {
     void* handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -114,7 +144,11 @@ extern "C" int pdegpu_comm_create(pdegpu_ctx* ctx, int rank, int world, const vo
     c->world = world;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
-    const ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
+    ncclResult_t r;
+    {
+        StdoutToStderr quiet;
+        r = api->CommInitRank(&c->comm, world, id, rank);
+    }
     if (r != ncclSuccess) {
         const int rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, api->GetErrorString ? api->GetErrorString(r) : "?");
         delete c;

@@ -264,15 +264,45 @@ def element_mode_from_env() -> int:
 # ---- output-volume policy ------------------------------------------------------------------------------------------------
 # The reference stores EVERY step (fenics_mcp_server.py:300-315, 694-696, 711-713); at the grid sizes this build solves that is
 # hundreds of GB (config 3 at the dispatcher's defaults: 201 states x 1.08 GB = 217 GB).  Policy: the host array may take at most
-# PDEGPU_MAX_OUTPUT_GB, default 32 GB — a FIXED number, so that the same call returns arrays of the same shape on every machine.  A
+# PDEGPU_MAX_OUTPUT_GB, default 32 GB — a FIXED number, so that the same call returns arrays of the same shape on every machine that can hold
+# them (a host or container with less than twice that still available gets half of what it has: meta says which bound decided).  A
 # request beyond it is strided to the smallest stride that fits (first and last state always kept) and the stride actually used is
 # recorded in meta; with PDEGPU_OUTPUT_POLICY=error it raises instead, naming snapshot_stride.
 DEFAULT_OUTPUT_BUDGET_GB = 32.0
 
 
-def output_budget_bytes() -> int:
+def _memory_available_bytes():
+    """what this process may still allocate on the host: MemAvailable, cut by the cgroup's limit minus its usage where one is set; None if unknown"""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+                break
+    except OSError:
+        pass
+    for lim_f, use_f in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            lim = open(lim_f).read().strip()
+            if lim != "max" and int(lim) < (1 << 60):
+                room = int(lim) - int(open(use_f).read().strip())
+                avail = room if avail is None else min(avail, room)
+            break
+        except (OSError, ValueError):
+            continue
+    return avail
+
+
+def output_budget_bytes(explain: bool = False):
+    """the fixed default (or PDEGPU_MAX_OUTPUT_GB), never more than half of what the host can still give — on a small host or container the fixed
+    32 GB would be allocated (and pickled) where the request should be strided; explain=True also returns what decided"""
     v = os.environ.get("PDEGPU_MAX_OUTPUT_GB")
-    return int(float(v if v else DEFAULT_OUTPUT_BUDGET_GB) * 1e9)
+    budget, why = int(float(v if v else DEFAULT_OUTPUT_BUDGET_GB) * 1e9), ("PDEGPU_MAX_OUTPUT_GB" if v else "default")
+    avail = _memory_available_bytes()
+    if avail is not None and avail // 2 < budget:
+        budget, why = max(avail // 2, 0), "half of the host memory still available"
+    return (budget, why) if explain else budget
 
 
 def count_snapshots(num_steps: int, stride: int) -> int:
@@ -286,12 +316,12 @@ def snapshot_policy(num_steps: int, n_nodes: int, requested_stride: int, steady:
     req = max(1, int(requested_stride))
     if steady:
         return req, {"snapshot_stride": req}
-    budget = output_budget_bytes()
+    budget, why = output_budget_bytes(explain=True)
     need = count_snapshots(num_steps, req) * n_nodes * 8
     if need <= budget:
         return req, {"snapshot_stride": req}
     msg = (f"{count_snapshots(num_steps, req)} stored states x {n_nodes} nodes x 8 B = {need / 1e9:.1f} GB exceed the output budget "
-           f"of {budget / 1e9:.1f} GB (PDEGPU_MAX_OUTPUT_GB)")
+           f"of {budget / 1e9:.1f} GB ({why}; PDEGPU_MAX_OUTPUT_GB)")
     if os.environ.get("PDEGPU_OUTPUT_POLICY", "auto").lower() == "error":
         raise PdeGpuError(EINVAL, msg + "; pass snapshot_stride=k (or PDEGPU_SNAPSHOT_STRIDE) to keep every k-th state")
     if 2 * n_nodes * 8 > budget:

@@ -66,14 +66,14 @@ class NativeComm:
         self.lib = L.load_library()
         self.rank, self.world, self.ctx = rank, world, engine.ctx
         ident = (C.c_ubyte * 128)()
-        if rank == 0:
-            rc = self.lib.pdegpu_comm_unique_id(ident)
-            if rc != 0:
-                raise L.PdeGpuError(rc, "pdegpu_comm_unique_id failed: librccl.so.1 cannot be loaded or refused to make an id")
+        rc = self.lib.pdegpu_comm_unique_id(ident) if rank == 0 else 0
         if world > 1:
-            box = [bytes(ident)]
+            # (status, id) travel together: a rank 0 that cannot make an id must not leave the others waiting in the broadcast
+            box = [(int(rc), bytes(ident))]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            rc, ident = box[0][0], (C.c_ubyte * 128).from_buffer_copy(box[0][1])
+        if rc != 0:
+            raise L.PdeGpuError(rc, "pdegpu_comm_unique_id failed on rank 0: librccl.so.1 cannot be loaded or refused to make an id")
         self.h = C.c_void_p()
         L.check(self.ctx, self.lib.pdegpu_comm_create(self.ctx, rank, world, ident, C.byref(self.h)))
 
@@ -707,28 +707,31 @@ def solve_elasticity_slabs(grid, el, n_cells, rtol: float = 1e-8, max_iter: int 
     stream = torch.cuda.Stream(device=local)
     with torch.cuda.stream(stream):
         eng = GpuElasticitySlabEngine(grid, el, k0, nk, local, stream)
-        comm = NativeComm(eng, rank, world, group) if transport == "library" else None
-        cg = SlabCG(eng, rank, world, group, comm=comm)
-        cg.start(0.0)
-        rr0 = eng.rr()
-        it, chunk = 0, 16
-        rr = rr0
-        while rr > rtol * rtol * rr0 and it < max_iter:
-            cg.iterate(chunk)
-            it += chunk
-            rr = eng.rr()                       # the only host synchronisation: once per chunk
-            chunk = min(2 * chunk, 256)
-        cg.finish()
-        u_local = eng.get_u((nx + 1) * (ny + 1)).reshape(nk, (nx + 1) * (ny + 1), 3)
-        u_all = gather_slabs(u_local, nz + 1, rank, world, group, local)
-        out = {"iterations": it, "rel_residual": (rr / rr0) ** 0.5 if rr0 > 0 else 0.0}
-        if rank == 0:
-            u = np.ascontiguousarray(u_all.reshape(-1, 3))
-            field = np.empty(u.shape[0])
-            ctx = eng.ctx
-            L.check(ctx, eng.lib.pdegpu_elasticity_postprocess(ctx, grid, el, L.dptr(u), L.dptr(field)))
-            out.update(displacement=u, field=field)
-        if comm is not None:
-            comm.close()
-        eng.close()
+        comm = None
+        try:
+            comm = NativeComm(eng, rank, world, group) if transport == "library" else None
+            cg = SlabCG(eng, rank, world, group, comm=comm)
+            cg.start(0.0)
+            rr0 = eng.rr()
+            it, chunk = 0, 16
+            rr = rr0
+            while rr > rtol * rtol * rr0 and it < max_iter:
+                cg.iterate(chunk)
+                it += chunk
+                rr = eng.rr()                       # the only host synchronisation: once per chunk
+                chunk = min(2 * chunk, 256)
+            cg.finish()
+            u_local = eng.get_u((nx + 1) * (ny + 1)).reshape(nk, (nx + 1) * (ny + 1), 3)
+            u_all = gather_slabs(u_local, nz + 1, rank, world, group, local)
+            out = {"iterations": it, "rel_residual": (rr / rr0) ** 0.5 if rr0 > 0 else 0.0}
+            if rank == 0:
+                u = np.ascontiguousarray(u_all.reshape(-1, 3))
+                field = np.empty(u.shape[0])
+                ctx = eng.ctx
+                L.check(ctx, eng.lib.pdegpu_elasticity_postprocess(ctx, grid, el, L.dptr(u), L.dptr(field)))
+                out.update(displacement=u, field=field)
+        finally:                                    # the communicator goes before the context it was made on, whatever happened
+            if comm is not None:
+                comm.close()
+            eng.close()
     return out

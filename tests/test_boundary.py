@@ -175,3 +175,45 @@ def test_solve_params_dict_end_to_end(case, tmp_path, gpu_ctx):
     assert np.abs(field.values - ref.values).max() <= 1e-8 * max(np.abs(ref.values).max(), 1e-300)
     assert set(ref.meta) <= set(field.meta)
     assert out["solver_result"].dim == p["dim"] and out["solver_result"].meta == field.meta
+
+
+@pytest.mark.gpu
+def test_tool_calls_write_nothing_to_stdout(lib, gpu_ctx, tmp_path):
+    """stdout is the reference server's JSON-RPC channel (fenics_mcp_server.py:41-52; every raw solver redirects it, :223-225, 364-366, 508-510; SURVEY §5:
+    "the build's server must never write to stdout").  One call of every tool family — 1-D direct, 2-D persistent launch, 3-D marching / hybrid / weighted
+    marching / class-table, elasticity 1-D / 2-D / 3-D, the plot tool — and the creation of the library's RCCL communicator (RCCL prints a version banner
+    when a communicator is initialised: csrc/comm.hip points fd 1 at stderr for that call), in a child process whose fd 1 is a file: it must stay empty."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    script = f'''
+import sys
+sys.path[:0] = [{str(root)!r}, {str(root / "pde-solver_amd")!r}]
+from pdegpu import server as S, _lib as L, dist as D
+d = {str(tmp_path)!r}
+outs = [S.solve_heat_1D(nx=40, num_steps=3, data_dir=d), S.solve_heat_2D(nx=20, ny=20, num_steps=2, data_dir=d),
+        S.solve_heat_3D(nx=8, ny=8, nz=8, num_steps=2, data_dir=d), S.solve_heat_3D(nx=8, ny=8, nz=8, num_steps=2, T_left=50.0, data_dir=d),
+        S.solve_heat_3D(nx=8, ny=8, nz=8, num_steps=2, core_radius=0.4, core_diffusivity=5.0, data_dir=d),
+        S.solve_heat_3D(nx=8, ny=8, nz=8, num_steps=2, geometry_type="cylinder", cylinder_radius=0.5, data_dir=d),
+        S.solve_heat_3D_spherical(nr=8, ntheta=8, nphi=8, num_steps=2, data_dir=d), S.solve_heat_2D_spherical(nr=8, ntheta=8, num_steps=2, data_dir=d),
+        S.solve_heat_2D_cylindrical(nr=8, nz=8, num_steps=2, data_dir=d), S.solve_heat_1D_cylindrical(nr=10, num_steps=2, data_dir=d),
+        S.solve_heat_1D_spherical(nr=10, num_steps=2, data_dir=d), S.solve_elasticity_1D_static(nx=10, body_force=1.0, data_dir=d),
+        S.solve_elasticity_2D_static(nx=8, ny=8, body_fy=-1e4, data_dir=d), S.solve_elasticity_3D_static(nx=8, ny=4, nz=4, body_fz=-7e4, data_dir=d)]
+S.plot_time_series_field_from_file(outs[2].data_file, output_dir=d)
+S.solve({{"pde_type": "heat", "dim": 3, "nx": 6, "ny": 6, "nz": 6, "num_steps": 2}}, data_dir=d)
+
+
+class H:
+    ctx = L.context(0)
+
+
+c = D.NativeComm(H, 0, 1)          # ncclCommInitRank of a one-rank communicator: the banner, if this RCCL prints one, must go to stderr
+c.close()
+sys.stderr.write("CHILD DONE %d\\n" % len(outs))
+'''
+    out_file = tmp_path / "fd1.txt"
+    with open(out_file, "wb") as fh:
+        p = subprocess.run([sys.executable, "-c", script], stdout=fh, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    assert b"CHILD DONE 14" in p.stderr
+    assert out_file.read_bytes() == b"", out_file.read_bytes()[:500]

@@ -106,6 +106,18 @@ def test_slab_cg_world_1_2_3_agree_and_match_oracle(tmp_path, variant):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("variant", ["sr", "classic"])
+def test_slab_cg_at_the_world_size_of_the_scaling_run(tmp_path, variant):
+    """world size 8 — what the driver's scaling bench launches: 12 node planes over 8 ranks, i.e. slabs of two planes and of ONE plane (its only plane
+    is next to both ghosts and is first and last owned plane at once), the first and the last slab holding a Dirichlet plane; partition, ownership of
+    the dot products and the thin-slab paths of SlabCG must reproduce the one-slab iterates"""
+    x1, rr1 = _run(1, tmp_path, variant)
+    x8, rr8 = _run(8, tmp_path, variant)
+    assert np.allclose(rr8[:2], rr1[:2], rtol=1e-11)
+    assert np.abs(x8 - x1).max() < 1e-11 * np.abs(x1).max()
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_transient_heat_over_slabs_matches_oracle(tmp_path, world):
     """the distributed time loop (x-halo exchange per step, step right-hand side, reference norm, CG, gather to rank 0, axes

@@ -57,6 +57,30 @@ def test_bench_line_of_the_multi_rank_path(lib, gpu_ctx):
     assert chk5["rr_single_gpu"] > 0 and chk5["rel_diff"] < 1e-8, chk5
 
 
+def test_bench_line_at_four_ranks_on_one_gpu(lib, gpu_ctx):
+    """the widest rehearsal this pool allows on a card (its process guard admits six GPU processes: this test's own context, the launcher and 4 ranks;
+    world size 8 itself runs on the CPU, tests/test_dist_gloo.py::test_slab_cg_at_the_world_size_of_the_scaling_run): bench.py under the driver's
+    launcher, 49 node planes over 4 ranks (slabs of 13 and 12 planes, config 5's 65 planes as 17 + 3 x 16), JSON contract and the three single-GPU
+    parity figures"""
+    import json
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PDEGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "2", "--cells", "48", "--extras-timeout", "500"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["config"]["unknowns"] == 47 * 47 * (4 * 48 - 1) and d["value"] > 0
+    assert "aborted" not in d["extras"], d["extras"]
+    for key, bound in (("config3_strong", 1e-9), ("config4_strong", 1e-9), ("config5_elasticity", 1e-8)):
+        chk = d["extras"][key]["single_gpu_check"]
+        assert chk["rr_single_gpu"] > 0 and chk["rel_diff"] < bound, (key, chk)
+
+
 def test_multi_process_elasticity_slabs(lib, gpu_ctx):
     """solve_elasticity_slabs with 2 ranks sharing the GPU (gloo rehearsal): von Mises field == the single-process solve; k1 split
     around the exchange (forced on these 5-plane slabs: the default splits slabs of >= 32 MiB per vector)"""

@@ -279,6 +279,7 @@ def test_weighted_rows_with_composite_core_match_oracle(lib):
 def test_snapshot_policy_keeps_a_request_that_fits(monkeypatch):
     from pdegpu import _lib as L
     monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "1")
+    assert L._memory_available_bytes() is None or L._memory_available_bytes() > 0          # the real probe (MemAvailable / cgroup) on this host
     assert L.snapshot_policy(200, 1001, 1, False) == (1, {"snapshot_stride": 1})
     assert L.snapshot_policy(200, 10 ** 9, 7, True) == (7, {"snapshot_stride": 7})          # steady: one state
 
@@ -286,6 +287,7 @@ def test_snapshot_policy_keeps_a_request_that_fits(monkeypatch):
 def test_snapshot_policy_auto_strides_config3_defaults(monkeypatch):
     """config 3 at the dispatcher's defaults: 201 states x 513^3 nodes = 217 GB -> strided to fit, recorded for meta"""
     from pdegpu import _lib as L
+    monkeypatch.setattr(L, "_memory_available_bytes", lambda: None)        # (a host that can hold the budget: the fixed number decides)
     monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "64")
     monkeypatch.delenv("PDEGPU_OUTPUT_POLICY", raising=False)
     N = 513 ** 3
@@ -304,8 +306,23 @@ def test_snapshot_policy_auto_strides_config3_defaults(monkeypatch):
     assert L.count_snapshots(10 ** 6, big) * 8e6 <= 32e9 < L.count_snapshots(10 ** 6, big - 1) * 8e6
 
 
+def test_output_budget_is_capped_by_what_the_host_can_still_give(monkeypatch):
+    """a container with 10 GB to spare must stride where the fixed 32 GB would be allocated and pickled; meta says which bound decided"""
+    from pdegpu import _lib as L
+    monkeypatch.delenv("PDEGPU_MAX_OUTPUT_GB", raising=False)
+    monkeypatch.delenv("PDEGPU_OUTPUT_POLICY", raising=False)
+    monkeypatch.setattr(L, "_memory_available_bytes", lambda: 10_000_000_000)
+    assert L.output_budget_bytes(explain=True) == (5_000_000_000, "half of the host memory still available")
+    N = 257 ** 3
+    stride, meta = L.snapshot_policy(200, N, 1, False)
+    assert L.count_snapshots(200, stride) * N * 8 <= 5e9 < L.count_snapshots(200, stride - 1) * N * 8 and "host memory" in meta["snapshot_policy"]
+    monkeypatch.setattr(L, "_memory_available_bytes", lambda: 10 ** 12)
+    assert L.output_budget_bytes(explain=True) == (32_000_000_000, "default")
+
+
 def test_snapshot_policy_error_mode_and_hopeless_requests(monkeypatch):
     from pdegpu import _lib as L
+    monkeypatch.setattr(L, "_memory_available_bytes", lambda: None)
     monkeypatch.setenv("PDEGPU_MAX_OUTPUT_GB", "8")
     monkeypatch.setenv("PDEGPU_OUTPUT_POLICY", "error")
     with pytest.raises(L.PdeGpuError, match="snapshot_stride"):
