@@ -280,20 +280,9 @@ int     pdegpu_el_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const
                                  pdegpu_el_session** out);
 void    pdegpu_el_session_destroy(pdegpu_el_session* s);
 int     pdegpu_el_session_begin(pdegpu_el_session* s);      /* b = body m; x = 0; r = P b; z; local r.z, r.r */
-int     pdegpu_el_session_k1(pdegpu_el_session* s);         /* x += a p; p = D^-1 r + beta p; q = A p; local p.q */
-int     pdegpu_el_session_k2(pdegpu_el_session* s);         /* r -= a q; local r.z (z = D^-1 r), r.r */
 int     pdegpu_el_session_flush(pdegpu_el_session* s);      /* pending x += a p */
-double* pdegpu_el_session_scalars(pdegpu_el_session* s);    /* device {p.q, r.z, r.r, r.z_prev, ...} */
 int     pdegpu_el_session_scalars_host(pdegpu_el_session* s, double* out4);   /* synchronises */
-int64_t pdegpu_el_session_plane_doubles(const pdegpu_el_session* s);
-void*   pdegpu_el_session_plane_ptr(pdegpu_el_session* s, int vec, int comp, int64_t which);
 int     pdegpu_el_session_get_u(pdegpu_el_session* s, double* u_out /* host [nk * plane nodes][3] */);
-/* k1 in two steps so that the halo exchange overlaps the part of it that reads no ghost plane (same protocol as pdegpu_session_k1_part):
- * part 0 = p-update of the owned planes + the marching apply on the planes away from the ghosts (call it right after posting the exchange),
- * part 1 = p-update of the ghost planes + the apply on the one or two edge planes (one launch) + the p.q sum.  can_split_k1 = 1 for 3-D
- * marching sessions on slabs with a neighbour whose vectors hold at least el_split_min_mb (32) MiB; other sessions do nothing in part 0 and the whole k1 in part 1. */
-int     pdegpu_el_session_can_split_k1(const pdegpu_el_session* s);
-int     pdegpu_el_session_k1_part(pdegpu_el_session* s, int part);
 /* The PCG recurrences of a session (default: the context's el_cg_variant tunable).  0 = classic: the host all-reduces scalars[0] (p.Ap) after k1 and
  * scalars[1..2] (r.z, r.r) after k2.  1 = single-reduction form: the residual update r -= a q moves INTO k1, fused with the p-update (7 vector
  * passes instead of 8, one launch less); k2 and flush do nothing; after k1 / k1_part(1) the block scalars[0..3] = {p.Ap, r.z, r.r, Ap.D^-1 Ap} is
@@ -303,12 +292,13 @@ int     pdegpu_el_session_k1_part(pdegpu_el_session* s, int part);
  * classic form, so a driver may always call it.  x always matches the residual scalars[2] reports.  Choose before begin(). */
 int     pdegpu_el_session_set_cg_variant(pdegpu_el_session* s, int variant);
 int     pdegpu_el_session_cg_variant(const pdegpu_el_session* s);
-int     pdegpu_el_session_k1_pre(pdegpu_el_session* s);
 /* von Mises + project() (:1840-1866) on one GPU from a displacement field gathered on the host, disp [N][dim] */
 int     pdegpu_elasticity_postprocess(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el, const double* disp,
                                       double* field_out);
 
-/* ---- slab-resident CG session: the unit the benchmark and the multi-GPU driver step -------------
+/* ---- slab-resident CG session: the unit the benchmark and the multi-GPU driver run --------------
+ * (whole solves and chunks of iterations here; the single steps of an iteration — k1 / k2 and their parts, plane pointers, the exchange
+ *  building blocks — are the driver / rehearsal API of pdegpu_stepwise.h)
  * A session owns the device vectors of ONE slab of a 3-D (or 2-D) heat system
  *      A = cM*M + cK*K  with the Dirichlet set of `heat`,
  * for global node planes [k0, k0+nk) of the slowest axis (z in 3-D, y in 2-D), plus one ghost plane on
@@ -323,36 +313,7 @@ void pdegpu_session_destroy(pdegpu_session* s);
 /* set x to the Dirichlet values on constrained nodes and `fill` elsewhere; b = M*(fill_rhs) i.e. the
  * right-hand side of a constant load (steady: b = source*m) is prepared by session_begin. */
 int  pdegpu_session_begin(pdegpu_session* s, double x_fill);
-/* device pointers / geometry the host needs for halo exchange: plane `which` of vector `vec`
- * (0:x 1:r 2:p(current) 3:q), which = -1 lower ghost, 0 first owned, nk-1 last owned, nk upper ghost.
- * plane_doubles = number of fp64 in one contiguous plane. */
-void*   pdegpu_session_plane_ptr(pdegpu_session* s, int vec, int64_t which);
-int64_t pdegpu_session_plane_doubles(const pdegpu_session* s);
-/* 1 if the ghost planes of p must be exchanged together with r before every k1 (class-table kernels and the 72-B
- * variant); 0 when k1 maintains p on the ghost planes itself (fused z-marching kernels, cg_variant 1): then only
- * r is exchanged. */
-int     pdegpu_session_needs_p_halo(const pdegpu_session* s);
-/* pointer to the device scalars {pq_local, rr_local, pq_global, rr_global, rr_global_prev, ...}.  residual / k1 /
- * k2 leave this slab's dot product in BOTH the *_local and the *_global slot; the multi-GPU host all-reduces
- * the *_global slot in place (8 bytes, stays on the device); single GPU: nothing to do. */
-double* pdegpu_session_scalars(pdegpu_session* s);
 int  pdegpu_session_residual(pdegpu_session* s);            /* r = P(b - A x), rr_local */
-int  pdegpu_session_k1(pdegpu_session* s);                  /* x+=a*p; p=r+beta*p; q=A p; pq_local */
-int  pdegpu_session_k2(pdegpu_session* s);                  /* r-=alpha*q; rr_local */
-/* k1 in two steps, so that the halo exchange overlaps the bulk of it: part 0 = the owned planes whose stencil touches no ghost
- * plane (call it right after posting the exchange), part 1 = the one or two planes next to the ghosts (after the exchange has
- * completed) + the sum of all partials -> pq_local.  can_split_k1 = 1 for the fused z-marching kernels; other sessions do
- * nothing in part 0 and the whole k1 in part 1, so a driver may always call part 0 then part 1. */
-int  pdegpu_session_can_split_k1(const pdegpu_session* s);
-int  pdegpu_session_k1_part(pdegpu_session* s, int part);
-/* K2 in two steps, so that the NEXT iteration's exchange is posted as soon as its planes are final: part 0 = the one or two planes next to the
- * ghosts (one launch) — after it the first / last owned plane of r belong to the new residual: post the exchange —, part 1 = the planes in between
- * + k2's reduce (classic form).  The transfer then hides behind K2's bulk and the next K1's bulk (pdegpu_session_iterate_slab and pdegpu.dist.SlabCG do
- * this inside a chunk of iterations).  can_split_k2 = 1 for marching sessions whose K2 is the stencil form, on a slab with a neighbour, thin enough for the
- * exchange to need more than K1's bulk to hide behind (K1 bulk estimate < 4 plane transfers: ranks of 4 and 8 on 512^3; the split costs a launch); other
- * sessions run all of K2 in part 0 and nothing in part 1, so a driver may always call 0, post, 1. */
-int  pdegpu_session_can_split_k2(const pdegpu_session* s);
-int  pdegpu_session_k2_part(pdegpu_session* s, int part);
 /* The CG recurrences of the stepwise protocol.  variant 0 (default): classic CG — the host all-reduces pq_global after k1 and rr_global after
  * k2 (two 8-byte messages per iteration).  variant 1: single-reduction form (one message per iteration): k1 additionally sums
  * Ap.Ap, k2 leaves its r.r in per-workgroup partials, and k1 / k1_part(1) end with ONE reduce launch that fills scalars[2..4] =
@@ -363,7 +324,6 @@ int  pdegpu_session_k2_part(pdegpu_session* s, int part);
  * variant before begin() / residual(); pdegpu_session_iterate (the native single-slab loop) runs the classic form only. */
 int  pdegpu_session_set_cg_variant(pdegpu_session* s, int variant);
 int  pdegpu_session_cg_variant(const pdegpu_session* s);
-int  pdegpu_session_sr_poll(pdegpu_session* s);
 /* kernel timing of the stepwise protocol: set_timing(s, 1) starts a fresh measurement (hipEvent pairs around every k1 / k1_part
  * / k2 launch on the context stream), get_stats synchronises and ADDS kernel_ms[0] (k1), kernel_ms[1] (k2), launch counts and
  * algorithmic bytes since then to *stats.  set_timing(s, k), k > 1: only every k-th iteration is bracketed (an event record costs
@@ -377,7 +337,6 @@ int  pdegpu_session_get_stats(pdegpu_session* s, pdegpu_stats* stats);
 int  pdegpu_session_step_rhs(pdegpu_session* s);
 int  pdegpu_session_lift_norm(pdegpu_session* s);
 int  pdegpu_session_reset_cg(pdegpu_session* s);
-int  pdegpu_session_reduce_local(pdegpu_session* s, int which /*0 pq, 1 rr*/, int copy_to_global);
 int  pdegpu_session_flush(pdegpu_session* s);               /* pending x += alpha*p */
 /* run `iters` full CG iterations on a single slab without the host in the loop (k1,k2 back to back).
  * If time_kernels != 0, brackets every launch with hipEvents and accumulates stats->kernel_ms. */
@@ -390,10 +349,6 @@ int  pdegpu_session_time_apply(pdegpu_session* s, int reps, double* avg_ms_out);
 /* in-run memory calibration over the session's own vectors (padded slab, nk*PP doubles each):
  * which = 0 copy (1R+1W), 1 read-only (1R), 2 write-only (1W), 3 triad (2R+1W), 4 in-place update (2R+1W). */
 int  pdegpu_session_membench(pdegpu_session* s, int which, int reps, double* avg_ms_out);
-/* Diagnostic: average milliseconds of `reps` launches of the fused CG kernel K1 with its four vectors (x, r, p_old, p_new) taken from the session's
- * six vectors {x, r, p0, p1, q, b} in the order roles4 gives (distinct indices 0..5).  K1's time depends on where its vectors sit in physical
- * memory (profiles/r02_k1_bimodal_between_processes.log); single-slab marching sessions only; the session must be begun again afterwards. */
-int         pdegpu_session_debug_time_k1(pdegpu_session* s, const int32_t* roles4, int reps, double* avg_ms_out);
 int  pdegpu_session_get_x(pdegpu_session* s, double* x_out /* host [nk][plane nodes] */);
 int  pdegpu_session_sync(pdegpu_session* s);
 
@@ -420,18 +375,11 @@ int  pdegpu_comm_create(pdegpu_ctx* ctx, int rank, int world, const void* id128,
 void pdegpu_comm_destroy(pdegpu_comm* c);
 int  pdegpu_comm_rank(const pdegpu_comm* c);
 int  pdegpu_comm_world(const pdegpu_comm* c);
-/* one-GPU rehearsal (tools/slab_surrogate.py): on != 0 makes both slab neighbours this rank itself — real messages of the real size, meaningless iterates */
-int  pdegpu_comm_set_self_loop(pdegpu_comm* c, int on);
-int  pdegpu_comm_group_begin(pdegpu_comm* c);               /* comm stream waits for the context stream; ncclGroupStart */
-int  pdegpu_comm_group_end(pdegpu_comm* c);                 /* ncclGroupEnd; marks the end of the exchange for exchange_end */
-int  pdegpu_session_exchange_post(pdegpu_session* s, pdegpu_comm* c, int what, int x_planes, int lo_rank, int hi_rank);
-int  pdegpu_session_exchange_begin(pdegpu_session* s, pdegpu_comm* c, int x_planes);
-int  pdegpu_session_exchange_end(pdegpu_session* s, pdegpu_comm* c);
-int  pdegpu_session_allreduce(pdegpu_session* s, pdegpu_comm* c, int first, int count);
 int  pdegpu_session_iterate_slab(pdegpu_session* s, pdegpu_comm* c, int iters);
-int  pdegpu_el_session_exchange_post(pdegpu_el_session* s, pdegpu_comm* c, int what, int lo_rank, int hi_rank);
-int  pdegpu_el_session_exchange_begin(pdegpu_el_session* s, pdegpu_comm* c);
-int  pdegpu_el_session_exchange_end(pdegpu_el_session* s, pdegpu_comm* c);
+/* convergence polls of a host that runs chunks of iterate_slab: sr_poll (single-reduction form) sums this slab's share of the r.r the last k2 left
+ * into scalars[6]; allreduce sums scalars[first .. first+count) over the ranks in place on the context stream; pdegpu_session_rr then reads it */
+int  pdegpu_session_sr_poll(pdegpu_session* s);
+int  pdegpu_session_allreduce(pdegpu_session* s, pdegpu_comm* c, int first, int count);
 int  pdegpu_el_session_allreduce(pdegpu_el_session* s, pdegpu_comm* c, int first, int count);
 int  pdegpu_el_session_iterate_slab(pdegpu_el_session* s, pdegpu_comm* c, int iters);
 

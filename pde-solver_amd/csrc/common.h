@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "../../include/pdegpu.h"
+#include "../../include/pdegpu_stepwise.h"
 
 // ------------------------------------------------------------------------------------------------
 // context
