@@ -1038,25 +1038,36 @@ __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __res
         lk += dk;
         if (i2 >= PX2) { i2 -= PX2; ++j; }
         if (j >= g.NY) { j -= g.NY; ++lk; }
+        // every load of the node pair (4 vectors x D components) is issued before the first store: in program order a load behind a store waits for it
+        // (stores count in the in-order vmcnt, and the vectors may alias as far as the compiler knows), which made the D components 2 D dependent round trips
+        const bool upd = !ghost && alpha != 0.0;              // kernel-uniform
+        double2 po[D], rv[D], qv[D], xv[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const double2 po = el_ld2<NT>(a.p_old + c * a.stride + idx);
-            double2 rv = el_ld2<NT>(r + c * a.stride + idx);
-            if (!ghost && alpha != 0.0) {
-                const double2 qv = el_ld2<NT>(q + c * a.stride + idx);
-                rv.x -= alpha * qv.x;
-                rv.y -= alpha * qv.y;
-                el_st2<NT>(r + c * a.stride + idx, rv);
-                double2 xv = el_ld2<NT>(a.x + c * a.stride + idx);
-                xv.x += alpha * po.x;
-                xv.y += alpha * po.y;
-                el_st2<NT>(a.x + c * a.stride + idx, xv);
+            po[c] = el_ld2<NT>(a.p_old + c * a.stride + idx);
+            rv[c] = el_ld2<NT>(r + c * a.stride + idx);
+            qv[c] = make_double2(0.0, 0.0);
+            xv[c] = make_double2(0.0, 0.0);
+            if (upd) {
+                qv[c] = el_ld2<NT>(q + c * a.stride + idx);
+                xv[c] = el_ld2<NT>(a.x + c * a.stride + idx);
             }
-            const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv.x, sDinv[cls1 * 3 + c] * rv.y);
-            acc_rz += rv.x * zv.x + rv.y * zv.y;
-            acc_rr += rv.x * rv.x + rv.y * rv.y;
+        }
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            if (upd) {
+                rv[c].x -= alpha * qv[c].x;
+                rv[c].y -= alpha * qv[c].y;
+                el_st2<NT>(r + c * a.stride + idx, rv[c]);
+                xv[c].x += alpha * po[c].x;
+                xv[c].y += alpha * po[c].y;
+                el_st2<NT>(a.x + c * a.stride + idx, xv[c]);
+            }
+            const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv[c].x, sDinv[cls1 * 3 + c] * rv[c].y);
+            acc_rz += rv[c].x * zv.x + rv[c].y * zv.y;
+            acc_rr += rv[c].x * rv[c].x + rv[c].y * rv[c].y;
             // (p_n is read by the block apply that follows: a plain store even with NT)
-            *reinterpret_cast<double2*>(a.p_new + c * a.stride + idx) = make_double2(zv.x + beta * po.x, zv.y + beta * po.y);
+            *reinterpret_cast<double2*>(a.p_new + c * a.stride + idx) = make_double2(zv.x + beta * po[c].x, zv.y + beta * po[c].y);
         }
     }
     if (!ghost) {
