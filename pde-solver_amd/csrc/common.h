@@ -283,7 +283,7 @@ int weighted_assemble(pdegpu_ctx* ctx, const GridDev& g, const pdegpu_weight* w,
 int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, double* z, const double* dinv, double* scal,
               double* partials, int use_alpha, LaunchInfo* li, const DotIn& di = DotIn());
 // wmarch.hip: z-marching kernels of the weighted 3-D operators
-bool wmarch_supported(const GridDev& g);
+bool wmarch_supported(const GridDev& g, int cm);
 int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
 int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, double* scal, double* partials,
               LaunchInfo* li, const DotIn& di = DotIn());

@@ -1582,7 +1582,7 @@ int session_make_weighted(pdegpu_session* s, const pdegpu_weight* w) {
     }
     PG_TRY(weighted_assemble(ctx, s->g, w, h, lengths, s->cM, s->cK, s->ellA, s->ellM, s->dinv, s->ell_stride, s->ell_mode));
     s->weighted = true;
-    s->wfast = ctx->wfast != 0 && s->ell_mode != 0 && wmarch_supported(s->g);
+    s->wfast = ctx->wfast != 0 && s->ell_mode != 0 && wmarch_supported(s->g, s->ell_mode);
     if (s->wfast && s->ell_mode == 2) {
         const size_t nt = (size_t)16 * s->g.NZ * s->g.NY * sizeof(double);
         PG_HIP(ctx, hipMalloc(&s->rowA, nt));
@@ -1805,12 +1805,14 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
 }  // namespace
 
 // y = (cM M_w + cK K_w) x for the weighted forms of the curvilinear / composite tools (operator tests, timing).  marching = 1: the z-marching
-// kernels of wmarch.hip on the all-Dirichlet box — the free (interior) rows only, every other entry of y is 0; PDEGPU_EUNSUPPORTED where that path
-// does not apply (see wmarch_supported).  marching = 0: every row through the class-table kernels reading the per-node rows.
+// kernels of wmarch.hip on the all-Dirichlet box — the free (interior) rows only, every other entry of y is 0; marching = 2: the same with only the
+// two x-faces constrained (weights that do not depend on x: the rows of the nodes on the four natural faces are computed too); PDEGPU_EUNSUPPORTED
+// where that path does not apply (see wmarch_supported).  marching = 0: every row through the class-table kernels reading the per-node rows.
 extern "C" int pdegpu_heat_apply_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight, double cM, double cK, const double* x,
                                           double* y, int marching) {
     if (!ctx) return PDEGPU_EINVAL;
     if (!x || !y || !weight) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
+    if (marching < 0 || marching > 2) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "marching must be 0, 1 or 2");
     PG_TRY(validate_grid(ctx, grid));
     if (weight->kind < PDEGPU_WEIGHT_ONE || weight->kind > PDEGPU_WEIGHT_RCYL) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
     if (grid->element_mode != PDEGPU_ELEM_P1SPLIT) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted forms use the P1 split only");
@@ -1820,8 +1822,9 @@ extern "C" int pdegpu_heat_apply_weighted(pdegpu_ctx* ctx, const pdegpu_grid* gr
     heat.kappa = 1.0;
     heat.dt = 1.0;
     heat.fast_path = 0;
-    heat.bc_mode = marching ? PDEGPU_BC_UNIFORM : PDEGPU_BC_DIRECTIONAL;
+    heat.bc_mode = marching == 1 ? PDEGPU_BC_UNIFORM : PDEGPU_BC_DIRECTIONAL;
     heat.bc_present[0] = marching ? 1 : 0;
+    heat.bc_present[1] = marching == 2 ? 1 : 0;              // 2: T_left and T_right given, the other four faces natural
     const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
     pdegpu_session* s = nullptr;
     PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));

@@ -53,9 +53,10 @@ __device__ __forceinline__ double dpp_from_upper(double v) {
 }
 
 struct WGeom {
-    int ntx, nty;        // 128-node x-tiles, RY-row y-tiles of the interior rows 1 .. NY-2
+    int ntx, nty;        // 128-node x-tiles, RY-row y-tiles of the free rows jlo .. jhi
     int nwg_xy;          // workgroups per z-chunk (four consecutive tiles of the row-major tile order each)
-    int nzc, zlen;       // z-chunks of zlen planes over the interior planes 1 .. NZ-2
+    int nzc, zlen;       // z-chunks of zlen planes over the free planes klo .. khi
+    int jlo, jhi, klo, khi;   // rows / planes that carry unknowns: 1 .. N-2 where the y / z faces are Dirichlet, 0 .. N-1 where they are natural
 };
 
 // one row of one held plane: the two nodes of the lane and their x-neighbours (l = node i0-1, r = node i0+2)
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     const int w = (wid - zc * wgm.nwg_xy) * 4 + wv;
     const int yt = w / wgm.ntx, xt = w - yt * wgm.ntx;
     const int i0 = xt * 128 + 2 * lane;
-    const int j0 = 1 + yt * RY;
-    const int jmax = g.NY - 2;
-    const int lk0 = 1 + zc * wgm.zlen;
-    const int lk1 = min(lk0 + wgm.zlen, g.NZ - 1);
+    const int j0 = wgm.jlo + yt * RY;
+    const int jmax = wgm.jhi;
+    const int lk0 = wgm.klo + zc * wgm.zlen;
+    const int lk1 = min(lk0 + wgm.zlen, wgm.khi + 1);
     const bool active = yt < wgm.nty && zc < wgm.nzc && lk0 < lk1;          // wave-uniform
 
     double alpha_prev = 0.0, beta = 0.0;
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
         const bool mb = (i0 + 1 <= g.NX - 2);                               // node b = i0 + 1
         const bool elane = (lane == 0 && i0 >= 1) || (lane == 63 && i0 + 2 < g.PX);
         const long long eoff = (lane == 0) ? -1 : 2;
-        auto row_ok = [&](int j) { return j < g.NY; };
+        // (natural y / z faces: the rows -1 / NY and the planes -1 / NZ a face row asks for do not exist — they meet weights that are exactly 0: the row
+        // reads offset 0 of the vector, the ghost planes are zero)
+        auto row_ok = [&](int j) { return j >= 0 && j < g.NY; };
         auto load2 = [&](const double* v, long long off) { return *reinterpret_cast<const double2*>(v + off); };
         const double PG_CONSTANT* tab = (const double PG_CONSTANT*)a.ell;    // CM 2: the row table
 
@@ -272,20 +275,20 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
 // scalars of the row's line (entry 0 = D, entry 15 = D^-1).  Dirichlet nodes and pads of a free row hold z = q = 0 and add 0.
 template <int CM>
 __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const double* __restrict__ q, const double* __restrict__ dtab, const double* __restrict__ ditab,
-                                              GridDev g, int nrows, double* scal, double* __restrict__ partials, DotIn di) {
+                                              GridDev g, int nrows, int jlo, int ny_free, int klo, double* scal, double* __restrict__ partials, DotIn di) {
     __shared__ double sRed[4];
     const double alpha = cg_alpha_in(di, scal, sRed);
     double acc = 0.0;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ny2 = g.NY - 2, px2 = g.PX / 2;
+    const int ny2 = ny_free, px2 = g.PX / 2;
     const double PG_CONSTANT* tab = (const double PG_CONSTANT*)dtab;
     for (int row = blockIdx.x * 4 + wv; row < nrows; row += gridDim.x * 4) {       // wave-uniform
-        const int k = row / ny2, j = row - k * ny2 + 1;
-        const long long base = (long long)(k + 1) * g.PP + (long long)j * g.PX;
+        const int kk = row / ny2, j = row - kk * ny2 + jlo, k = kk + klo;
+        const long long base = (long long)k * g.PP + (long long)j * g.PX;
         double ds = 0.0, dis = 0.0;
         if (CM == 2) {
-            const long long e = ((long long)(k + 1) * g.NY + j) * 16;
+            const long long e = ((long long)k * g.NY + j) * 16;
             ds = tab[e];
             dis = tab[e + 15];
         }
@@ -342,12 +345,22 @@ __global__ __launch_bounds__(256) void k_wrowtab(const double* __restrict__ ellA
     }
 }
 
+// the rows / planes with unknowns: every boundary node Dirichlet -> the interior; x-faces Dirichlet and the other four natural -> all of them
+void wmarch_ranges(const GridDev& g, int* jlo, int* jhi, int* klo, int* khi) {
+    const bool sides_free = g.bc_mode == PDEGPU_BC_DIRECTIONAL && !g.bc_present[2];
+    *jlo = sides_free ? 0 : 1;
+    *jhi = sides_free ? g.NY - 1 : g.NY - 2;
+    *klo = sides_free ? 0 : 1;
+    *khi = sides_free ? g.NZ - 1 : g.NZ - 2;
+}
+
 WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
     WGeom w{};
+    wmarch_ranges(g, &w.jlo, &w.jhi, &w.klo, &w.khi);
     w.ntx = (g.NX - 1 + 127) / 128;
-    w.nty = (g.NY - 2 + RY - 1) / RY;
+    w.nty = (w.jhi - w.jlo + 1 + RY - 1) / RY;
     w.nwg_xy = (int)(((long long)w.ntx * w.nty + 3) / 4);
-    const int planes = g.NZ - 2;
+    const int planes = w.khi - w.klo + 1;
     // z-chunks: as few resident rounds of as short marches as possible (every chunk marches a two-plane prologue; CM 1 also loads its weights)
     const int target = std::max(1, wg_per_cu * ctx->num_cu);
     const int pcap = stencil_max_partials(const_cast<pdegpu_ctx*>(ctx));
@@ -408,13 +421,17 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
 
 }  // namespace
 
-// a weighted session whose operator applications can march: 3-D, one slab owning every plane, every boundary node Dirichlet, at least one interior
-// node per axis
-bool wmarch_supported(const GridDev& g) {
+// a weighted session whose operator applications can march: 3-D, one slab owning every plane, at least one interior node per axis, and either every
+// boundary node Dirichlet (the uniform boundary value; T_left, T_right and T_side all given) or — weights that do not depend on x (cm 2), whose row
+// table holds the truncated rows of the face nodes — both x-faces Dirichlet and the other four faces natural (the cylinder fallback with T_left /
+// T_right: its T_side matches no facet, fenics_mcp_server.py:590-594)
+bool wmarch_supported(const GridDev& g, int cm) {
     if (g.dim != 3 || g.k0 != 0 || g.nkl != g.NZ || g.flat2d) return false;
     if (g.NX < 3 || g.NY < 3 || g.NZ < 3) return false;
-    if (!(g.bc_mode == PDEGPU_BC_UNIFORM && g.bc_present[0])) return false;
-    return (long long)(g.NZ - 2) * (g.NY - 2) < 0x7fffffffLL;
+    if ((long long)g.NZ * g.NY >= 0x7fffffffLL) return false;
+    if (g.bc_mode == PDEGPU_BC_UNIFORM) return g.bc_present[0] != 0;
+    if (!g.bc_present[0] || !g.bc_present[1]) return false;
+    return g.bc_present[2] != 0 || cm == 2;
 }
 
 // a.ell / a.ell_stride / a.ell_mode (= CM) / a.wdinv describe the coefficients (see the header comment); mode: PLAIN, RESIDUAL, CG_K1
@@ -429,14 +446,17 @@ int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li
 // CM 1: dtab = the diagonal (compact rows of A, interior plane class, weight 0), ditab = its inverse, both [j * PX + i]; CM 2: dtab = the row table of A
 int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, double* scal, double* partials,
               LaunchInfo* li, const DotIn& di) {
-    const int nrows = (g.NZ - 2) * (g.NY - 2);
+    int jlo, jhi, klo, khi;
+    wmarch_ranges(g, &jlo, &jhi, &klo, &khi);
+    const int ny_free = jhi - jlo + 1;
+    const int nrows = (khi - klo + 1) * ny_free;
     long long nb = ((long long)nrows + 3) / 4;
     const long long cap = (long long)(ctx->wfast_k2_mult > 0 ? ctx->wfast_k2_mult : 4) * ctx->num_cu;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     if (li) { li->grid = (int)nb; li->block = 256; }
-    if (cm == 1) hipLaunchKernelGGL((k_wk2<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, scal, partials, di);
-    else hipLaunchKernelGGL((k_wk2<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, scal, partials, di);
+    if (cm == 1) hipLaunchKernelGGL((k_wk2<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
+    else hipLaunchKernelGGL((k_wk2<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

@@ -66,6 +66,54 @@ def test_marching_weighted_operator_matches_the_assembled_matrix(lib, gpu_ctx, c
     assert np.abs(y - A @ x).max() <= 1e-13 * scale
 
 
+@pytest.mark.parametrize("ry", [1, 2])
+@pytest.mark.parametrize("case", ["cylinder_fallback", "cylinder_fallback_core", "box_core", "box_core_two_cells"])
+def test_marching_weighted_operator_with_natural_side_faces(lib, gpu_ctx, case, ry):
+    """x-independent weights with only x = 0 / x = Lx constrained (the cylinder tool's T_left / T_right, :582-604): the marching kernels also compute the
+    truncated rows of the nodes on the four natural faces, edges and corners of those faces included == the oracle's assembled matrices"""
+    from pdegpu import _lib as L
+    okind, lkind, n, lengths, origin, core_radius, core_ratio = CASES[case]
+    coords, cells = o.box_mesh(*lengths, *n)
+    coords = coords + np.array(origin)
+    kcell = np.where(o.core_cells(coords, cells, core_radius), core_ratio, 1.0) if core_radius > 0 else None
+    K, M, _ = o.assemble_weighted(coords, cells, okind, kcell)
+    cM, cK = 1.0, 0.021
+    A = (cM * M + cK * K).tocsr()
+    N = coords.shape[0]
+    x = np.random.default_rng(7).uniform(-1.0, 1.0, N)
+    ix = np.arange(N) % (n[0] + 1)
+    free = (ix > 0) & (ix < n[0])
+    ref = np.where(free, A @ x, 0.0)
+    grid = L.make_grid(3, n, lengths, L.ELEM_P1SPLIT)
+    w = _weight(L, getattr(L, lkind), origin, core_radius, core_ratio)
+    y = np.empty(N)
+    L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", ry))
+    try:
+        L.check(gpu_ctx, lib.pdegpu_heat_apply_weighted(gpu_ctx, grid, w, cM, cK, L.dptr(x), L.dptr(y), 2))
+    finally:
+        L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", 2))
+    assert np.abs(y - ref).max() <= 1e-13 * np.abs(A).dot(np.abs(x)).max()
+
+
+def test_cylinder_tool_with_left_and_right_values_marches(lib, gpu_ctx):
+    """the reference's typical cylinder call — T_left / T_right forwarded, T_side matching no facet (:590-594): marching kernels, natural side faces"""
+    from pdegpu import heat
+    for extra in (dict(), dict(core_radius=0.3, core_diffusivity=40.0, steady=True, source_type="constant", source_value=5.0)):
+        kw = dict(Lx=1.0, nx=9, ny=8, nz=7, diffusivity=1.0, T_boundary=20.0, T_initial=60.0, dt=0.01, num_steps=3, cylinder_radius=0.5, T_left=100.0,
+                  T_right=20.0, T_side=55.0)
+        kw.update(extra)
+        ref = o.solve_heat_3d_cylinder_fallback(**kw)
+        got = heat._solve_heat_3d_raw(Ly=1.0, Lz=1.0, geometry_type="cylinder", rtol=1e-12, **kw)
+        assert got.meta["solver_path"] == "weighted-marching"
+        assert np.abs(got.values - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
+    # the composite core on the plain box with all three directional values: every boundary node constrained, three different values
+    kw = dict(Lx=1.0, Ly=0.8, Lz=0.9, nx=9, ny=8, nz=10, diffusivity=1.0, T_boundary=20.0, T_initial=70.0, dt=0.005, num_steps=3, core_radius=0.45,
+              core_diffusivity=35.0, T_left=90.0, T_right=-5.0, T_side=10.0)
+    got = heat._solve_heat_3d_raw(rtol=1e-12, **kw)
+    assert got.meta["solver_path"] == "weighted-marching"
+    assert np.abs(got.values - o.solve_heat_3d(**kw).values).max() <= 1e-9 * 90.0
+
+
 def test_marching_weighted_apply_refuses_what_it_does_not_cover(lib, gpu_ctx):
     from pdegpu import _lib as L
     grid = L.make_grid(2, (8, 9), (1.0, math.pi), L.ELEM_P1SPLIT)
