@@ -170,6 +170,7 @@ const char* pdegpu_version(void);
  * wfast_ry           | 2       | rows per wavefront column of those kernels where the weights are wave-uniform (1|2)
  * wfast_wg_per_cu    | 0       | workgroups per CU their z-chunking aims for (0 = occupancy API)
  * wfast_k2_mult      | 4       | workgroups per CU of their K2 (a wavefront per grid row)
+ * wfast_k2_nt        | -1      | non-temporal loads / stores in that K2: 1|0, -1 = where one vector exceeds 64 MiB
  * ell_compact        | 1       | weighted (curvilinear / composite) 3-D operators whose weight does not depend on one coordinate store the coefficient
  *                    |         | rows of three representative planes / columns instead of one row per node (0 = one row per node)
  * el_fast            | 1       | 3-D: z-marching block stencil (0 = thread-per-node class-table kernel)

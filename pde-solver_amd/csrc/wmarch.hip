@@ -273,7 +273,28 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
 // K2 of the weighted PCG on z = D^-1 r: z -= alpha D^-1 q on the free rows, partial r.z = sum D z^2.  A wavefront takes whole grid rows (j, k), so the
 // diagonal comes without index arithmetic: CM 1 from the interior plane class of the compact rows (D = centre weight, D^-1: [j * PX + i]), CM 2 as two
 // scalars of the row's line (entry 0 = D, entry 15 = D^-1).  Dirichlet nodes and pads of a free row hold z = q = 0 and add 0.
-template <int CM>
+// NT: non-temporal loads / stores of the two streamed vectors (HBM-resident grids: nothing of them is re-read before it has left every cache; a
+// compile-time choice — behind a runtime switch the compiler merges the two forms and drops the hint)
+typedef double wk_d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 wk_ld(const double* p) {
+    if constexpr (NT) {
+        const wk_d2 v = __builtin_nontemporal_load(reinterpret_cast<const wk_d2*>(p));
+        return make_double2(v.x, v.y);
+    } else {
+        return *reinterpret_cast<const double2*>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void wk_st(double* p, const double2& v) {
+    if constexpr (NT) {
+        const wk_d2 t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<wk_d2*>(p));
+    } else {
+        *reinterpret_cast<double2*>(p) = v;
+    }
+}
+template <int CM, bool NT>
 __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const double* __restrict__ q, const double* __restrict__ dtab, const double* __restrict__ ditab,
                                               GridDev g, int nrows, int jlo, int ny_free, int klo, double* scal, double* __restrict__ partials, DotIn di) {
     __shared__ double sRed[4];
@@ -297,8 +318,8 @@ __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const doubl
             const int sa = s0 + lane, sb = s0 + 64 + lane;
             const bool oka = sa < px2, okb = sb < px2;
             const long long offa = base + 2LL * (oka ? sa : 0), offb = base + 2LL * (okb ? sb : 0);
-            double2 ra = *reinterpret_cast<const double2*>(r + offa), rb = *reinterpret_cast<const double2*>(r + offb);
-            const double2 qa = *reinterpret_cast<const double2*>(q + offa), qb = *reinterpret_cast<const double2*>(q + offb);
+            double2 ra = wk_ld<NT>(r + offa), rb = wk_ld<NT>(r + offb);
+            const double2 qa = wk_ld<NT>(q + offa), qb = wk_ld<NT>(q + offb);
             double2 da = make_double2(ds, ds), db = da, ia = make_double2(dis, dis), ib = ia;
             if (CM == 1) {
                 const long long ta = (long long)j * g.PX + 2LL * (oka ? sa : 0), tb = (long long)j * g.PX + 2LL * (okb ? sb : 0);
@@ -312,11 +333,11 @@ __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const doubl
             rb.x -= alpha * (ib.x * qb.x);
             rb.y -= alpha * (ib.y * qb.y);
             if (oka) {
-                *reinterpret_cast<double2*>(r + offa) = ra;
+                wk_st<NT>(r + offa, ra);
                 acc += da.x * ra.x * ra.x + da.y * ra.y * ra.y;
             }
             if (okb) {
-                *reinterpret_cast<double2*>(r + offb) = rb;
+                wk_st<NT>(r + offb, rb);
                 acc += db.x * rb.x * rb.x + db.y * rb.y * rb.y;
             }
         }
@@ -455,8 +476,13 @@ int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     if (li) { li->grid = (int)nb; li->block = 256; }
-    if (cm == 1) hipLaunchKernelGGL((k_wk2<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
-    else hipLaunchKernelGGL((k_wk2<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
+    // z is read again by the next K1 and q was just written by this iteration's: on grids whose vectors stay in the caches the default policy keeps them there
+    int nt = ctx->wfast_k2_nt;
+    if (nt < 0) nt = ((long long)g.nkl * g.PP * 8 > (64LL << 20)) ? 1 : 0;
+    if (cm == 1 && nt) hipLaunchKernelGGL((k_wk2<1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
+    else if (cm == 1) hipLaunchKernelGGL((k_wk2<1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
+    else if (nt) hipLaunchKernelGGL((k_wk2<2, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
+    else hipLaunchKernelGGL((k_wk2<2, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }
