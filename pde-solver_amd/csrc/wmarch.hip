@@ -62,9 +62,14 @@ struct WGeom {
 // one row of one held plane: the two nodes of the lane and their x-neighbours (l = node i0-1, r = node i0+2)
 struct WRow { double l, x, y, r; };
 
-template <int CM, int RY, int MODE>
+// LQ (CM 1): the last LQ of a node pair's 15 weights live in LDS instead of registers — as a per-lane scratch (a lane reads back what it wrote: no
+// barrier, conflict-free 16-byte slots) — which is what lets a wavefront with per-lane weights own TWO rows: 2 x 30 weights in registers leave no
+// room for the plane state (> 256 VGPRs); with 8 of 15 in LDS (64 KB per workgroup, two workgroups per CU) it fits.
+template <int CM, int RY, int MODE, int LQ>
 __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     __shared__ double sRed[4];
+    __shared__ double2 sC[LQ > 0 ? 4 : 1][LQ > 0 ? RY : 1][LQ > 0 ? LQ : 1][LQ > 0 ? 64 : 1];
+    constexpr int NQR = 15 - LQ;               // weights of a node pair kept in registers
     constexpr bool K1 = (MODE == APPLY_CG_K1), RES = (MODE == APPLY_RESIDUAL);
     constexpr bool DI = RES;                   // the pass needs the Jacobi diagonal^-1 (of its own rows)
     constexpr int RH = RY + 2;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
 
         // ---- coefficients -------------------------------------------------------------------------------------------------------------------
         // CM 1: cA / cB = the 15 weights of node a / b of every own row, D = diagonal^-1 of the own rows (residual pass)
-        double cA[CM == 1 ? RY : 1][15], cB[CM == 1 ? RY : 1][15];
+        double cA[CM == 1 ? RY : 1][NQR], cB[CM == 1 ? RY : 1][NQR];
         double2 D[(CM == 1 && DI) ? RY : 1];
         if (CM == 1) {
 #pragma unroll
@@ -113,8 +118,12 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
 #pragma unroll
                 for (int q = 0; q < 15; ++q) {
                     const double2 c = load2(a.ell + (long long)q * a.ell_stride, off);
-                    cA[r][q] = c.x;
-                    cB[r][q] = c.y;
+                    if (q < NQR) {
+                        cA[r][q] = c.x;
+                        cB[r][q] = c.y;
+                    } else {
+                        sC[wv][r][q - NQR][lane] = c;
+                    }
                 }
             }
             if (DI) {
@@ -229,7 +238,13 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                 double ca[15], cb[15], da = 0.0, db = 0.0;
                 if (CM == 1) {
 #pragma unroll
-                    for (int q = 0; q < 15; ++q) { ca[q] = cA[r][q]; cb[q] = cB[r][q]; }
+                    for (int q = 0; q < NQR; ++q) { ca[q] = cA[r][q]; cb[q] = cB[r][q]; }
+#pragma unroll
+                    for (int q = NQR; q < 15; ++q) {
+                        const double2 c = sC[wv][r][q - NQR][lane];
+                        ca[q] = c.x;
+                        cb[q] = c.y;
+                    }
                     if (DI) { da = D[r].x; db = D[r].y; }
                 } else {
 #pragma unroll
@@ -403,16 +418,16 @@ WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu
     return w;
 }
 
-template <int CM, int RY>
+template <int CM, int RY, int LQ>
 int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     static int occ[4] = {0, 0, 0, 0};
     if (occ[mode & 3] == 0) {
         int nb = 0;
         hipError_t e;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN, LQ>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL, LQ>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1, LQ>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
         occ[mode & 3] = std::min(nb, 8);
@@ -432,9 +447,9 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
     }
     if (G == 0 || (li && li->dry)) return PDEGPU_OK;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -459,9 +474,9 @@ bool wmarch_supported(const GridDev& g, int cm) {
 int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     if (mode != APPLY_PLAIN && mode != APPLY_RESIDUAL && mode != APPLY_CG_K1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weighted marching: PLAIN, RESIDUAL or K1");
     const int ry = ctx->wfast_ry;
-    if (a.ell_mode == 1) return launch_wmarch<1, 1>(ctx, a, mode, li);
-    if (ry == 1) return launch_wmarch<2, 1>(ctx, a, mode, li);
-    return launch_wmarch<2, 2>(ctx, a, mode, li);
+    if (a.ell_mode == 1) return ctx->wfast_ry1 == 2 ? launch_wmarch<1, 2, 8>(ctx, a, mode, li) : launch_wmarch<1, 1, 0>(ctx, a, mode, li);
+    if (ry == 1) return launch_wmarch<2, 1, 0>(ctx, a, mode, li);
+    return launch_wmarch<2, 2, 0>(ctx, a, mode, li);
 }
 
 // CM 1: dtab = the diagonal (compact rows of A, interior plane class, weight 0), ditab = its inverse, both [j * PX + i]; CM 2: dtab = the row table of A
