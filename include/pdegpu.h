@@ -226,8 +226,9 @@ int pdegpu_heat_solve_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const p
  * :1374-1375 and of the box / cylinder branch :702-703 with r_expr and the DG0 kappa — applied matrix-free (operator tests, timing).
  * marching = 1: the z-marching kernels (csrc/wmarch.hip) on the box with every boundary node constrained: interior rows only, the rest of y is 0;
  * marching = 2: the same with only the faces x = 0 and x = Lx constrained (T_left, T_right of :582-604; weights that do not depend on x): the rows of
- * the nodes on the four natural faces too.  PDEGPU_EUNSUPPORTED where they do not apply (2-D / 1-D grids, weights depending on all coordinates,
- * fewer than 2 cells on an axis, natural faces with a weight that depends on x).
+ * the nodes on the four natural faces too; marching = 3: only x = 0 constrained (T_left alone); marching = 4: x = 0 and the four side faces
+ * constrained, x = Lx natural (T_left + T_side).  PDEGPU_EUNSUPPORTED where they do not apply (2-D / 1-D grids, weights depending on all
+ * coordinates, fewer than 2 cells on an axis, natural faces with a weight that depends on x).
  * marching = 0: every row, class-table kernels reading one coefficient row per node. */
 int pdegpu_heat_apply_weighted(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_weight* weight, double cM, double cK,
                                const double* x, double* y, int marching);

@@ -244,6 +244,7 @@ struct StencilArgs {
     int lk_lo2 = 0, lk_hi2 = 0;   // ... and a second, disjoint plane range in the SAME launch (the two edge planes of a slab: one launch, not two)
     const double* ell;        // weighted operators: per-node coefficients, ell[q * ell_stride + idx], q = 15-offset position
     long long ell_stride;
+    const double* wface[2] = {nullptr, nullptr};   // weighted marching kernels, weights independent of x: row tables of the x-face 0 / NX-1 where it is natural
     const double* wdinv = nullptr;   // weighted marching kernels, per-lane weights: Jacobi diagonal^-1 of the interior plane class, [j * PX + i]
     int ell_mode;             // 0: one row per node; 1: rows of three planes only (slowest index 0 | interior | last: the weight does not depend on that
                               // coordinate); 2: three rows per grid row (x index 0 | interior | last: the weight does not depend on x) — weighted.hip
@@ -287,9 +288,9 @@ int vec_k2_pc(pdegpu_ctx* ctx, const GridDev& g, double* r, const double* q, dou
 // wmarch.hip: z-marching kernels of the weighted 3-D operators
 bool wmarch_supported(const GridDev& g, int cm);
 int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li);
-int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, double* scal, double* partials,
-              LaunchInfo* li, const DotIn& di = DotIn());
-int wmarch_rowtab(pdegpu_ctx* ctx, const GridDev& g, const double* ellA, const double* ellM, long long stride, double* rowA, double* rowM);
+int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, const double* flo,
+              const double* fhi, double* scal, double* partials, LaunchInfo* li, const DotIn& di = DotIn());
+int wmarch_rowtab(pdegpu_ctx* ctx, const GridDev& g, const double* ellA, const double* ellM, long long stride, double* rowA, double* rowM, int cls);
 int vec_membench(pdegpu_ctx* ctx, const GridDev& g, int which, double* r, const double* q, double* b, double* sink);
 int vec_copy(pdegpu_ctx* ctx, const GridDev& g, double* dst, const double* src);
 int vec_pack(pdegpu_ctx* ctx, const GridDev& g, const double* v, double* dense);     // pitched -> dense

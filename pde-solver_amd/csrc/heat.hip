@@ -68,6 +68,7 @@ struct pdegpu_session {
     // weighted operators on an all-Dirichlet 3-D box with compact coefficient rows: z-marching kernels (wmarch.hip), no z vector
     bool wfast = false;
     double *rowA = nullptr, *rowM = nullptr;   // ell_mode 2: row tables [NZ * NY][16] (15 weights of the interior column class + D^-1)
+    double *rowAf[2] = {nullptr, nullptr}, *rowMf[2] = {nullptr, nullptr};   // ... and of the column classes x = 0 / x = NX-1 where that face is natural
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -263,6 +264,7 @@ void wfast_args(const pdegpu_session* s, int which, StencilArgs* a) {
     } else {
         a->ell = which == 0 ? s->rowA : s->rowM;
         a->wdinv = nullptr;
+        for (int f = 0; f < 2; ++f) a->wface[f] = which == 0 ? s->rowAf[f] : s->rowMf[f];
     }
 }
 
@@ -466,7 +468,7 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         return PDEGPU_OK;
     }
     if (s->wfast) return wmarch_k2(s->ctx, s->g, s->ell_mode, s->r.v, s->q.v, s->ell_mode == 1 ? s->ellA + s->g.PP : s->rowA,
-                                   s->ell_mode == 1 ? s->dinv + s->g.PP : nullptr, s->d_scal, part_out, li, di);
+                                   s->ell_mode == 1 ? s->dinv + s->g.PP : nullptr, s->rowAf[0], s->rowAf[1], s->d_scal, part_out, li, di);
     if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, part_out, 1, li, di);
     return vec_k2(s->ctx, s->g, s->r.v, s->q.v, s->d_scal, part_out, li, di);
 }
@@ -636,6 +638,10 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
         if (b0) (void)hipFree(b0);
     if (s->rowA) (void)hipFree(s->rowA);
     if (s->rowM) (void)hipFree(s->rowM);
+    for (int f = 0; f < 2; ++f) {
+        if (s->rowAf[f]) (void)hipFree(s->rowAf[f]);
+        if (s->rowMf[f]) (void)hipFree(s->rowMf[f]);
+    }
     vec_free(&s->z);
     vec_free(&s->xprev);
     delete s;
@@ -1589,7 +1595,13 @@ int session_make_weighted(pdegpu_session* s, const pdegpu_weight* w) {
         const size_t nt = (size_t)16 * s->g.NZ * s->g.NY * sizeof(double);
         PG_HIP(ctx, hipMalloc(&s->rowA, nt));
         PG_HIP(ctx, hipMalloc(&s->rowM, nt));
-        PG_TRY(wmarch_rowtab(ctx, s->g, s->ellA, s->ellM, s->ell_stride, s->rowA, s->rowM));
+        PG_TRY(wmarch_rowtab(ctx, s->g, s->ellA, s->ellM, s->ell_stride, s->rowA, s->rowM, 1));
+        for (int f = 0; f < 2; ++f) {           // a natural x-face: the rows of its nodes (column class 0 / 2 of the compact rows)
+            if (!(s->g.bc_mode == PDEGPU_BC_DIRECTIONAL && !s->g.bc_present[f])) continue;
+            PG_HIP(ctx, hipMalloc(&s->rowAf[f], nt));
+            PG_HIP(ctx, hipMalloc(&s->rowMf[f], nt));
+            PG_TRY(wmarch_rowtab(ctx, s->g, s->ellA, s->ellM, s->ell_stride, s->rowAf[f], s->rowMf[f], f == 0 ? 0 : 2));
+        }
     }
     return PDEGPU_OK;
 }
@@ -1814,7 +1826,7 @@ extern "C" int pdegpu_heat_apply_weighted(pdegpu_ctx* ctx, const pdegpu_grid* gr
                                           double* y, int marching) {
     if (!ctx) return PDEGPU_EINVAL;
     if (!x || !y || !weight) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
-    if (marching < 0 || marching > 2) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "marching must be 0, 1 or 2");
+    if (marching < 0 || marching > 4) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "marching must be 0 .. 4");
     PG_TRY(validate_grid(ctx, grid));
     if (weight->kind < PDEGPU_WEIGHT_ONE || weight->kind > PDEGPU_WEIGHT_RCYL) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "unknown weight kind %d", weight->kind);
     if (grid->element_mode != PDEGPU_ELEM_P1SPLIT) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted forms use the P1 split only");
@@ -1827,6 +1839,7 @@ extern "C" int pdegpu_heat_apply_weighted(pdegpu_ctx* ctx, const pdegpu_grid* gr
     heat.bc_mode = marching == 1 ? PDEGPU_BC_UNIFORM : PDEGPU_BC_DIRECTIONAL;
     heat.bc_present[0] = marching ? 1 : 0;
     heat.bc_present[1] = marching == 2 ? 1 : 0;              // 2: T_left and T_right given, the other four faces natural
+    heat.bc_present[2] = marching == 4 ? 1 : 0;              // 3: T_left only;  4: T_left and T_side (x = Lx natural)
     const int64_t nslow = grid->dim == 3 ? (int64_t)grid->n[2] + 1 : 1;
     pdegpu_session* s = nullptr;
     PG_TRY(pdegpu_session_create(ctx, grid, &heat, 0, nslow, &s));

@@ -57,6 +57,7 @@ struct WGeom {
     int nwg_xy;          // workgroups per z-chunk (four consecutive tiles of the row-major tile order each)
     int nzc, zlen;       // z-chunks of zlen planes over the free planes klo .. khi
     int jlo, jhi, klo, khi;   // rows / planes that carry unknowns: 1 .. N-2 where the y / z faces are Dirichlet, 0 .. N-1 where they are natural
+    int xlo, xhi;             // first / last column that carries unknowns: 1 / NX-2, or 0 / NX-1 where that x-face is natural (FX instantiations)
 };
 
 // one row of one held plane: the two nodes of the lane and their x-neighbours (l = node i0-1, r = node i0+2)
@@ -65,8 +66,13 @@ struct WRow { double l, x, y, r; };
 // LQ (CM 1): the last LQ of a node pair's 15 weights live in LDS instead of registers — as a per-lane scratch (a lane reads back what it wrote: no
 // barrier, conflict-free 16-byte slots) — which is what lets a wavefront with per-lane weights own TWO rows: 2 x 30 weights in registers leave no
 // room for the plane state (> 256 VGPRs); with 8 of 15 in LDS (64 KB per workgroup, two workgroups per CU) it fits.
-template <int CM, int RY, int MODE, int LQ>
+// FX (CM 2): a natural x-face (T_left or T_right not given, fenics_mcp_server.py:606-623).  Its nodes are lanes of ordinary rows, but their weights are
+// those of the column class "face" (truncated cells), not the wave-uniform ones: every lane reads the 128-byte line of ITS face table (lanes without a
+// face node: any line, unused) beside the scalar line of the row, the stencil of the two nodes is formed a second time with it, and the face lanes
+// keep that second result.  A template flag: sessions without a natural x-face run the instantiation without those loads.
+template <int CM, int RY, int MODE, int LQ, bool FX>
 __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
+    static_assert(!FX || CM == 2, "natural x-faces: weights independent of x only");
     __shared__ double sRed[4];
     __shared__ double2 sC[LQ > 0 ? 4 : 1][LQ > 0 ? RY : 1][LQ > 0 ? LQ : 1][LQ > 0 ? 64 : 1];
     constexpr int NQR = 15 - LQ;               // weights of a node pair kept in registers
@@ -96,8 +102,14 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     if (active) {
         const double shift = a.in_shift;
         const bool lane_ok = i0 < g.PX;
-        const bool ma = (i0 >= 1) && (i0 <= g.NX - 2);                      // node a = i0 is a free node
-        const bool mb = (i0 + 1 <= g.NX - 2);                               // node b = i0 + 1
+        const bool ma = (i0 >= wgm.xlo) && (i0 <= wgm.xhi);                 // node a = i0 is a free node
+        const bool mb = (i0 + 1 <= wgm.xhi);                                // node b = i0 + 1
+        // FX: which of the lane's two nodes sits on a natural x-face, and the face table of that node (0: x = 0, 1: x = NX-1)
+        const bool fa_lo = FX && wgm.xlo == 0 && i0 == 0, fa_hi = FX && wgm.xhi == g.NX - 1 && i0 == g.NX - 1;
+        const bool fb_hi = FX && wgm.xhi == g.NX - 1 && i0 + 1 == g.NX - 1;
+        const bool face_a = fa_lo || fa_hi, face_b = fb_hi;
+        // (lanes without a face node read a line of whichever face table exists and never use it; only one of the two may be allocated)
+        const double* ftab = (fa_hi || fb_hi || !a.wface[0]) ? a.wface[1] : a.wface[0];
         const bool elane = (lane == 0 && i0 >= 1) || (lane == 63 && i0 + 2 < g.PX);
         const long long eoff = (lane == 0) ? -1 : 2;
         // (natural y / z faces: the rows -1 / NY and the planes -1 / NZ a face row asks for do not exist — they meet weights that are exactly 0: the row
@@ -212,6 +224,15 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                     for (int q = 0; q < 16; ++q) CS[r][q] = tab[e + q];
                 }
             }
+            double2 CF[FX ? RY : 1][8];             // FX: the face line of every own row (per-lane address)
+            if (FX) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    const long long e = ((long long)lk * g.NY + min(j0 + r, jmax)) * 16;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) CF[r][q] = load2(ftab, e + 2 * q);
+                }
+            }
             double2 XV[RY];
             if (K1 && lk + 1 < lk1) {
 #pragma unroll
@@ -252,20 +273,46 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                     if (DI) da = db = CS[r][15];
                 }
                 // 15-offset list (tables_math.h pg_off15): 0 centre, 1/2 -+x, 3/4 -+y, 5/6 -+z, 7/8 -+(1,1,0), 9/10 -+(1,0,1), 11/12 -+(0,1,1), 13/14 -+(1,1,1)
-                const double qa = ca[0] * C[c].x + ca[1] * C[c].l + ca[2] * C[c].y + ca[3] * C[c - 1].x + ca[4] * C[c + 1].x + ca[5] * P[c].x +
-                                  ca[6] * N[c].x + ca[7] * C[c - 1].l + ca[8] * C[c + 1].y + ca[9] * P[c].l + ca[10] * N[c].y + ca[11] * P[c - 1].x +
-                                  ca[12] * N[c + 1].x + ca[13] * P[c - 1].l + ca[14] * N[c + 1].y;
-                const double qb = cb[0] * C[c].y + cb[1] * C[c].x + cb[2] * C[c].r + cb[3] * C[c - 1].y + cb[4] * C[c + 1].y + cb[5] * P[c].y +
-                                  cb[6] * N[c].y + cb[7] * C[c - 1].x + cb[8] * C[c + 1].r + cb[9] * P[c].x + cb[10] * N[c].r + cb[11] * P[c - 1].y +
-                                  cb[12] * N[c + 1].y + cb[13] * P[c - 1].x + cb[14] * N[c + 1].r;
+                auto stencil_a = [&](const double* w) {
+                    return w[0] * C[c].x + w[1] * C[c].l + w[2] * C[c].y + w[3] * C[c - 1].x + w[4] * C[c + 1].x + w[5] * P[c].x + w[6] * N[c].x +
+                           w[7] * C[c - 1].l + w[8] * C[c + 1].y + w[9] * P[c].l + w[10] * N[c].y + w[11] * P[c - 1].x + w[12] * N[c + 1].x +
+                           w[13] * P[c - 1].l + w[14] * N[c + 1].y;
+                };
+                auto stencil_b = [&](const double* w) {
+                    return w[0] * C[c].y + w[1] * C[c].x + w[2] * C[c].r + w[3] * C[c - 1].y + w[4] * C[c + 1].y + w[5] * P[c].y + w[6] * N[c].y +
+                           w[7] * C[c - 1].x + w[8] * C[c + 1].r + w[9] * P[c].x + w[10] * N[c].r + w[11] * P[c - 1].y + w[12] * N[c + 1].y +
+                           w[13] * P[c - 1].x + w[14] * N[c + 1].r;
+                };
+                double qa = stencil_a(ca), qb = stencil_b(cb);
+                double diag_a = ca[0], diag_b = cb[0];
+                if (FX) {                                                    // the face nodes of this wave take the second result
+                    double cf[16];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { cf[2 * q] = CF[r][q].x; cf[2 * q + 1] = CF[r][q].y; }
+                    const double fa = stencil_a(cf), fb = stencil_b(cf);
+                    qa = face_a ? fa : qa;
+                    qb = face_b ? fb : qb;
+                    diag_a = face_a ? cf[0] : diag_a;
+                    diag_b = face_b ? cf[0] : diag_b;
+                    if (DI) {
+                        da = face_a ? cf[15] : da;
+                        db = face_b ? cf[15] : db;
+                    }
+                }
+                bool fra = ma && jok, frb = mb && jok;                       // the node carries an unknown
+                if (FX) {
+                    double dv;
+                    fra = fra && i0 < g.NX && !pg_dirichlet(g, i0, j, lk, &dv);
+                    frb = frb && i0 + 1 < g.NX && !pg_dirichlet(g, i0 + 1, j, lk, &dv);
+                }
                 double2 o;
                 if (RES) {                                                   // z = D^-1 (rhs - A in);  r.z = D z^2
-                    o.x = (ma && jok) ? da * (RHS[r].x - qa) : 0.0;
-                    o.y = (mb && jok) ? db * (RHS[r].y - qb) : 0.0;
-                    acc += ca[0] * o.x * o.x + cb[0] * o.y * o.y;            // (the centre weight IS the diagonal)
+                    o.x = fra ? da * (RHS[r].x - qa) : 0.0;
+                    o.y = frb ? db * (RHS[r].y - qb) : 0.0;
+                    acc += diag_a * o.x * o.x + diag_b * o.y * o.y;          // (the centre weight IS the diagonal)
                 } else {
-                    o.x = (ma && jok) ? qa : 0.0;
-                    o.y = (mb && jok) ? qb : 0.0;
+                    o.x = fra ? qa : 0.0;
+                    o.y = frb ? qb : 0.0;
                     acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
                 }
                 if (lane_ok && jok) *reinterpret_cast<double2*>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0) = o;
@@ -311,7 +358,8 @@ __device__ __forceinline__ void wk_st(double* p, const double2& v) {
 }
 template <int CM, bool NT>
 __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const double* __restrict__ q, const double* __restrict__ dtab, const double* __restrict__ ditab,
-                                              GridDev g, int nrows, int jlo, int ny_free, int klo, double* scal, double* __restrict__ partials, DotIn di) {
+                                              GridDev g, int nrows, int jlo, int ny_free, int klo, const double* __restrict__ flo, const double* __restrict__ fhi,
+                                              double* scal, double* __restrict__ partials, DotIn di) {
     __shared__ double sRed[4];
     const double alpha = cg_alpha_in(di, scal, sRed);
     double acc = 0.0;
@@ -322,11 +370,14 @@ __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const doubl
     for (int row = blockIdx.x * 4 + wv; row < nrows; row += gridDim.x * 4) {       // wave-uniform
         const int kk = row / ny2, j = row - kk * ny2 + jlo, k = kk + klo;
         const long long base = (long long)k * g.PP + (long long)j * g.PX;
-        double ds = 0.0, dis = 0.0;
+        double ds = 0.0, dis = 0.0, dlo = 0.0, dilo = 0.0, dhi = 0.0, dihi = 0.0;
         if (CM == 2) {
             const long long e = ((long long)k * g.NY + j) * 16;
             ds = tab[e];
             dis = tab[e + 15];
+            // natural x-faces (kernel-uniform): the diagonal of the face node of this row from its own table
+            if (flo) { dlo = ((const double PG_CONSTANT*)flo)[e]; dilo = ((const double PG_CONSTANT*)flo)[e + 15]; }
+            if (fhi) { dhi = ((const double PG_CONSTANT*)fhi)[e]; dihi = ((const double PG_CONSTANT*)fhi)[e + 15]; }
         }
         for (int s0 = 0; s0 < px2; s0 += 128) {
             // two 64-pair segments per round: their loads are in flight together
@@ -336,6 +387,16 @@ __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const doubl
             double2 ra = wk_ld<NT>(r + offa), rb = wk_ld<NT>(r + offb);
             const double2 qa = wk_ld<NT>(q + offa), qb = wk_ld<NT>(q + offb);
             double2 da = make_double2(ds, ds), db = da, ia = make_double2(dis, dis), ib = ia;
+            if (CM == 2 && (flo || fhi)) {
+                const int ihi = g.NX - 1;
+                if (flo && sa == 0) { da.x = dlo; ia.x = dilo; }
+                if (fhi) {
+                    if (2 * sa == ihi) { da.x = dhi; ia.x = dihi; }
+                    if (2 * sa + 1 == ihi) { da.y = dhi; ia.y = dihi; }
+                    if (2 * sb == ihi) { db.x = dhi; ib.x = dihi; }
+                    if (2 * sb + 1 == ihi) { db.y = dhi; ib.y = dihi; }
+                }
+            }
             if (CM == 1) {
                 const long long ta = (long long)j * g.PX + 2LL * (oka ? sa : 0), tb = (long long)j * g.PX + 2LL * (okb ? sb : 0);
                 da = *reinterpret_cast<const double2*>(dtab + ta);
@@ -365,11 +426,11 @@ __global__ __launch_bounds__(256) void k_wk2(double* __restrict__ r, const doubl
 // CM 2: the row tables [NZ * NY][16] from the compact rows of the column class "interior" (entry e = 3 * row + 1 of the q-major arrays):
 // 15 weights + (table of A) the Jacobi diagonal^-1
 __global__ __launch_bounds__(256) void k_wrowtab(const double* __restrict__ ellA, const double* __restrict__ ellM, long long stride, long long rows,
-                                                  double* __restrict__ rowA, double* __restrict__ rowM) {
+                                                  double* __restrict__ rowA, double* __restrict__ rowM, int cls) {
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < rows * 16; t += (long long)gridDim.x * 256) {
         const long long row = t >> 4;
         const int q = (int)(t & 15);
-        const long long e = 3 * row + 1;
+        const long long e = 3 * row + cls;                   // column class: 0 = x-face 0, 1 = interior, 2 = x-face NX-1
         if (q < 15) {
             rowA[t] = ellA[q * stride + e];
             rowM[t] = ellM[q * stride + e];
@@ -381,19 +442,24 @@ __global__ __launch_bounds__(256) void k_wrowtab(const double* __restrict__ ellA
     }
 }
 
-// the rows / planes with unknowns: every boundary node Dirichlet -> the interior; x-faces Dirichlet and the other four natural -> all of them
-void wmarch_ranges(const GridDev& g, int* jlo, int* jhi, int* klo, int* khi) {
-    const bool sides_free = g.bc_mode == PDEGPU_BC_DIRECTIONAL && !g.bc_present[2];
+// the rows / planes / columns with unknowns: Dirichlet faces -> the interior range; natural faces (directional conditions, value not given) -> the face too
+void wmarch_ranges(const GridDev& g, int* jlo, int* jhi, int* klo, int* khi, int* xlo = nullptr, int* xhi = nullptr) {
+    const bool dirn = g.bc_mode == PDEGPU_BC_DIRECTIONAL;
+    // (a natural x-face has free nodes on its edges whatever the side faces are — T_side constrains 0 < x < Lx only, :614-617 — so every row and plane
+    // is visited then and the kernels mask node by node with the Dirichlet predicate)
+    const bool sides_free = dirn && (!g.bc_present[2] || !g.bc_present[0] || !g.bc_present[1]);
     *jlo = sides_free ? 0 : 1;
     *jhi = sides_free ? g.NY - 1 : g.NY - 2;
     *klo = sides_free ? 0 : 1;
     *khi = sides_free ? g.NZ - 1 : g.NZ - 2;
+    if (xlo) *xlo = (dirn && !g.bc_present[0]) ? 0 : 1;
+    if (xhi) *xhi = (dirn && !g.bc_present[1]) ? g.NX - 1 : g.NX - 2;
 }
 
 WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
     WGeom w{};
-    wmarch_ranges(g, &w.jlo, &w.jhi, &w.klo, &w.khi);
-    w.ntx = (g.NX - 1 + 127) / 128;
+    wmarch_ranges(g, &w.jlo, &w.jhi, &w.klo, &w.khi, &w.xlo, &w.xhi);
+    w.ntx = (w.xhi + 1 + 127) / 128;          // tiles start at node 0 and must reach the last free column
     w.nty = (w.jhi - w.jlo + 1 + RY - 1) / RY;
     w.nwg_xy = (int)(((long long)w.ntx * w.nty + 3) / 4);
     const int planes = w.khi - w.klo + 1;
@@ -418,16 +484,16 @@ WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu
     return w;
 }
 
-template <int CM, int RY, int LQ>
+template <int CM, int RY, int LQ, bool FX>
 int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     static int occ[4] = {0, 0, 0, 0};
     if (occ[mode & 3] == 0) {
         int nb = 0;
         hipError_t e;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN, LQ>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL, LQ>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1, LQ>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
         occ[mode & 3] = std::min(nb, 8);
@@ -447,9 +513,9 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
     }
     if (G == 0 || (li && li->dry)) return PDEGPU_OK;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -459,29 +525,30 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
 
 // a weighted session whose operator applications can march: 3-D, one slab owning every plane, at least one interior node per axis, and either every
 // boundary node Dirichlet (the uniform boundary value; T_left, T_right and T_side all given) or — weights that do not depend on x (cm 2), whose row
-// table holds the truncated rows of the face nodes — both x-faces Dirichlet and the other four faces natural (the cylinder fallback with T_left /
-// T_right: its T_side matches no facet, fenics_mcp_server.py:590-594)
+// tables hold the truncated rows of the face nodes — any of the directional values missing (the cylinder fallback with T_left / T_right, whose T_side
+// matches no facet, fenics_mcp_server.py:590-594; T_left alone; ...)
 bool wmarch_supported(const GridDev& g, int cm) {
     if (g.dim != 3 || g.k0 != 0 || g.nkl != g.NZ || g.flat2d) return false;
     if (g.NX < 3 || g.NY < 3 || g.NZ < 3) return false;
     if ((long long)g.NZ * g.NY >= 0x7fffffffLL) return false;
     if (g.bc_mode == PDEGPU_BC_UNIFORM) return g.bc_present[0] != 0;
-    if (!g.bc_present[0] || !g.bc_present[1]) return false;
-    return g.bc_present[2] != 0 || cm == 2;
+    if (cm == 2) return true;                              // any mix of T_left / T_right / T_side: natural faces come from the row / face tables
+    return g.bc_present[0] && g.bc_present[1] && g.bc_present[2];
 }
 
 // a.ell / a.ell_stride / a.ell_mode (= CM) / a.wdinv describe the coefficients (see the header comment); mode: PLAIN, RESIDUAL, CG_K1
 int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     if (mode != APPLY_PLAIN && mode != APPLY_RESIDUAL && mode != APPLY_CG_K1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weighted marching: PLAIN, RESIDUAL or K1");
     const int ry = ctx->wfast_ry;
-    if (a.ell_mode == 1) return ctx->wfast_ry1 == 2 ? launch_wmarch<1, 2, 8>(ctx, a, mode, li) : launch_wmarch<1, 1, 0>(ctx, a, mode, li);
-    if (ry == 1) return launch_wmarch<2, 1, 0>(ctx, a, mode, li);
-    return launch_wmarch<2, 2, 0>(ctx, a, mode, li);
+    if (a.ell_mode == 1) return ctx->wfast_ry1 == 2 ? launch_wmarch<1, 2, 8, false>(ctx, a, mode, li) : launch_wmarch<1, 1, 0, false>(ctx, a, mode, li);
+    if (a.wface[0] || a.wface[1]) return ry == 1 ? launch_wmarch<2, 1, 0, true>(ctx, a, mode, li) : launch_wmarch<2, 2, 0, true>(ctx, a, mode, li);
+    if (ry == 1) return launch_wmarch<2, 1, 0, false>(ctx, a, mode, li);
+    return launch_wmarch<2, 2, 0, false>(ctx, a, mode, li);
 }
 
 // CM 1: dtab = the diagonal (compact rows of A, interior plane class, weight 0), ditab = its inverse, both [j * PX + i]; CM 2: dtab = the row table of A
-int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, double* scal, double* partials,
-              LaunchInfo* li, const DotIn& di) {
+int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double* q, const double* dtab, const double* ditab, const double* flo,
+              const double* fhi, double* scal, double* partials, LaunchInfo* li, const DotIn& di) {
     int jlo, jhi, klo, khi;
     wmarch_ranges(g, &jlo, &jhi, &klo, &khi);
     const int ny_free = jhi - jlo + 1;
@@ -494,19 +561,20 @@ int wmarch_k2(pdegpu_ctx* ctx, const GridDev& g, int cm, double* r, const double
     // z is read again by the next K1 and q was just written by this iteration's: on grids whose vectors stay in the caches the default policy keeps them there
     int nt = ctx->wfast_k2_nt;
     if (nt < 0) nt = ((long long)g.nkl * g.PP * 8 > (64LL << 20)) ? 1 : 0;
-    if (cm == 1 && nt) hipLaunchKernelGGL((k_wk2<1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
-    else if (cm == 1) hipLaunchKernelGGL((k_wk2<1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
-    else if (nt) hipLaunchKernelGGL((k_wk2<2, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
-    else hipLaunchKernelGGL((k_wk2<2, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, scal, partials, di);
+    if (cm == 1 && nt) hipLaunchKernelGGL((k_wk2<1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, flo, fhi, scal, partials, di);
+    else if (cm == 1) hipLaunchKernelGGL((k_wk2<1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, flo, fhi, scal, partials, di);
+    else if (nt) hipLaunchKernelGGL((k_wk2<2, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, flo, fhi, scal, partials, di);
+    else hipLaunchKernelGGL((k_wk2<2, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, r, q, dtab, ditab, g, nrows, jlo, ny_free, klo, flo, fhi, scal, partials, di);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }
 
-int wmarch_rowtab(pdegpu_ctx* ctx, const GridDev& g, const double* ellA, const double* ellM, long long stride, double* rowA, double* rowM) {
+// cls: the column class the table is made of (1 = interior: the wave-uniform rows; 0 / 2 = the nodes of the x-face 0 / NX-1)
+int wmarch_rowtab(pdegpu_ctx* ctx, const GridDev& g, const double* ellA, const double* ellM, long long stride, double* rowA, double* rowM, int cls) {
     const long long rows = (long long)g.NZ * g.NY;
     long long nb = (rows * 16 + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_wrowtab, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ellA, ellM, stride, rows, rowA, rowM);
+    hipLaunchKernelGGL(k_wrowtab, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ellA, ellM, stride, rows, rowA, rowM, cls);
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
 }

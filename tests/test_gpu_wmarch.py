@@ -67,10 +67,12 @@ def test_marching_weighted_operator_matches_the_assembled_matrix(lib, gpu_ctx, c
 
 
 @pytest.mark.parametrize("ry", [1, 2])
+@pytest.mark.parametrize("faces", [2, 3, 4])
 @pytest.mark.parametrize("case", ["cylinder_fallback", "cylinder_fallback_core", "box_core", "box_core_two_cells"])
-def test_marching_weighted_operator_with_natural_side_faces(lib, gpu_ctx, case, ry):
-    """x-independent weights with only x = 0 / x = Lx constrained (the cylinder tool's T_left / T_right, :582-604): the marching kernels also compute the
-    truncated rows of the nodes on the four natural faces, edges and corners of those faces included == the oracle's assembled matrices"""
+def test_marching_weighted_operator_with_natural_faces(lib, gpu_ctx, case, faces, ry):
+    """x-independent weights with directional conditions (:582-604, :606-623) — faces = 2: x = 0 and x = Lx constrained (the cylinder tool's T_left /
+    T_right), 3: x = 0 alone, 4: x = 0 and the side faces (x = Lx natural; T_side constrains 0 < x < Lx only, so the edges of the face x = Lx stay free):
+    the marching kernels also compute the truncated rows of the nodes on the natural faces, their edges and corners == the oracle's assembled matrices"""
     from pdegpu import _lib as L
     okind, lkind, n, lengths, origin, core_radius, core_ratio = CASES[case]
     coords, cells = o.box_mesh(*lengths, *n)
@@ -81,15 +83,17 @@ def test_marching_weighted_operator_with_natural_side_faces(lib, gpu_ctx, case, 
     A = (cM * M + cK * K).tocsr()
     N = coords.shape[0]
     x = np.random.default_rng(7).uniform(-1.0, 1.0, N)
-    ix = np.arange(N) % (n[0] + 1)
-    free = (ix > 0) & (ix < n[0])
+    if faces == 4 and n[0] <= 2:
+        pytest.skip("T_side constrains nothing with two cells in x (facet rule): the same case as faces = 3")
+    dir_mask = o.box_dirichlet(*n, T_left=1.0, T_right=1.0 if faces == 2 else None, T_side=1.0 if faces == 4 else None)[0]
+    free = ~dir_mask
     ref = np.where(free, A @ x, 0.0)
     grid = L.make_grid(3, n, lengths, L.ELEM_P1SPLIT)
     w = _weight(L, getattr(L, lkind), origin, core_radius, core_ratio)
     y = np.empty(N)
     L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", ry))
     try:
-        L.check(gpu_ctx, lib.pdegpu_heat_apply_weighted(gpu_ctx, grid, w, cM, cK, L.dptr(x), L.dptr(y), 2))
+        L.check(gpu_ctx, lib.pdegpu_heat_apply_weighted(gpu_ctx, grid, w, cM, cK, L.dptr(x), L.dptr(y), faces))
     finally:
         L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_ry", 2))
     assert np.abs(y - ref).max() <= 1e-13 * np.abs(A).dot(np.abs(x)).max()
@@ -112,6 +116,26 @@ def test_cylinder_tool_with_left_and_right_values_marches(lib, gpu_ctx):
     got = heat._solve_heat_3d_raw(rtol=1e-12, **kw)
     assert got.meta["solver_path"] == "weighted-marching"
     assert np.abs(got.values - o.solve_heat_3d(**kw).values).max() <= 1e-9 * 90.0
+
+
+@pytest.mark.parametrize("case", ["cylinder_left_only", "core_left_only_steady", "core_left_and_side"])
+def test_natural_x_face_solves_march_and_match_the_oracle(lib, gpu_ctx, case):
+    from pdegpu import heat
+    if case == "cylinder_left_only":
+        kw = dict(Lx=1.0, nx=9, ny=8, nz=7, diffusivity=1.0, T_boundary=20.0, T_initial=60.0, dt=0.01, num_steps=3, cylinder_radius=0.5, T_left=100.0)
+        ref = o.solve_heat_3d_cylinder_fallback(**kw)
+        got = heat._solve_heat_3d_raw(Ly=1.0, Lz=1.0, geometry_type="cylinder", rtol=1e-12, **kw)
+    else:
+        kw = dict(Lx=1.0, Ly=0.8, Lz=0.9, nx=9, ny=8, nz=10, diffusivity=1.0, T_boundary=20.0, T_initial=70.0, dt=0.005, num_steps=3, core_radius=0.45,
+                  core_diffusivity=35.0, T_left=50.0)
+        if case == "core_left_only_steady":
+            kw.update(steady=True, source_type="constant", source_value=4.0)
+        else:
+            kw.update(T_side=10.0, initial_type="zero")
+        ref = o.solve_heat_3d(**kw)
+        got = heat._solve_heat_3d_raw(rtol=1e-12, **kw)
+    assert got.meta["solver_path"] == "weighted-marching"
+    assert np.abs(got.values - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
 
 
 def test_marching_weighted_apply_refuses_what_it_does_not_cover(lib, gpu_ctx):
