@@ -498,7 +498,10 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
         if (e != hipSuccess || nb < 1) nb = 2;
         occ[mode & 3] = std::min(nb, 8);
     }
-    const int wg = ctx->wfast_wg_per_cu > 0 ? ctx->wfast_wg_per_cu : occ[mode & 3];
+    // HBM-resident vectors: two workgroups per CU — fewer, longer-lived streams move more bytes per second on this memory system (the plain marching
+    // kernels' finding, §4b of docs/history.md; here composite core 320^3 70.2 -> 71.1, 384^3 65.7 -> 73.0, spherical 384^3 61.7 -> 69.8 GDoF/s; 512^3 unchanged)
+    const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
+    const int wg = ctx->wfast_wg_per_cu > 0 ? ctx->wfast_wg_per_cu : (hbm ? std::min(occ[mode & 3], 2) : occ[mode & 3]);
     const WGeom wgm = wmarch_geom(ctx, a.g, RY, wg);
     const int G = (wgm.nwg_xy * wgm.nzc + 7) / 8 * 8;      // a multiple of 8: the XCD-aware order always applies (surplus workgroups idle)
     if (li) { li->grid = G; li->block = 256; }
