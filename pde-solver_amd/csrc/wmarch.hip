@@ -515,6 +515,8 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
         }
     }
     if (G == 0 || (li && li->dry)) return PDEGPU_OK;
+    if (G > stencil_max_partials(ctx))         // one partial per workgroup (rows of more than ~80 000 x 2 tiles: nothing this device holds)
+        return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted marching kernels: %d workgroups exceed the %d partials of a session", G, stencil_max_partials(ctx));
     switch (mode) {
         case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
         case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
