@@ -138,6 +138,29 @@ def test_natural_x_face_solves_march_and_match_the_oracle(lib, gpu_ctx, case):
     assert np.abs(got.values - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
 
 
+@pytest.mark.parametrize("case,faces", [("spherical_two_x_tiles", 1), ("cylinder_fallback_core", 1), ("cylinder_fallback_core", 2), ("box_core", 3), ("box_core", 4)])
+def test_marching_weighted_operator_is_symmetric_positive_on_the_free_nodes(lib, gpu_ctx, case, faces):
+    """what PCG needs of the operator the kernels apply: <A x, y> = <x, A y> and <A x, x> > 0 for vectors that vanish on the constrained nodes —
+    a property of the kernels themselves, no oracle involved (symmetry / SPD property tests)"""
+    from pdegpu import _lib as L
+    okind, lkind, n, lengths, origin, core_radius, core_ratio = CASES[case]
+    N = (n[0] + 1) * (n[1] + 1) * (n[2] + 1)
+    if faces == 1:
+        dir_mask = o.box_dirichlet(*n, T_boundary=0.0)[0]
+    else:
+        dir_mask = o.box_dirichlet(*n, T_left=1.0, T_right=1.0 if faces == 2 else None, T_side=1.0 if faces == 4 else None)[0]
+    rng = np.random.default_rng(11)
+    x, y = (np.where(dir_mask, 0.0, rng.uniform(-1.0, 1.0, N)) for _ in range(2))
+    grid = L.make_grid(3, n, lengths, L.ELEM_P1SPLIT)
+    w = _weight(L, getattr(L, lkind), origin, core_radius, core_ratio)
+    Ax, Ay = np.empty(N), np.empty(N)
+    L.check(gpu_ctx, lib.pdegpu_heat_apply_weighted(gpu_ctx, grid, w, 1.0, 0.05, L.dptr(x), L.dptr(Ax), faces))
+    L.check(gpu_ctx, lib.pdegpu_heat_apply_weighted(gpu_ctx, grid, w, 1.0, 0.05, L.dptr(y), L.dptr(Ay), faces))
+    assert np.all(Ax[dir_mask] == 0.0)
+    assert abs(Ax @ y - x @ Ay) <= 1e-12 * (np.abs(Ax) @ np.abs(y))
+    assert Ax @ x > 0 and Ay @ y > 0
+
+
 def test_marching_weighted_apply_refuses_what_it_does_not_cover(lib, gpu_ctx):
     from pdegpu import _lib as L
     grid = L.make_grid(2, (8, 9), (1.0, math.pi), L.ELEM_P1SPLIT)
