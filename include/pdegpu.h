@@ -170,6 +170,9 @@ const char* pdegpu_version(void);
  * wfast_ry           | 2       | rows per wavefront column of those kernels where the weights are wave-uniform (1|2)
  * wfast_wg_per_cu    | 0       | workgroups per CU their z-chunking aims for (0 = occupancy API)
  * wfast_k2_mult      | 4       | workgroups per CU of their K2 (a wavefront per grid row)
+ * wfast_ex           | -1      | those kernels hand tile-edge x-neighbours between the workgroup's waves through LDS (0 = 2-lane global loads;
+ *                    |         | -1 = per-lane weights always, wave-uniform weights on cache-resident grids: where it measured faster)
+ * wfast_nt           | -1      | non-temporal stores of q / p / x (and loads of x) in those marching kernels: 1|0, -1 = where one vector exceeds 64 MiB
  * wfast_k2_nt        | -1      | non-temporal loads / stores in that K2: 1|0, -1 = where one vector exceeds 64 MiB
  * ell_compact        | 1       | weighted (curvilinear / composite) 3-D operators whose weight does not depend on one coordinate store the coefficient
  *                    |         | rows of three representative planes / columns instead of one row per node (0 = one row per node)

@@ -45,6 +45,9 @@ struct pdegpu_ctx {
     int wfast_ry = 2;           // rows per wavefront column of the weighted marching kernels whose weights are wave-uniform (1 | 2; 192^3 composite core 53.7 -> 62.3 GDoF/s
                                 // with 2); per-lane weights: always 1 (the 30 weights of a row pair leave no registers for a second row)
     int wfast_ry1 = 2;          // ... and where they are per-lane (r^2 sin(theta)): 2 = two rows, 8 of a node pair's 15 weights in LDS; 1 = one row, all in registers
+    int wfast_ex = -1;          // their marching kernels: 1 = tile-edge x-neighbours handed between the workgroup's waves through LDS instead of 2-lane global loads;
+                                // -1 = where measured faster (per-lane weights: always; wave-uniform weights: cache-resident grids)
+    int wfast_nt = -1;          // their marching kernels: non-temporal stores of q / p / x and loads of x: 1 | 0; -1 = where one vector exceeds 64 MiB
     int wfast_k2_nt = -1;       // K2 of those sessions: non-temporal loads / stores 1 | 0; -1 = where one vector exceeds 64 MiB
     int wfast_k2_mult = 4;      // K2 of those sessions: workgroups per CU (a wavefront per grid row; 192^3 composite core: 57 -> 60 GDoF/s from 2 to 4)
     int wfast_wg_per_cu = 0;    // workgroups per CU their z-chunking aims for; 0 = what the occupancy API reports

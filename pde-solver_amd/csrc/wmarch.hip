@@ -52,6 +52,27 @@ __device__ __forceinline__ double dpp_from_upper(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// non-temporal 16-byte accesses (a compile-time choice: behind a runtime switch the compiler merges the two forms and drops the hint)
+typedef double wm_d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 wm_ld(const double* p) {
+    if constexpr (NT) {
+        const wm_d2 v = __builtin_nontemporal_load(reinterpret_cast<const wm_d2*>(p));
+        return make_double2(v.x, v.y);
+    } else {
+        return *reinterpret_cast<const double2*>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void wm_st(double* p, const double2& v) {
+    if constexpr (NT) {
+        const wm_d2 t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<wm_d2*>(p));
+    } else {
+        *reinterpret_cast<double2*>(p) = v;
+    }
+}
+
 struct WGeom {
     int ntx, nty;        // 128-node x-tiles, RY-row y-tiles of the free rows jlo .. jhi
     int nwg_xy;          // workgroups per z-chunk (four consecutive tiles of the row-major tile order each)
@@ -70,8 +91,13 @@ struct WRow { double l, x, y, r; };
 // those of the column class "face" (truncated cells), not the wave-uniform ones: every lane reads the 128-byte line of ITS face table (lanes without a
 // face node: any line, unused) beside the scalar line of the row, the stencil of the two nodes is formed a second time with it, and the face lanes
 // keep that second result.  A template flag: sessions without a natural x-face run the instantiation without those loads.
-template <int CM, int RY, int MODE, int LQ, bool FX>
+// NT: non-temporal stores of q / p / x (and loads of x, which nothing reads again before the next iteration) on HBM-resident grids, as in k_fast.
+// EX: the tile-edge x-neighbours (node i0-1 of lane 0, node i0+2 of lane 63) are handed between the x-adjacent wavefronts of the workgroup through LDS
+// (one barrier per plane; the four waves of a workgroup march in lockstep anyway) instead of 2-lane global loads — 2 (RY + 2) of them per plane and
+// vector, more load instructions than the wide ones; only a wave whose neighbour tile belongs to another workgroup still loads its edge from memory.
+template <int CM, int RY, int MODE, int LQ, bool FX, bool NT, bool EX>
 __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
+    __shared__ double sEdge[EX ? 2 : 1][4][RY + 2][2];
     static_assert(!FX || CM == 2, "natural x-faces: weights independent of x only");
     __shared__ double sRed[4];
     __shared__ double2 sC[LQ > 0 ? 4 : 1][LQ > 0 ? RY : 1][LQ > 0 ? LQ : 1][LQ > 0 ? 64 : 1];
@@ -94,14 +120,18 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     const int jmax = wgm.jhi;
     const int lk0 = wgm.klo + zc * wgm.zlen;
     const int lk1 = min(lk0 + wgm.zlen, wgm.khi + 1);
-    const bool active = yt < wgm.nty && zc < wgm.nzc && lk0 < lk1;          // wave-uniform
+    const bool wg_active = zc < wgm.nzc && lk0 < lk1;                       // workgroup-uniform
+    const bool wave_active = wg_active && yt < wgm.nty;                     // wave-uniform
+    // EX: every wave of a workgroup with work runs the march (an inactive one with its loads at offset 0 and its stores masked) so that the barriers match
+    const bool active = EX ? wg_active : wave_active;
+    int estep = 0;                                                          // edge hand-off counter (the same in every wave of the workgroup)
 
     double alpha_prev = 0.0, beta = 0.0;
     if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);          // (every thread of every workgroup: the prologue sum has barriers)
     double acc = 0.0;
     if (active) {
         const double shift = a.in_shift;
-        const bool lane_ok = i0 < g.PX;
+        const bool lane_ok = wave_active && i0 < g.PX;
         const bool ma = (i0 >= wgm.xlo) && (i0 <= wgm.xhi);                 // node a = i0 is a free node
         const bool mb = (i0 + 1 <= wgm.xhi);                                // node b = i0 + 1
         // FX: which of the lane's two nodes sits on a natural x-face, and the face table of that node (0: x = 0, 1: x = NX-1)
@@ -110,7 +140,10 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
         const bool face_a = fa_lo || fa_hi, face_b = fb_hi;
         // (lanes without a face node read a line of whichever face table exists and never use it; only one of the two may be allocated)
         const double* ftab = (fa_hi || fb_hi || !a.wface[0]) ? a.wface[1] : a.wface[0];
-        const bool elane = (lane == 0 && i0 >= 1) || (lane == 63 && i0 + 2 < g.PX);
+        // the x-neighbour tile of this wave inside the workgroup (waves are consecutive tiles of the row-major tile order)
+        const bool has_l = EX && wv > 0 && xt > 0, has_r = EX && wv < 3 && xt + 1 < wgm.ntx;
+        const bool elane = wave_active && ((lane == 0 && i0 >= 1 && !has_l) || (lane == 63 && i0 + 2 < g.PX && !has_r));      // edge from global memory
+        const bool need_ge = !EX || __builtin_amdgcn_readfirstlane((int)((xt > 0 && !has_l) || (xt * 128 + 128 < g.PX && !has_r))) != 0;
         const long long eoff = (lane == 0) ? -1 : 2;
         // (natural y / z faces: the rows -1 / NY and the planes -1 / NZ a face row asks for do not exist — they meet weights that are exactly 0: the row
         // reads offset 0 of the vector, the ghost planes are zero)
@@ -160,46 +193,66 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                 const long long off = (rok && lane_ok) ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0;
                 const long long offe = (rok && elane) ? (long long)lk * g.PP + (long long)j * g.PX + i0 + eoff : 0;
                 vin[r] = load2(a.in, off);
-                ein[r] = a.in[offe];
+                ein[r] = 0.0;
+                ep[r] = 0.0;
+                if (need_ge) ein[r] = a.in[offe];                 // (wave-uniform branch)
                 if (K1) {
                     vp[r] = load2(a.p_old, off);
-                    ep[r] = a.p_old[offe];
+                    if (need_ge) ep[r] = a.p_old[offe];
                 }
+            }
+            double2 vals[RH];
+            double eg[RH];
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                if (K1) {
+                    vals[r].x = vin[r].x + beta * vp[r].x;
+                    vals[r].y = vin[r].y + beta * vp[r].y;
+                    eg[r] = ein[r] + beta * ep[r];
+                    if (po_out) po_out[r] = vp[r];
+                } else {
+                    vals[r].x = vin[r].x + shift;
+                    vals[r].y = vin[r].y + shift;
+                    eg[r] = ein[r] + shift;
+                }
+            }
+            const int buf = estep & 1;
+            if (EX) {
+                ++estep;
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    if (lane == 0) sEdge[buf][wv][r][0] = vals[r].x;
+                    if (lane == 63) sEdge[buf][wv][r][1] = vals[r].y;
+                }
+                __syncthreads();
             }
 #pragma unroll
             for (int r = 0; r < RH; ++r) {
-                double2 val;
-                double e;
-                if (K1) {
-                    val.x = vin[r].x + beta * vp[r].x;
-                    val.y = vin[r].y + beta * vp[r].y;
-                    e = ein[r] + beta * ep[r];
-                    if (po_out) po_out[r] = vp[r];
-                } else {
-                    val.x = vin[r].x + shift;
-                    val.y = vin[r].y + shift;
-                    e = ein[r] + shift;
+                double e = eg[r];
+                if (EX) {
+                    if (lane == 0 && has_l) e = sEdge[buf][wv - 1][r][1];
+                    if (lane == 63 && has_r) e = sEdge[buf][wv + 1][r][0];
                 }
-                const double lv = dpp_from_lower(val.y), rv = dpp_from_upper(val.x);
-                rows[r].x = val.x;
-                rows[r].y = val.y;
+                const double lv = dpp_from_lower(vals[r].y), rv = dpp_from_upper(vals[r].x);
+                rows[r].x = vals[r].x;
+                rows[r].y = vals[r].y;
                 rows[r].l = (lane == 0) ? e : lv;
                 rows[r].r = (lane == 63) ? e : rv;
             }
         };
         auto own_xload = [&](int lk, int j) {
             const bool ok = j <= jmax && lane_ok;
-            return load2(a.x, ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0);
+            return wm_ld<NT>(a.x + (ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0));
         };
         // K1: store p_n and x += alpha_{n-1} p_{n-1} of an owned row (every node of the row pair: Dirichlet nodes and pads hold p = 0, r = 0)
         auto own_update = [&](int lk, int j, const WRow& pn, const double2& po, double2 xv) {
             if (K1 && j <= jmax && lane_ok) {
                 const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
-                *reinterpret_cast<double2*>(a.p_new + off) = make_double2(pn.x, pn.y);
+                wm_st<NT>(a.p_new + off, make_double2(pn.x, pn.y));
                 if (alpha_prev != 0.0) {
                     xv.x += alpha_prev * po.x;
                     xv.y += alpha_prev * po.y;
-                    *reinterpret_cast<double2*>(a.x + off) = xv;
+                    wm_st<NT>(a.x + off, xv);
                 }
             }
         };
@@ -315,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                     o.y = frb ? qb : 0.0;
                     acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
                 }
-                if (lane_ok && jok) *reinterpret_cast<double2*>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0) = o;
+                if (lane_ok && jok) wm_st<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
             }
             if (K1 && lk + 1 < lk1) {
 #pragma unroll
@@ -484,16 +537,16 @@ WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu
     return w;
 }
 
-template <int CM, int RY, int LQ, bool FX>
-int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+template <int CM, int RY, int LQ, bool FX, bool NT, bool EX>
+int launch_wmarch_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
     static int occ[4] = {0, 0, 0, 0};
     if (occ[mode & 3] == 0) {
         int nb = 0;
         hipError_t e;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX, NT, EX>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX, NT, EX>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX, NT, EX>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
         occ[mode & 3] = std::min(nb, 8);
@@ -518,12 +571,27 @@ int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* l
     if (G > stencil_max_partials(ctx))         // one partial per workgroup (rows of more than ~80 000 x 2 tiles: nothing this device holds)
         return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted marching kernels: %d workgroups exceed the %d partials of a session", G, stencil_max_partials(ctx));
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
+}
+
+// non-temporal hints where one vector of the session exceeds 64 MiB (wfast_nt: -1 auto, 0 never, 1 always)
+template <int CM, int RY, int LQ, bool FX>
+int launch_wmarch(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
+    int nt = ctx->wfast_nt;
+    if (nt < 0) nt = ((long long)a.g.nkl * a.g.PP * 8 > (64LL << 20)) ? 1 : 0;
+    // edge hand-off through LDS (wfast_ex: -1 auto, 0 off, 1 on).  Measured by kernel time, alternating processes on one box (K1, 193^3 / 257^3 / 385^3 / 513^3
+    // nodes): per-lane weights 88.6 -> 80.5, 171 -> 162, 592 -> 572, 1283 -> 1172 us with it; wave-uniform weights 68.7 -> 66.3 us at 193^3 but 162 -> 165,
+    // 568 -> 600, 1236 -> 1265 us on the HBM-resident grids (the barrier takes the four waves' freedom to run ahead of each other, which that form —
+    // three waves per SIMD, scalar loads per plane step — uses): on for the former always, for the latter on cache-resident grids only
+    int ex = ctx->wfast_ex;
+    if (ex < 0) ex = (CM == 1 || (long long)a.g.nkl * a.g.PP * 8 <= (64LL << 20)) ? 1 : 0;
+    if (ex) return nt ? launch_wmarch_nt<CM, RY, LQ, FX, true, true>(ctx, a, mode, li) : launch_wmarch_nt<CM, RY, LQ, FX, false, true>(ctx, a, mode, li);
+    return nt ? launch_wmarch_nt<CM, RY, LQ, FX, true, false>(ctx, a, mode, li) : launch_wmarch_nt<CM, RY, LQ, FX, false, false>(ctx, a, mode, li);
 }
 
 }  // namespace
