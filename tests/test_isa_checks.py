@@ -50,3 +50,26 @@ def test_the_scanner_sees_the_pattern(tmp_path):
                    "\ts_or_b64 exec, exec, s[14:15]\n\tv_add_f64 v[0:1], v[0:1], v[2:3]\n\tv_mov_b32_dpp v1, v2 wave_shr:1 row_mask:0xf bank_mask:0xf\n")
     hits = masked_dpp(bad)
     assert len(hits) == 1 and hits[0][0] == "_Zk" and "v190" in hits[0][2]
+
+
+def test_wave_uniform_weights_arrive_by_scalar_loads():
+    """csrc/wmarch.hip, weights that do not depend on x: the 128-byte line of a grid row must reach the kernel through the scalar cache
+    (`s_load_dwordx16` + x8 + x4 + x2 into SGPRs, constant address space) — as vector loads of a uniform address it would cost the 15 load
+    instructions per node pair the class-table kernel paid; and the kernels with per-lane weights must not spill"""
+    f = BUILD / "wmarch-hip-amdgcn-amd-amdhsa-gfx950.s"
+    if not f.exists():
+        pytest.skip("no device assembly of wmarch.hip in pde-solver_amd/build")
+    text = f.read_text(errors="replace")
+    bodies = dict(re.findall(r"^(_ZN\S*k_wmarchILi(?:1|2)\S*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M))
+    cm2 = {k: v for k, v in bodies.items() if "k_wmarchILi2E" in k}
+    assert len(cm2) >= 6
+    for name, body in cm2.items():
+        assert "s_load_dwordx16" in body, name
+    # launch bounds (256, 2) leave 256 VGPRs: none of the instantiations the library launches by default may use scratch
+    for m in re.finditer(r"\.amdhsa_kernel (\S*k_wmarch\S*)(.*?)\.end_amdhsa_kernel", text, re.S):
+        name, meta = m.group(1), m.group(2)
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta).group(1))
+        edge_handoff = name.endswith("Lb1EEEv11StencilArgsNS_5WGeomE")
+        per_lane_two_rows = "k_wmarchILi1ELi2E" in name
+        if not per_lane_two_rows or edge_handoff:      # (per-lane weights, two rows, WITHOUT the LDS edge hand-off: 5 dwords of spill, not a default)
+            assert scratch == 0, (name, scratch)
