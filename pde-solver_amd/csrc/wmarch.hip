@@ -266,17 +266,23 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
             for (int r = 1; r <= RY; ++r) own_update(lk0, j0 - 1 + r, C[r], PO[r], own_xload(lk0, j0 - 1 + r));
         }
 
-        for (int lk = lk0; lk < lk1; ++lk) {
-            // CM 2: the 128-byte line of every own row of this plane (15 weights + D^-1), requested before the plane's vector loads
-            double CS[CM == 2 ? RY : 1][16];
+        // CM 2: the 128-byte line of every own row of a plane (15 weights + D^-1), requested a whole plane step AHEAD: at the end of the step before, behind
+        // the stencil that consumed the previous lines.  (Scalar loads and LDS share one counter — lgkmcnt, and scalar loads return out of order, so any
+        // wait with one outstanding is a wait for all — hence not at the top of the step in front of the edge hand-off's LDS traffic.  Measured: no
+        // difference either way, 572-584 us against 568-595 us at 385^3; the hand-off stays slower for this form on HBM-resident grids, see launch_wmarch.)
+        double CS[CM == 2 ? RY : 1][16];
+        auto load_lines = [&](int lk) {
             if (CM == 2) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
-                    const long long e = ((long long)lk * g.NY + min(j0 + r, jmax)) * 16;
+                    const long long e = ((long long)min(lk, wgm.khi) * g.NY + min(j0 + r, jmax)) * 16;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) CS[r][q] = tab[e + q];
                 }
             }
+        };
+        load_lines(lk0);
+        for (int lk = lk0; lk < lk1; ++lk) {
             double2 CF[FX ? RY : 1][8];             // FX: the face line of every own row (per-lane address)
             if (FX) {
 #pragma unroll
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                 P[r] = C[r];
                 C[r] = N[r];
             }
+            load_lines(lk + 1);
         }
     }
     const double tot = block_sum_256(acc, sRed);
