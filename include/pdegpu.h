@@ -183,6 +183,9 @@ const char* pdegpu_version(void);
  * el_fast_yzface     | 3       | bit 0: y-face rows, bit 1: the planes 0 / NZ-1 as well (the class-table pass keeps the box edges)
  * el_fast_nt         | -1      | non-temporal stores of the output: 1|0, -1 = where the vectors are HBM-resident
  * el_fast_waves      | 0       | wavefront target of the marching part; 0 = 4096, 8192 on HBM-resident grids
+ * el_bnd_gran        | 64      | boundary nodes a boundary workgroup of the marching apply takes per pass where only edges and corners are left to them (64|256)
+ * el_fast_fit        | 1       | a launch between one and two resident rounds of workgroups is cut into as many z-chunks as fill ONE round, of two
+ *                    |         | lengths (config 5: 19 chunks of 4 / 3 planes = 766 workgroups on 768 slots instead of 21 x 3 = 846; 0 = equal chunks)
  * el_cg_variant      | 1       | PCG recurrences: 1 = single-reduction form (the r- and p-updates fused into ONE pass of 7 vector reads /
  *                    |         | writes, one scalar reduction per iteration; same iteration counts), 0 = classic (p-update, apply, K2)
  * el_split_min_mb    | 32      | slab loop: k1 is split around the halo exchange where one vector of the slab holds at least this many
@@ -268,6 +271,8 @@ int pdegpu_heat_tables_host(const pdegpu_grid* grid, double* tabK, double* tabM,
  *      disp_out  [N][dim] nullable. */
 int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el,
                             double* field_out, double* disp_out, pdegpu_stats* stats);
+/* y = K u on the full grid (parity tests).  use_mfma: 0 = vector block stencil, every row of the operator; 1 = element-by-element MFMA (3-D);
+ * 2 = the launch the PCG loop issues: as 0, but the rows of the clamped face x = 0 give 0 */
 int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity* el,
                             const double* u, double* y, int use_mfma);
 /* average device time (ms) of `reps` applications of the elasticity operator: use_mfma = 0 vector block stencil,

@@ -274,18 +274,22 @@ __device__ __forceinline__ ElW36 el_expand_weights(const ElW18& k) {
 constexpr int kElXt = 62;
 struct ElFastGeom {
     int ntx, nty, nzc, zlen;   // 62-node x-tiles, RY-row y-tiles, z-chunks of zlen planes
+    int nlong, z0;             // the z-chunks z0 .. z0+nlong-1 of the first range have zlen planes, the others zlen - 1 (z0 = 0, nlong = nzc1: all of one
+                               // length; z0 = 1 keeps the chunk that also computes the plane 0 short, like the last one with the plane NZ-1)
     int nyg;                   // groups of 4 y-tiles (one workgroup each) of the y-hand-off variant
     int lkb, lke;              // local interior plane range [lkb, lke)
     int lkb2, lke2, nzc1;      // plane-range launches of the slab loop: a second, disjoint range [lkb2, lke2) = the z-chunks nzc1 .. nzc-1 (the two edge
                                // planes of a slab in ONE launch); nzc1 = nzc and an empty range otherwise
     int nb_fast;               // workgroups of the marching part (4 waves each); they FOLLOW the nb_bnd boundary workgroups
     int nb_bnd;                // boundary workgroups
+    int bnd_gran;              // nodes a boundary workgroup takes per pass (256 | 64)
     int bnd_last;              // 1: they take the LAST block indices
     int full_lo, full_hi;      // 1: this slab owns the global plane 0 / NZ-1 (all of its nodes are boundary nodes)
     int ring;                  // boundary nodes of an interior plane: 2 NX + 2 (NY - 2)
     long long nbnd;            // boundary nodes of the slab
     const unsigned* mask;      // [27] nonzero-block masks of the class table
     const double* gf;          // [3][3][3] face remainder vectors g (see ElW36::faces)
+    unsigned long long* trace; // tuning aid (PDEGPU_EL_TRACE_FILE, pdegpu_elasticity_time_apply): per workgroup {start, end} of the 100 MHz clock + XCD / CU ids
 };
 
 __device__ __forceinline__ double el_dpp_lower(double v) {     // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1)
@@ -380,7 +384,9 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
     for (int e = threadIdx.x; e < 27 * PG_NOFF15 * 9; e += 256) sTab[e] = a.tab[e];
     if (threadIdx.x < 27) sMask[threadIdx.x] = fg.mask[threadIdx.x];
     __syncthreads();
-    for (long long e0 = (long long)bidx * 256 + threadIdx.x; e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * 256) {
+    // (fg.bnd_gran nodes per workgroup and pass: 256, or 64 — one wavefront's worth — where the nodes are few: every thread's 48 loads go to 48 different
+    // cache lines, and 256 such threads on ONE CU made the last boundary workgroup the longest-lived of config 5's launch, 18 us)
+    for (long long e0 = (long long)bidx * fg.bnd_gran + threadIdx.x; threadIdx.x < fg.bnd_gran && e0 < fg.nbnd; e0 += (long long)fg.nb_bnd * fg.bnd_gran) {
         unsigned e = (unsigned)e0;                        // 32-bit divisions (nbnd < 2^31 is checked on the host)
         int i, j, lk;
         const unsigned plane_nodes = (unsigned)g.NX * (unsigned)g.NY;
@@ -470,6 +476,8 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
 template <int RY, bool YX, bool ZF, bool NTS>
 __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, ElW18 wk, ElFastGeom fg) {
     const ElW36 w = el_expand_weights(wk);
+    unsigned long long t_start = 0;
+    if (fg.trace) t_start = wall_clock64();
     __shared__ double sTab[27 * PG_NOFF15 * 9];
     __shared__ unsigned sMask[27];
     __shared__ double sRed[8];
@@ -513,8 +521,8 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
         const int i = xt * kElXt + lane;                         // lanes 0 and 63: x-halo only (lane 0 of the first tile: the face x = 0)
         const int j0 = 1 + yt * RY;                           // first owned row; held rows j0-1 .. j0+RY
         const bool range2 = zc >= fg.nzc1;
-        const int lk0 = range2 ? fg.lkb2 + (zc - fg.nzc1) * fg.zlen : fg.lkb + zc * fg.zlen;
-        const int lk1 = min(lk0 + fg.zlen, range2 ? fg.lke2 : fg.lke);
+        const int lk0 = range2 ? fg.lkb2 + (zc - fg.nzc1) * fg.zlen : fg.lkb + zc * (fg.zlen - 1) + min(max(zc - fg.z0, 0), fg.nlong);
+        const int lk1 = min(lk0 + ((range2 || (zc >= fg.z0 && zc < fg.z0 + fg.nlong)) ? fg.zlen : fg.zlen - 1), range2 ? fg.lke2 : fg.lke);
         if (zc >= 0 && lk0 < lk1) {
             // Loads are unconditional (branch-free, all of a plane in flight at once): every address a wave can form lies
             // inside the allocation — rows up to NY (= first row of the next plane), columns up to NX+60 < PX+64, planes
@@ -775,6 +783,12 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
     if (qmq) {
         const double t2 = block_sum_256(acc2, sRed);
         if (threadIdx.x == 0) a.partials_qmq[blockIdx.x] = t2;
+    }
+    if (fg.trace && threadIdx.x == 0) {
+        fg.trace[3 * blockIdx.x] = t_start;
+        fg.trace[3 * blockIdx.x + 1] = wall_clock64();
+        // HW_REG_XCC_ID (id 20) bits [3:0]; HW_REG_HW_ID (id 4): CU id bits [11:8], SH [12], SE [15:13]
+        fg.trace[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((15 << 11) | 4);
     }
 }
 
@@ -1538,6 +1552,7 @@ bool el_vec_nt(const ElSession* s);
 // Launch geometry of the marching apply over the local planes [a, b) (and, in the same launch, [a2, b2): the two edge planes of a slab with
 // neighbours); the whole slab is (0, nkl).  A range takes the slab's global end plane (z-face: every node a boundary node) along when it
 // contains it.
+int el_fast_wg_per_cu(const ElSession* s);
 void el_fast_geometry_range(const ElSession* s, int a, int b, int a2, int b2, ElFastGeom* out) {
     const GridDev& g = s->g;
     ElFastGeom& fg = *out;
@@ -1575,15 +1590,60 @@ void el_fast_geometry_range(const ElSession* s, int a, int b, int a2, int b2, El
         fg.nbnd = (long long)(fg.full_lo + fg.full_hi) * per + 4LL * (planes + planes2);
     }
     fg.nb_bnd = (int)std::min<long long>((fg.nbnd + 255) / 256, 2LL * s->ctx->num_cu);      // grid-stride: the 29 KB table is loaded per workgroup
+    fg.bnd_gran = 256;
+    if (s->ctx->el_bnd_gran == 64 && fg.nbnd <= 64LL * s->ctx->num_cu / 4) {                // few boundary nodes (edges and corners only): a wavefront's worth each
+        fg.bnd_gran = 64;
+        fg.nb_bnd = (int)((fg.nbnd + 63) / 64);
+    }
+    fg.nlong = fg.nzc1;
+    fg.z0 = 0;
+    // A launch between one and two resident rounds is refitted to ONE (el_fast_fit): as many z-chunks as fill the slots, of two lengths (zlen and
+    // zlen - 1).  What the per-workgroup timeline shows at config 5 (tools/el_trace.py, profiles/r04_el_apply_timelines.log): every workgroup lives
+    // 7 us + 1 us per plane whatever the chunk length, all 768 resident ones start inside the first microsecond, and the 78 of the 846 that do not
+    // fit wait for a slot until t = 8-11 us — the kernel lasts two workgroup lifetimes for 9 % more work than fits one.
+    if (s->ctx->el_fast_fit && yx && planes > 0 && planes2 == 0 && s->ctx->el_fast_waves <= 0) {
+        const long long wgc = cols / 4, slots = (long long)el_fast_wg_per_cu(s) * s->ctx->num_cu;
+        const long long nb_default = (wgc * fg.nzc1 + 7) / 8 * 8 + fg.nb_bnd;
+        if (nb_default > slots && nb_default < 2 * slots) {
+            long long nfit = (slots - fg.nb_bnd) / wgc;
+            while (nfit >= 1 && (wgc * nfit + 7) / 8 * 8 + fg.nb_bnd > slots) --nfit;
+            if (nfit >= 1 && nfit <= planes) {
+                fg.zlen = (int)((planes + nfit - 1) / nfit);
+                fg.nzc1 = fg.nzc = (int)nfit;
+                fg.nlong = fg.zlen > 1 ? (int)(planes - nfit * (fg.zlen - 1)) : (int)nfit;
+                // the first and the last chunk also compute the planes 0 / NZ-1 where the z-faces are inside the marching part: the short ones
+                fg.z0 = (fg.nlong + 2 <= nfit) ? 1 : 0;
+                fg.nb_fast = (int)((wgc * nfit + 7) / 8 * 8);
+            }
+        }
+    }
     fg.bnd_last = s->ctx->el_bnd_last != 0 ? 1 : 0;
     fg.mask = s->d_mask;
     fg.gf = reinterpret_cast<const double*>(s->d_mask + 32);
+    fg.trace = nullptr;
 }
 void el_fast_geometry(ElSession* s) { el_fast_geometry_range(s, 0, s->g.nkl, 0, 0, &s->fgeom); }
 
 // non-temporal hints where the vectors are HBM-resident (one component set beyond 64 MiB, the heat kernels' threshold); el_fast_nt = 0 | 1 forces
 bool el_vec_nt(const ElSession* s) {
     return s->ctx->el_fast_nt < 0 ? (long long)s->stride * 3 * 8 > (64LL << 20) : (s->ctx->el_fast_nt & 1) != 0;
+}
+
+// workgroups of the marching apply a CU holds at once (the 2-row y-hand-off instantiations; without a device — host-only callers — the 3 of its launch bounds)
+int el_fast_wg_per_cu(const ElSession* s) {
+    static int occ[2] = {0, 0};
+    const int zf = (s->w36.faces & 4) ? 1 : 0;
+    if (occ[zf] == 0) {
+        int nb = 0;
+        const hipError_t e = zf ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_el_fast<2, true, true, false>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_el_fast<2, true, false, false>, 256, 0);
+        if (e != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 3;
+        }
+        occ[zf] = nb;
+    }
+    return occ[zf];
 }
 
 // fgr != nullptr: a plane-range launch of the marching apply (el_fast_geometry_range)
@@ -1934,7 +1994,7 @@ int el_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_elasticity*
     if (s->fast) {
         el_fast_geometry(s);
         if (s->fgeom.nbnd > 0x7fffffffLL) s->fast = false;
-        npart = std::max(npart, (size_t)s->fgeom.nb_fast + (size_t)((s->fgeom.nbnd + 255) / 256));
+        npart = std::max(npart, (size_t)s->fgeom.nb_fast + (size_t)std::max<long long>((s->fgeom.nbnd + 255) / 256, s->fgeom.nb_bnd));
         // a split K1 (slab with neighbours) appends the partials of its two launches
         const int lo = s->g.k0 > 0 ? 1 : 0, hi = (s->g.k0 + s->g.nkl < s->g.NZ) ? 1 : 0;
         if ((lo || hi) && s->g.nkl >= 4) {
@@ -2212,7 +2272,8 @@ extern "C" int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid,
     if (!el || !u || !y) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "null argument");
     PG_TRY(validate_grid(ctx, grid));
     if (grid->dim < 2) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "block operator exists for dim 2 and 3");
-    if (use_mfma && grid->dim != 3) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "the MFMA element-by-element apply is 3-D only");
+    if (use_mfma == 1 && grid->dim != 3) return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "the MFMA element-by-element apply is 3-D only");
+    if (use_mfma < 0 || use_mfma > 2) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "form: 0 vector block stencil, 1 MFMA, 2 the PCG loop's masked launch");
     PG_HIP(ctx, hipSetDevice(ctx->device));
     ElSession s;
     PG_TRY(el_create(ctx, grid, el, &s));
@@ -2229,7 +2290,7 @@ extern "C" int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid,
         if (rc == PDEGPU_OK) rc = vec_unpack(ctx, s.g, d_dense, s.x + (long long)c * s.stride);
         if (rc == PDEGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "sync failed");
     }
-    if (rc == PDEGPU_OK && use_mfma) {
+    if (rc == PDEGPU_OK && use_mfma == 1) {
         double* d_Ke = nullptr;
         rc = upload_macro_element(&s, grid, &d_Ke);
         if (rc == PDEGPU_OK) rc = el_apply_mfma(&s, s.x, s.q, d_Ke);
@@ -2239,7 +2300,7 @@ extern "C" int pdegpu_elasticity_apply(pdegpu_ctx* ctx, const pdegpu_grid* grid,
         ElArgs a = s.args();
         a.in = s.x;
         a.out = s.q;
-        a.mask_dirichlet = 0;
+        a.mask_dirichlet = use_mfma == 2 ? 1 : 0;      // 2: the launch of the PCG loop — rows of the clamped face give 0
         rc = el_apply(&s, a, APPLY_PLAIN);
     }
     for (int c = 0; c < D && rc == PDEGPU_OK; ++c) {
@@ -2300,6 +2361,34 @@ extern "C" int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* 
     (void)hipEventDestroy(e1);
     if (d_Ke) (void)hipFree(d_Ke);
     *avg_ms_out = ms / reps;
+    // tuning aid: one more launch of the marching apply with per-workgroup timestamps, written as text to $PDEGPU_EL_TRACE_FILE
+    // (block, start, end in 10-ns ticks from the earliest start, XCD, HW_ID; tools/el_trace.py)
+    const char* tf = getenv("PDEGPU_EL_TRACE_FILE");
+    if (rc == PDEGPU_OK && tf && *tf && !use_mfma && s.fast && ctx->el_fast) {
+        const ElFastGeom& fgs = s.fgeom;
+        const int nb = fgs.nb_fast + fgs.nb_bnd;
+        unsigned long long* d_tr = nullptr;
+        if (hipMalloc(&d_tr, (size_t)nb * 3 * sizeof(unsigned long long)) == hipSuccess) {
+            ElFastGeom fgt = fgs;
+            fgt.trace = d_tr;
+            a.partials_qmq = s.part4;
+            rc = el_apply(&s, a, APPLY_PLAIN, &fgt);
+            std::vector<unsigned long long> h((size_t)nb * 3);
+            if (rc == PDEGPU_OK && hipMemcpyAsync(h.data(), d_tr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess) {
+                unsigned long long t0 = ~0ULL;
+                for (int b = 0; b < nb; ++b) t0 = std::min(t0, h[3 * b]);
+                if (FILE* f = fopen(tf, "w")) {
+                    fprintf(f, "# nb_fast %d nb_bnd %d bnd_last %d ntx %d nty %d nyg %d nzc %d zlen %d nlong %d z0 %d\n", fgs.nb_fast, fgs.nb_bnd, fgs.bnd_last, fgs.ntx,
+                            fgs.nty, fgs.nyg, fgs.nzc, fgs.zlen, fgs.nlong, fgs.z0);
+                    for (int b = 0; b < nb; ++b)
+                        fprintf(f, "%d %llu %llu %llu %llu\n", b, h[3 * b] - t0, h[3 * b + 1] - t0, h[3 * b + 2] >> 32, h[3 * b + 2] & 0xffffffffULL);
+                    fclose(f);
+                }
+            }
+            (void)hipFree(d_tr);
+        }
+    }
     return rc;
 }
 

@@ -69,6 +69,52 @@ def test_fast_block_apply_variants_match_assembled_matrix(lib, gpu_ctx, n, Ls):
     assert np.array_equal(outs[(1, 1, 2048, 1)], outs[(1, 1, 2048, 0)]) and np.array_equal(outs[(1, 2, 2048, 1)], outs[(1, 2, 2048, 0)])
 
 
+@pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((64, 3, 3), (2.0, 0.3, 0.2)), ((130, 5, 3), (1.0, 0.2, 0.1)), ((2, 2, 2), (1.0, 1.0, 1.0)),
+                                  ((20, 11, 8), (1.0, 0.5, 0.4)), ((62, 14, 17), (1.0, 0.2, 0.3))])
+def test_masked_launch_of_the_pcg_loop_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
+    """form 2 of pdegpu_elasticity_apply is the launch the PCG loop issues: the rows of the assembled matrix, zero on the clamped face"""
+    from pdegpu import _lib
+    E, nu = 210e9, 0.3
+    lam, mu = o.lame(E, nu)
+    c, cells = o.box_mesh(*Ls, *n)
+    K = o.assemble_elasticity(c, cells, lam, mu)
+    u = np.random.default_rng(12).uniform(-1, 1, (c.shape[0], 3))
+    ref = (K @ u.ravel()).reshape(-1, 3)
+    ref[c[:, 0] < 1e-12] = 0.0
+    el = _lib.Elasticity()
+    el.E, el.nu = E, nu
+    y = np.full_like(u, np.nan)
+    _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, _lib.make_grid(3, n, Ls), el, _lib.dptr(u), _lib.dptr(y), 2))
+    assert rel_err(y, ref) < 1e-12
+
+
+@pytest.mark.parametrize("n", [(256, 64, 64), (250, 60, 44), (186, 70, 90)])
+def test_one_round_refit_of_the_marching_apply_changes_no_bit(lib, gpu_ctx, n):
+    """el_fast_fit (and el_bnd_gran: 64 instead of 256 boundary nodes per boundary workgroup): a launch whose equal z-chunks would need between one and two resident rounds of workgroups (config 5: 21 chunks of 3 planes,
+    846 workgroups on the 768 slots of 256 CUs) is cut into as many chunks as fill one round, of two lengths (19 chunks of 4 / 3 planes).  Same
+    per-node arithmetic: the result must be the equal-chunk launch's bit for bit (that launch is checked against the assembled matrix above and,
+    at config 5's size, by the independent residual of test_config5_at_full_size)"""
+    from pdegpu import _lib
+    nodes = (n[0] + 1) * (n[1] + 1) * (n[2] + 1)
+    u = np.random.default_rng(4).uniform(-1, 1, (nodes, 3))
+    el = _lib.Elasticity()
+    el.E, el.nu = 210e9, 0.3
+    g = _lib.make_grid(3, n, (1.0, 0.25, 0.25))
+    outs = []
+    try:
+        for fit, gran in ((1, 64), (0, 64), (1, 256)):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_fast_fit", fit))
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_bnd_gran", gran))
+            y = np.full_like(u, np.nan)
+            _lib.check(gpu_ctx, lib.pdegpu_elasticity_apply(gpu_ctx, g, el, _lib.dptr(u), _lib.dptr(y), 2))
+            outs.append(y)
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_fast_fit", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_bnd_gran", 64))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.all(outs[0].reshape(n[2] + 1, n[1] + 1, n[0] + 1, 3)[:, :, 0] == 0.0)
+
+
 @pytest.mark.parametrize("n,Ls", [((6, 5, 4), (1.0, 0.6, 0.25)), ((37, 3, 2), (2.0, 0.3, 0.2)), ((16, 1, 1), (1.0, 0.1, 0.1))])
 def test_mfma_element_by_element_apply_matches_assembled_matrix(lib, gpu_ctx, n, Ls):
     """v_mfma_f64_16x16x4_f64 element-by-element form (24x24 macro element, scatter by fp64 atomics) == matrix;
