@@ -476,7 +476,7 @@ __device__ __forceinline__ double el_boundary_role(const ElArgs& a, int faces, c
 template <int RY, bool YX, bool ZF, bool NTS>
 __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, ElW18 wk, ElFastGeom fg) {
     const ElW36 w = el_expand_weights(wk);
-    unsigned long long t_start = 0;
+    unsigned long long t_start = 0, t_pro = 0, t_planes = 0, t_loop = 0;      // (trace only: phase stamps of a marching workgroup)
     if (fg.trace) t_start = wall_clock64();
     __shared__ double sTab[27 * PG_NOFF15 * 9];
     __shared__ unsigned sMask[27];
@@ -747,9 +747,14 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                         }
                 }
             };
+            if (fg.trace) t_pro = wall_clock64();
             load_plane(lk0 - 1, PA);
             load_plane(lk0, PB);
             load_plane(lk0 + 1, PC);                          // the address is inside the allocation even when lk0 + 1 == lk1 == nkl
+            if (fg.trace) {                                   // (trace only: when the three planes of the first step have landed)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t_planes = wall_clock64();
+            }
             if constexpr (ZF)
                 if (zlo_chunk) zface_lo(lk0 - 1, PA, PB);
             for (int lk = lk0; lk < lk1; lk += 4) {
@@ -761,6 +766,7 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
                 if (lk + 3 >= lk1) break;
                 step(lk + 3, PD, PA, PB, PC);
             }
+            if (fg.trace) t_loop = wall_clock64();
             if (qmq) {
                 const double* dv = dinv_of(cls_x + 3 + 9);
 #pragma unroll
@@ -778,6 +784,8 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
             }
         }
     }
+    unsigned long long t_red = 0;
+    if (fg.trace) t_red = wall_clock64();
     const double tot = block_sum_256(acc, sRed);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
     if (qmq) {
@@ -785,10 +793,16 @@ __global__ __launch_bounds__(256, (RY <= 2) ? 3 : 2) void k_el_fast(ElArgs a, El
         if (threadIdx.x == 0) a.partials_qmq[blockIdx.x] = t2;
     }
     if (fg.trace && threadIdx.x == 0) {
-        fg.trace[3 * blockIdx.x] = t_start;
-        fg.trace[3 * blockIdx.x + 1] = wall_clock64();
+        unsigned long long* tr = fg.trace + 8 * blockIdx.x;
+        tr[0] = t_start;
+        tr[1] = wall_clock64();
         // HW_REG_XCC_ID (id 20) bits [3:0]; HW_REG_HW_ID (id 4): CU id bits [11:8], SH [12], SE [15:13]
-        fg.trace[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((15 << 11) | 4);
+        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((15 << 11) | 4);
+        tr[3] = t_pro;         // entry .. here: kernel arguments, weights, table fill and its barrier, index arithmetic
+        tr[4] = t_planes;      // .. the three planes of the first step have landed
+        tr[5] = t_loop;        // .. the z-loop is done
+        tr[6] = t_red;         // .. (the plane NZ-1 of the last chunk) the block sums begin
+        tr[7] = 0;
     }
 }
 
@@ -2368,21 +2382,23 @@ extern "C" int pdegpu_elasticity_time_apply(pdegpu_ctx* ctx, const pdegpu_grid* 
         const ElFastGeom& fgs = s.fgeom;
         const int nb = fgs.nb_fast + fgs.nb_bnd;
         unsigned long long* d_tr = nullptr;
-        if (hipMalloc(&d_tr, (size_t)nb * 3 * sizeof(unsigned long long)) == hipSuccess) {
+        if (hipMalloc(&d_tr, (size_t)nb * 8 * sizeof(unsigned long long)) == hipSuccess && hipMemsetAsync(d_tr, 0, (size_t)nb * 64, ctx->stream) == hipSuccess) {
             ElFastGeom fgt = fgs;
             fgt.trace = d_tr;
             a.partials_qmq = s.part4;
             rc = el_apply(&s, a, APPLY_PLAIN, &fgt);
-            std::vector<unsigned long long> h((size_t)nb * 3);
+            std::vector<unsigned long long> h((size_t)nb * 8);
             if (rc == PDEGPU_OK && hipMemcpyAsync(h.data(), d_tr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                 hipStreamSynchronize(ctx->stream) == hipSuccess) {
                 unsigned long long t0 = ~0ULL;
-                for (int b = 0; b < nb; ++b) t0 = std::min(t0, h[3 * b]);
+                for (int b = 0; b < nb; ++b) t0 = std::min(t0, h[8 * b]);
                 if (FILE* f = fopen(tf, "w")) {
                     fprintf(f, "# nb_fast %d nb_bnd %d bnd_last %d ntx %d nty %d nyg %d nzc %d zlen %d nlong %d z0 %d\n", fgs.nb_fast, fgs.nb_bnd, fgs.bnd_last, fgs.ntx,
                             fgs.nty, fgs.nyg, fgs.nzc, fgs.zlen, fgs.nlong, fgs.z0);
+                    auto rel = [&](unsigned long long t) { return t ? t - t0 : 0ULL; };
                     for (int b = 0; b < nb; ++b)
-                        fprintf(f, "%d %llu %llu %llu %llu\n", b, h[3 * b] - t0, h[3 * b + 1] - t0, h[3 * b + 2] >> 32, h[3 * b + 2] & 0xffffffffULL);
+                        fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu %llu\n", b, h[8 * b] - t0, h[8 * b + 1] - t0, h[8 * b + 2] >> 32, h[8 * b + 2] & 0xffffffffULL,
+                                rel(h[8 * b + 3]), rel(h[8 * b + 4]), rel(h[8 * b + 5]), rel(h[8 * b + 6]));
                     fclose(f);
                 }
             }

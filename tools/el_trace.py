@@ -46,3 +46,12 @@ yg, zc = (bm // hdr["ntx"]) % nyg, nzc - 1 - bm // per_chunk
 print("boundary workgroups:", " ".join(f"{v:.1f}" for v in dur[~m]))
 print("by y-group (median/max us):", " ".join(f"{np.median(d[yg == y]):.1f}/{d[yg == y].max():.1f}" for y in range(nyg) if np.any(yg == y)))
 print("by z-chunk (median/max us):", " ".join(f"{np.median(d[zc == z]):.1f}/{d[zc == z].max():.1f}" for z in range(nzc) if np.any(zc == z)))
+# phases of a marching workgroup (wave 0's stamps): entry -> prologue done -> first three planes landed -> z-loop done -> sums begin -> end
+ph = t[m][:, 5:9] * 0.01
+ok = ph[:, 0] > 0
+if ok.any():
+    s0, e0 = st[m][ok], en[m][ok]
+    seg = np.stack([ph[ok, 0] - s0, ph[ok, 1] - ph[ok, 0], ph[ok, 2] - ph[ok, 1], ph[ok, 3] - ph[ok, 2], e0 - ph[ok, 3]], axis=1)
+    names = ["prologue (args, weights, table fill + barrier)", "first three planes land", "z-loop", "after the loop (plane NZ-1 of the last chunk)", "block sums + partials"]
+    for k, nm in enumerate(names):
+        print(f"  {nm:48s} median {np.median(seg[:, k]):5.2f}  90 % {np.percentile(seg[:, k], 90):5.2f}  max {seg[:, k].max():5.2f} us")

@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void fake_apply(const double* p, double* q, lo
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 200;
+    const int nzp = argc > 2 ? atoi(argv[2]) : 65;            // node planes (65 = config 5; fewer: a smaller working set)
+    const bool inplace = argc > 3 && atoi(argv[3]) != 0;      // p updated in place (one p vector instead of the loop's two)
     Geo g;
-    g.NX = 257; g.NY = 65; g.NZ = 65; g.PX = 272;
+    g.NX = 257; g.NY = 65; g.NZ = nzp; g.PX = 272;
     g.PP = (long long)g.PX * g.NY;
     g.stride = g.PP * g.NZ + 4096;
     const size_t vec = (size_t)3 * g.stride;
@@ -254,7 +256,7 @@ int main(int argc, char** argv) {
     int cur = 0;
     auto args = [&]() {
         Args a;
-        a.g = g; a.q = q; a.r = r; a.p_old = cur ? p1 : p0; a.p_new = cur ? p0 : p1; a.x = x;
+        a.g = g; a.q = q; a.r = r; a.p_old = cur ? p1 : p0; a.p_new = inplace ? (cur ? p1 : p0) : (cur ? p0 : p1); a.x = x;
         a.dinv = dinv; a.scal = scal; a.part = part; a.part2 = part2;
         return a;
     };
@@ -262,12 +264,12 @@ int main(int argc, char** argv) {
         float only_apply = 0.f, both = 0.f;
         for (int phase = 0; phase < 2; ++phase) {
             for (int w = 0; w < 10; ++w) {
-                if (phase) { launch(args()); cur ^= 1; }
+                if (phase) { launch(args()); if (!inplace) cur ^= 1; }
                 hipLaunchKernelGGL(fake_apply, dim3(2048), dim3(256), 0, st, cur ? p1 : p0, q, n2);
             }
             CK(hipEventRecord(e0, st));
             for (int w = 0; w < reps; ++w) {
-                if (phase) { launch(args()); cur ^= 1; }
+                if (phase) { launch(args()); if (!inplace) cur ^= 1; }
                 hipLaunchKernelGGL(fake_apply, dim3(2048), dim3(256), 0, st, cur ? p1 : p0, q, n2);
             }
             CK(hipEventRecord(e1, st));
@@ -279,7 +281,8 @@ int main(int argc, char** argv) {
                7.0 * 3 * g.PP * g.NZ * 8 / (us * 1e-6) / 1e12);
         fflush(stdout);
     };
-    for (int mult : {4, 8, 16}) {
+    printf("%d node planes: vectors of %.1f MB, %s\n", nzp, 3.0 * g.PP * g.NZ * 8 / 1e6, inplace ? "p in place (5 vectors)" : "two p vectors (6 vectors)");
+    for (int mult : {4}) {
         char nm[96];
         snprintf(nm, sizeof nm, "v0 grid-stride, %d workgroups", mult * 256);
         run(nm, [&](Args a) { hipLaunchKernelGGL(upd_v0, dim3(mult * 256), dim3(256), 0, st, a); });
