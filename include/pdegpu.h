@@ -183,6 +183,8 @@ const char* pdegpu_version(void);
  * el_fast_yzface     | 3       | bit 0: y-face rows, bit 1: the planes 0 / NZ-1 as well (the class-table pass keeps the box edges)
  * el_fast_nt         | -1      | non-temporal stores of the output: 1|0, -1 = where the vectors are HBM-resident
  * el_fast_waves      | 0       | wavefront target of the marching part; 0 = 4096, 8192 on HBM-resident grids
+ * el_xdefer          | 1       | single-reduction PCG of a whole solve: x += alpha p is left out of every other update pass and made up for by the next
+ *                    |         | one from what that pass reads anyway (6 instead of 7 vector passes on average); 0 = in every pass
  * el_bnd_gran        | 64      | boundary nodes a boundary workgroup of the marching apply takes per pass where only edges and corners are left to them (64|256)
  * el_fast_fit        | 1       | a launch between one and two resident rounds of workgroups is cut into as many z-chunks as fill ONE round, of two
  *                    |         | lengths (config 5: 19 chunks of 4 / 3 planes = 766 workgroups on 768 slots instead of 21 x 3 = 846; 0 = equal chunks)

@@ -64,6 +64,8 @@ struct pdegpu_ctx {
     int el_bnd_gran = 64;       // k_el_fast: boundary nodes a boundary workgroup takes per pass where they are few (edges and corners only): 64 | 256
     int el_fast_fit = 1;        // k_el_fast: 1 = a launch that would need between one and two resident rounds of workgroups is cut into as many z-chunks as fill
                                 // ONE round, of two lengths (config 5: 19 chunks of 4 / 3 planes = 766 workgroups on 768 slots instead of 21 x 3 = 846)
+    int el_xdefer = 1;          // single-reduction elasticity PCG of a whole solve: 1 = x += alpha p is left out of every other update pass and made up for by the
+                                // next one from what that pass reads anyway (6 instead of 7 vector passes on average); 0 = x updated in every pass
     int el_cg_variant = 1;      // elasticity PCG: 1 = single-reduction form (K2 and p-update fused into one pass, one scalar reduction per iteration); 0 = classic
     int el_split_min_mb = 32;   // slab loop: K1 is split around the halo exchange where one vector of the slab (3 components) holds at least this many MiB
     int el_fast_waves = 0;      // wavefronts the marching part aims for (sets the z-chunk length); 0 = 4096, 8192 on HBM-resident grids

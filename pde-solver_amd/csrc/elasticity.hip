@@ -21,7 +21,9 @@ namespace {
 // device scalars of the elasticity PCG; RZ and RR are adjacent so the multi-GPU host all-reduces them as one 16-byte message
 // Single-reduction form (el_cg_variant 1): the block {ESC_PQ, ESC_RZ, ESC_RR, ESC_QMQ} = {p.Ap, r.z, r.r, Ap.D^-1 Ap} is ONE 32-byte message per iteration
 // (ESC_QMQ takes the slot the classic form uses for the previous r.z).
-enum { ESC_PQ = 0, ESC_RZ = 1, ESC_RR = 2, ESC_RZ_PREV = 3, ESC_QMQ = 3, ESC_COUNT = 8 };
+enum { ESC_PQ = 0, ESC_RZ = 1, ESC_RR = 2, ESC_RZ_PREV = 3, ESC_QMQ = 3,
+       ESC_XD_FLAG = 4, ESC_XD_ALPHA = 5, ESC_XD_BETA = 6,      // deferred x update of the single-reduction form (el_xdefer, see k_el_update)
+       ESC_COUNT = 8 };
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -989,9 +991,14 @@ __global__ __launch_bounds__(256) void k_el_pupdate(ElArgs a, long long first, l
 // the next block and forms the next alpha.  7 vector passes (read r, q, p_old, x; write r, p_new, x) where K2 + p-update make 8, one launch less, and
 // ONE scalar reduction per iteration.  ghost != 0: only p_new = D^-1 r + beta p_old on up to two index ranges (the ghost planes of a slab, whose r has
 // just arrived from the neighbour), no sums.
+// xmode (el_xdefer): the x update of every other pass is left out and made up for by the next one — 6 instead of 7 vector passes on average.
+//   1: this pass may SKIP x += alpha p_old (it does when its beta is not small) and records {skipped, alpha, beta} in the scalars;
+//   2: the pass right after a mode-1 pass: if that one skipped, x += alpha p_old + alpha' p_old' with the previous pass's p_old' = (p_old - z) / beta'
+//      (p_old = z + beta' p_old' was formed there; z = D^-1 r of the r this pass reads, before its own update) — nothing more is read for it;
+//   0: the plain pass.  The host never ends a chunk on a mode-1 pass, so nothing is pending when x or the scalars are looked at.
 template <int D, bool NT>
 __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __restrict__ q, double* __restrict__ r, int ghost, long long first,
-                                                    long long total, long long first2, long long total2, int nb1) {
+                                                    long long total, long long first2, long long total2, int nb1, int xmode) {
     __shared__ double sRed4[16];
     __shared__ double sDinv[27 * 3];
     if (threadIdx.x < 81) sDinv[threadIdx.x] = a.dinv[threadIdx.x];
@@ -1038,6 +1045,20 @@ __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __res
     const double alpha = (pq > 0.0 && rz > 0.0) ? rz / pq : 0.0;                  // 0 on the first iteration (p.Ap = 0)
     const double rz_next = alpha * alpha * qmq - rz;
     const double beta = (alpha > 0.0 && rz_next > 0.0) ? rz_next / rz : 0.0;      // a lost prediction restarts with the preconditioned residual
+    // deferred x update (kernel-uniform): x += cx_p p_old - cx_z D^-1 r_in
+    const bool skip_x = xmode == 1 && alpha != 0.0 && beta > 1e-2;
+    const bool dbl = xmode == 2 && a.scal[ESC_XD_FLAG] != 0.0;
+    double cx_p = alpha, cx_z = 0.0;
+    if (dbl) {
+        cx_z = a.scal[ESC_XD_ALPHA] / a.scal[ESC_XD_BETA];
+        cx_p = alpha + cx_z;
+    }
+    if (xmode == 1 && blockIdx.x == 0 && threadIdx.x == 0) {      // (slots no workgroup of this launch reads)
+        double* sc = const_cast<double*>(a.scal);
+        sc[ESC_XD_FLAG] = skip_x ? 1.0 : 0.0;
+        sc[ESC_XD_ALPHA] = alpha;
+        sc[ESC_XD_BETA] = beta;
+    }
     const GridDev& g = a.g;
     const bool second = (int)blockIdx.x >= nb1;               // workgroup-uniform
     if (second) {
@@ -1069,6 +1090,7 @@ __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __res
         // every load of the node pair (4 vectors x D components) is issued before the first store: in program order a load behind a store waits for it
         // (stores count in the in-order vmcnt, and the vectors may alias as far as the compiler knows), which made the D components 2 D dependent round trips
         const bool upd = !ghost && alpha != 0.0;              // kernel-uniform
+        const bool xdo = !ghost && ((upd && !skip_x) || dbl);
         double2 po[D], rv[D], qv[D], xv[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) {
@@ -1076,20 +1098,21 @@ __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __res
             rv[c] = el_ld2<NT>(r + c * a.stride + idx);
             qv[c] = make_double2(0.0, 0.0);
             xv[c] = make_double2(0.0, 0.0);
-            if (upd) {
-                qv[c] = el_ld2<NT>(q + c * a.stride + idx);
-                xv[c] = el_ld2<NT>(a.x + c * a.stride + idx);
-            }
+            if (upd) qv[c] = el_ld2<NT>(q + c * a.stride + idx);
+            if (xdo) xv[c] = el_ld2<NT>(a.x + c * a.stride + idx);
         }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
+            if (xdo) {
+                // (cx_z = 0 unless this pass makes up for the one before: then D^-1 r of the r just read is the z that pass formed p_old from)
+                xv[c].x += cx_p * po[c].x - cx_z * (sDinv[cls0 * 3 + c] * rv[c].x);
+                xv[c].y += cx_p * po[c].y - cx_z * (sDinv[cls1 * 3 + c] * rv[c].y);
+                el_st2<NT>(a.x + c * a.stride + idx, xv[c]);
+            }
             if (upd) {
                 rv[c].x -= alpha * qv[c].x;
                 rv[c].y -= alpha * qv[c].y;
                 el_st2<NT>(r + c * a.stride + idx, rv[c]);
-                xv[c].x += alpha * po[c].x;
-                xv[c].y += alpha * po[c].y;
-                el_st2<NT>(a.x + c * a.stride + idx, xv[c]);
             }
             const double2 zv = make_double2(sDinv[cls0 * 3 + c] * rv[c].x, sDinv[cls1 * 3 + c] * rv[c].y);
             acc_rz += rv[c].x * zv.x + rv[c].y * zv.y;
@@ -1834,7 +1857,7 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr, int part = -1) {
 // ---- single-reduction PCG (variant 1) ---------------------------------------------------------------------------------------------------
 // update pass over the owned planes; lazy: sum the previous block from partials in the prologue (single-slab loops) unless the block has just
 // been reduced into the scalars (sr_mem)
-int el_sr_update(ElSession* s, bool lazy) {
+int el_sr_update(ElSession* s, bool lazy, int xmode = 0) {
     const GridDev& g = s->g;
     ElArgs a = s->args();
     a.p_old = s->p[s->pcur];
@@ -1852,10 +1875,10 @@ int el_sr_update(ElSession* s, bool lazy) {
     }
     const long long total = (long long)g.nkl * g.PP;
     if (s->D == 3) {
-        if (el_vec_nt(s)) hipLaunchKernelGGL((k_el_update<3, true>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk);
-        else hipLaunchKernelGGL((k_el_update<3, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk);
+        if (el_vec_nt(s)) hipLaunchKernelGGL((k_el_update<3, true>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk, xmode);
+        else hipLaunchKernelGGL((k_el_update<3, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk, xmode);
     } else {
-        hipLaunchKernelGGL((k_el_update<2, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk);
+        hipLaunchKernelGGL((k_el_update<2, false>), dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 0, 0LL, total, 0LL, 0LL, s->nblk, xmode);
     }
     PG_HIP(s->ctx, hipGetLastError());
     s->ucur ^= 1;
@@ -1875,8 +1898,8 @@ int el_sr_ghost_update(ElSession* s) {
     const long long f1 = lo ? lo_first : hi_first, f2 = (lo && hi) ? hi_first : 0, t2 = (lo && hi) ? (long long)g.PP : 0;
     const int nbp = (int)std::max<long long>(1, std::min<long long>(s->nblk, ((long long)g.PP / 2 + 255) / 256));
     const int nb1 = nbp, nb = t2 > 0 ? 2 * nbp : nbp;
-    if (s->D == 3) hipLaunchKernelGGL((k_el_update<3, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 1, f1, (long long)g.PP, f2, t2, nb1);
-    else hipLaunchKernelGGL((k_el_update<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 1, f1, (long long)g.PP, f2, t2, nb1);
+    if (s->D == 3) hipLaunchKernelGGL((k_el_update<3, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 1, f1, (long long)g.PP, f2, t2, nb1, 0);
+    else hipLaunchKernelGGL((k_el_update<2, false>), dim3(nb), dim3(256), 0, s->ctx->stream, a, s->q, s->r, 1, f1, (long long)g.PP, f2, t2, nb1, 0);
     PG_HIP(s->ctx, hipGetLastError());
     return PDEGPU_OK;
 }
@@ -1892,7 +1915,7 @@ int el_sr_reduce(ElSession* s, int n_apply) {
 // One iteration = update pass + apply.  part: -1 whole (slabs without neighbours; lazy: no reduce launch), 0 = the update pass of the owned planes
 // (the host then posts the exchange of r), 1 = the apply on the planes away from the ghosts (overlaps the exchange), 2 = the ghost planes'
 // p-update, the remaining apply and the block reduce.
-int el_sr_k1(ElSession* s, bool lazy, int part) {
+int el_sr_k1(ElSession* s, bool lazy, int part, int xmode = 0) {
     const GridDev& g = s->g;
     const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;
     ElArgs b = s->args();
@@ -1901,7 +1924,7 @@ int el_sr_k1(ElSession* s, bool lazy, int part) {
     if (part < 0) {
         if (lo || hi) return pdegpu_set_err(s->ctx, PDEGPU_EINVAL, "single-reduction PCG on a slab with neighbours: the residual update is part of k1, "
                                                                     "so r travels INSIDE it — call k1_pre, exchange r, then k1_part(0) and k1_part(1)");
-        PG_TRY(el_sr_update(s, lazy));
+        PG_TRY(el_sr_update(s, lazy, xmode));
         s->pcur ^= 1;
         b.in = s->p[s->pcur];
         b.partials = s->part3;
@@ -2209,7 +2232,12 @@ extern "C" int pdegpu_elasticity_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid,
             // single-reduction PCG: update pass (K2 and p-update fused) + block apply; with lazy_dot the update pass sums the previous block in its
             // prologue and one reduce launch closes the chunk for the poll
             const bool lz = ctx->lazy_dot != 0;
-            for (int i = 0; i < n; ++i) PG_TRY(el_sr_k1(&s, lz, -1));
+            // el_xdefer: the passes of a chunk go in pairs (may skip the x update | makes up for it); an odd last pass is a plain one, so that
+            // nothing is pending when the chunk's poll — or the caller — looks
+            for (int i = 0; i < n; ++i) {
+                const int xmode = !ctx->el_xdefer ? 0 : ((i & 1) ? 2 : (i + 1 < n ? 1 : 0));
+                PG_TRY(el_sr_k1(&s, lz, -1, xmode));
+            }
             if (lz) PG_TRY(el_sr_reduce(&s, s.last_apply_blocks));
         } else {
             ElLazy lazy;

@@ -508,7 +508,7 @@ static const char* const kTunableKeys[] = {
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
     "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
-    "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran"};
+    "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran", "el_xdefer"};
 
 extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
     if (!out) return PDEGPU_EINVAL;
@@ -586,6 +586,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "el_fast_ry")) return &ctx->el_fast_ry;
     if (!strcmp(key, "el_fast_fit")) return &ctx->el_fast_fit;
     if (!strcmp(key, "el_bnd_gran")) return &ctx->el_bnd_gran;
+    if (!strcmp(key, "el_xdefer")) return &ctx->el_xdefer;
     if (!strcmp(key, "el_fast_yx")) return &ctx->el_fast_yx;
     if (!strcmp(key, "el_fast_xface")) return &ctx->el_fast_xface;
     if (!strcmp(key, "el_bnd_last")) return &ctx->el_bnd_last;

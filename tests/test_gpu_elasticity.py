@@ -174,6 +174,31 @@ def test_elasticity_3d_matches_oracle(lib, gpu_ctx, quantity):
         assert got.meta[k] == v
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_deferred_x_update_of_the_pcg_gives_the_same_solve(lib, gpu_ctx, dim):
+    """el_xdefer: every other update pass of the single-reduction PCG leaves x += alpha p out and the next one makes up for it with the
+    search direction rebuilt from what it reads anyway (p_old' = (p_old - D^-1 r) / beta').  Same iterates up to round-off: both settings against
+    the oracle, against each other, and the iteration counts within 1 %"""
+    from pdegpu import elasticity, _lib
+    if dim == 3:
+        kw = dict(Lx=1.0, Ly=0.25, Lz=0.25, nx=40, ny=9, nz=7, E=210e9, nu=0.3, body_fx=3.0e3, body_fy=0.0, body_fz=-76518.0, quantity="stress")
+        solve, ref = elasticity._solve_elasticity_3d_static, o.solve_elasticity_3d(**kw)
+    else:
+        kw = dict(Lx=1.0, Ly=0.3, nx=48, ny=14, E=210e9, nu=0.3, body_fx=1.0e4, body_fy=-76518.0, quantity="strain", plane_stress=False)
+        solve, ref = elasticity._solve_elasticity_2d_static, o.solve_elasticity_2d(**kw)
+    got = {}
+    try:
+        for xd in (1, 0):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_xdefer", xd))
+            got[xd] = solve(**kw, rtol=1e-12, want_displacement=True)
+            assert rel_err(got[xd].displacement, ref.extra["displacement"]) < TOL and rel_err(got[xd].values, ref.values) < TOL
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_xdefer", 1))
+    assert rel_err(got[1].displacement, got[0].displacement) < 1e-9
+    it1, it0 = got[1].meta["cg_iterations"], got[0].meta["cg_iterations"]
+    assert it0 > 50 and abs(it1 - it0) <= max(2, 0.01 * it0), (it1, it0)
+
+
 def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
     from pdegpu import elasticity, _lib
     f = elasticity._solve_elasticity_3d_static(1, 1, 1, 4, 4, 4, 210e9, 0.3)          # no load -> u = 0 (:2639-2642)
