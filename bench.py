@@ -312,9 +312,17 @@ class Runner:
             elapsed = max_over_ranks(elapsed)
             res["elapsed"] = elapsed
             res["k1_ms"] = stats.kernel_ms[0] / max(1, stats.kernel_launches[0])
-            res["k2_ms"] = stats.kernel_ms[1] / max(1, stats.kernel_launches[1])
             nodes_local = (nx + 1) * (ny + 1) * nk
-            res["k1_per_dof"] = round(stats.alg_bytes[0] / max(1, stats.kernel_launches[0]) / nodes_local)      # 40 or 48
+            res["k1_per_dof"] = round(stats.alg_bytes[0] / max(1, stats.kernel_launches[0]) / nodes_local)      # 40 or 48; 24: x is updated by K2
+            # K2: all of its launches together, and — sessions whose K2 carries the x update of every other iteration (tunable cg_xdefer) — the two
+            # forms apart: kernel_ms[1] the launches without the update (24 B/DoF), kernel_ms[2] those with it (40 B/DoF)
+            n2 = stats.kernel_launches[1] + stats.kernel_launches[2]
+            res["k2_ms"] = (stats.kernel_ms[1] + stats.kernel_ms[2]) / max(1, n2)
+            res["k2_per_dof"] = (stats.alg_bytes[1] + stats.alg_bytes[2]) / max(1, n2) / nodes_local
+            res["k2_forms"] = None
+            if stats.kernel_launches[2] > 0:
+                res["k2_forms"] = {"without_x": {"launches": int(stats.kernel_launches[1]), "avg_ms": stats.kernel_ms[1] / max(1, stats.kernel_launches[1]), "per_dof": 24},
+                                   "with_x": {"launches": int(stats.kernel_launches[2]), "avg_ms": stats.kernel_ms[2] / stats.kernel_launches[2], "per_dof": 40}}
             res["unknowns_rank0"] = (nx - 1) * (ny - 1) * max(0, min(k0 + nk, nz) - max(k0, 1))
             res["split_k1"] = bool(eng.can_split_k1()) and not self.args.no_overlap
             if extras_n1:
@@ -416,18 +424,38 @@ def run_config5(R, steps, warmup, native):
 
 
 def roofline_of(res, general):
-    """K1 (the SpMV-bearing fused kernel) and K2 of rank 0's slab, algorithmic bytes over the HIP-event time of the timed region"""
+    """K1 (the SpMV-bearing fused kernel) and K2 of rank 0's slab, algorithmic bytes over the HIP-event time of the timed region.  The dominant kernel
+    is K1: where the solution vector is updated by K2 (k1_per_dof 24) K1 is still the launch with the largest share of an iteration (every iteration
+    has one; the two forms of K2 alternate)"""
     unk = res["unknowns_rank0"]
-    k1_bytes, k2_bytes = float(res["k1_per_dof"]) * unk, 24.0 * unk
+    k1_bytes, k2_bytes = float(res["k1_per_dof"]) * unk, float(res.get("k2_per_dof", 24.0)) * unk
     ach = k1_bytes / (res["k1_ms"] * 1e-3) / 1e9 if res["k1_ms"] > 0 else 0.0
     k2a = k2_bytes / (res["k2_ms"] * 1e-3) / 1e9 if res["k2_ms"] > 0 else 0.0
+    x_in_k2 = res["k1_per_dof"] == 24
+    if general:
+        k1_name = "k_general<CG_K1>"
+    elif x_in_k2:
+        k1_name = "k_fast<7,2,CG_K1,nt,ex,xu=0> (p=r+b*p; q=A p [not stored]; p.q — x is updated by K2, every other iteration)"
+    else:
+        k1_name = "k_fast<7,2,CG_K1,nt,ex> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)"
+    others = []
+    forms = res.get("k2_forms")
+    if forms:
+        for key, name in (("with_x", "k_fast<7,2,CG_K2,nt,ex,xu=1> (r-=a*(A p); r.r; x += a*p + the update the K2 before left out)"),
+                          ("without_x", "k_fast<7,2,CG_K2,nt,ex,xu=0> (r-=a*(A p); r.r)")):
+            f = forms[key]
+            a_ = f["per_dof"] * unk / (f["avg_ms"] * 1e-3) / 1e9 if f["avg_ms"] > 0 else 0.0
+            others.append({"kernel": name, "alg_bytes_per_launch": float(f["per_dof"]) * unk, "avg_ms": f["avg_ms"], "launches": f["launches"],
+                           "achieved": a_, "frac": a_ / HBM_PEAK_GBS})
+    else:
+        others.append({"kernel": "k_fast<7,2,CG_K2,nt,ex> (r-=a*(A p); r.r)" if res["k1_per_dof"] in (24, 40) else "k_k2 (r-=a*q; r.r)",
+                       "alg_bytes_per_launch": k2_bytes, "avg_ms": res["k2_ms"], "achieved": k2a, "frac": k2a / HBM_PEAK_GBS})
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-            "kernel": ("k_fast<7,2,CG_K1,nt,ex> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)" if not general else "k_general<CG_K1>") +
-                      (" — rank 0's slab; a split K1 counts its parts together" if res.get("split_k1") else ""),
+            "kernel": k1_name + (" — rank 0's slab; a split K1 counts its parts together" if res.get("split_k1") else ""),
             "alg_bytes_per_launch": k1_bytes, "avg_ms": res["k1_ms"],
-            "other_kernels": [{"kernel": "k_fast<7,2,CG_K2,nt,ex> (r-=a*(A p); r.r)" if res["k1_per_dof"] == 40 else "k_k2 (r-=a*q; r.r)",
-                               "alg_bytes_per_launch": k2_bytes, "avg_ms": res["k2_ms"], "achieved": k2a, "frac": k2a / HBM_PEAK_GBS}],
-            "cg_iteration_alg_bytes_per_dof": res["k1_per_dof"] + 24}
+            "other_kernels": others,
+            "k2_all_launches": {"avg_ms": res["k2_ms"], "alg_bytes_per_launch": k2_bytes, "achieved": k2a, "frac": k2a / HBM_PEAK_GBS},
+            "cg_iteration_alg_bytes_per_dof": res["k1_per_dof"] + float(res.get("k2_per_dof", 24.0))}
 
 
 _REAL_STDOUT = None
@@ -498,7 +526,7 @@ def main():
     }
     rl = roofline_of(res, args.general)
     if world > 1:
-        per_gpu = float(res["k1_per_dof"] + 24) * res["unknowns"] / world / (res["elapsed"] / args.steps) / 1e9
+        per_gpu = float(res["k1_per_dof"] + res.get("k2_per_dof", 24.0)) * res["unknowns"] / world / (res["elapsed"] / args.steps) / 1e9
         rl["whole_iteration_per_gpu"] = {"achieved": per_gpu, "frac": per_gpu / HBM_PEAK_GBS,
                                          "note": "K1 + K2 algorithmic bytes per GPU over the whole iteration incl. halo exchange and the scalar all-reduce(s)"}
     else:

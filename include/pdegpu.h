@@ -105,7 +105,9 @@ typedef struct pdegpu_stats {
     double  solve_ms;           /* device time of the whole call (hipEvent) */
     double  cg_ms;              /* device time inside CG iterations */
     double  kernel_ms[4];       /* summed hipEvent time: [0] operator apply (SpMV, fused or not),
-                                   [1] vector update(s), [2] right-hand-side/other, [3] transfers */
+                                   [1] vector update(s), [2] right-hand-side/other, [3] transfers.  Stepwise timing of a session whose
+                                   solution vector is updated by K2 (tunable cg_xdefer): [1] the K2 launches without the x update,
+                                   [2] those that carry it */
     int64_t kernel_launches[4];
     double  alg_bytes[4];       /* algorithmic HBM bytes of the launches counted in kernel_ms */
     int32_t path;               /* 0 general class-table kernels, 1 fused z-marching kernels */
@@ -142,6 +144,9 @@ const char* pdegpu_version(void);
  * fast_cfg_plain|res|k1|k2 | -1 | per-mode word ry + 16 wg_per_cu + 256 ex + 512 pf; -1 = the global tunables
  * cg_variant         | 1       | 1 = K2 applies the marching stencil to the stored p again (64 B/DoF, 7-point operator); 2 = also for
  *                    |         | the 15-point operator of transient runs; 0 = K1 stores q, flat K2 (72 B/DoF)
+ * cg_xdefer          | 1       | marching sessions in the 64 B/DoF form: the solution vector is updated by K2 (which holds p_n, r_n and alpha_n) instead
+ *                    |         | of the next K1, and only by every other K2 — the one in between records its alpha, the next forms both updates
+ *                    |         | with p_(n-1) = (p_n - r_n) / beta_n.  K1 24 B/DoF, K2 24 | 40 B/DoF: 56 instead of 64 B/DoF per iteration
  * lazy_dot           | 1       | single-slab loops: the next kernel's prologue sums the previous launch's partials (no reduce launches)
  * place_tune         | 1       | HBM-resident marching sessions time K1 once with each of their six interchangeable vectors as the
  *                    |         | solution vector and keep the fastest (~18 launches at creation; profiles/r03_placement_*.log)

@@ -38,6 +38,9 @@ struct pdegpu_ctx {
                                 // longer-lived streams move more bytes per second on this memory system (512^3: K1 1.03 -> 0.92 ms,
                                 // K2 0.62 -> 0.55 ms against the occupancy limit of 5-8) — and the occupancy API on cache-resident grids
     int grid_mult = 8;          // flat kernels: workgroups per CU
+    int cg_xdefer = 1;          // marching sessions in the 64 B/DoF form: 1 = the solution vector is updated by K2 (which holds p_n, r_n and alpha_n) instead of
+                                // the next K1, and only by every other K2 — the one in between records its alpha, the next forms both updates with
+                                // p_{n-1} = (p_n - r_n) / beta_n: K1 24 B/DoF, K2 24 | 40 B/DoF = 56 instead of 64 B/DoF per iteration; 0 = x += alpha p in K1
     int cg_variant = 1;         // fast path: 0 = K1 stores q, flat K2 (72 B/DoF); 1 = K2 recomputes q = A p (64 B/DoF)
     int el_grid_mult = 4;       // elasticity kernels: workgroups per CU (each loads the 29 KB class table into LDS)
     int wfast = 1;              // weighted 3-D operators whose coefficient rows are compact (ell_compact) on an all-Dirichlet box: 1 = z-marching kernels with the
@@ -247,6 +250,11 @@ struct StencilArgs {
     int bnd_xcols = 2;        // boundary pass: x-face columns of the interior rows it still owns (2 both, 1 only x = NX-1, 0 none)
     int free_x = 0;           // marching kernel: 1 = the x-faces carry unknowns (their CG vectors are not zero: load them); 2 = and the
                               // x-face nodes of interior rows are computed by the marching kernel itself (edge lanes, halved in-face terms)
+    // x_in_k2 sessions (marching kernels, K2 = the stencil on the stored p): K1 leaves x alone and records its beta in xd[1]; K2 either leaves x alone too
+    // and records its alpha in xd[0] (xmode 0), or updates x for itself and for the K2 before it (xmode 2) — k_fast's XU template parameter
+    int x_in_k2 = 0;
+    int xmode = 0;
+    double* xd = nullptr;
     int lk_lo = 0, lk_hi = 0; // marching kernel: restrict the launch to the local planes [lk_lo, lk_hi) (lk_hi > lk_lo; 0, 0 = all).  The
                               // multi-GPU loop launches K1 on the planes away from the ghosts first (halo exchange in flight)
     int lk_lo2 = 0, lk_hi2 = 0;   // ... and a second, disjoint plane range in the SAME launch (the two edge planes of a slab: one launch, not two)

@@ -56,6 +56,13 @@ struct pdegpu_session {
     bool sr_k2_pending = false;    // K2's r.r partials (d_part + npart) have not been summed into SC_RR yet: the next K1's reduce launch does
     int sr_k2_grid = 0;
     bool sr_skip_x = false;        // flush has applied the pending x += alpha p: the next K1 must not
+    // x_in_k2 (tunable cg_xdefer; marching sessions whose K2 is the stencil on the stored p): the solution vector is updated by K2, and only by
+    // every other one — the K2 in between records its alpha, the next forms both updates from what it reads anyway (k_fast, template XU)
+    bool xk2 = false;
+    bool xk2_pending = false;      // the latest K2 left its x += alpha p out (flush, or the next K2, makes up for it)
+    int xk2_mode = 0;              // StencilArgs.xmode of the current iteration's K2 launches (0 leave out + record, 2 update for two)
+    long long timed_k2x = 0;       // timed K2 launches that carried the x update (byte accounting)
+    double* d_xd = nullptr;        // {alpha of the K2 that left its update out, beta of the latest K1}
     int rr_slot = SC_RR;           // the scalar pdegpu_session_rr reports (SC_RR_POLL after pdegpu_session_sr_poll)
     Persist2d* p2d = nullptr;      // 2-D sessions: register-resident persistent CG (created on first use)
     // weighted (curvilinear) operators: per-node coefficients + Jacobi-PCG
@@ -354,6 +361,25 @@ bool k2_is_stencil(const pdegpu_session* s) {
     return s->fast && (!s->hybrid || hyb_ok) && ((s->ctx->cg_variant == 1 && s->npt == 7) || (s->ctx->cg_variant == 2 && (s->npt == 7 || s->npt == 15)));
 }
 
+// x_in_k2: pure marching sessions (no boundary launch, no tile forms, no weights) in the 64 B/DoF form
+bool xk2_eligible(const pdegpu_session* s) {
+    return s->ctx->cg_xdefer != 0 && s->d_xd && k2_is_stencil(s) && s->fast && !s->hybrid && !s->tile3d && !s->plane2d && !s->weighted && !s->wfast;
+}
+// before the K2 launch(es) of an iteration: leave x out (and record alpha) or update it for this iteration and the one before, alternating
+void xk2_begin(pdegpu_session* s) {
+    if (!s->xk2) return;
+    s->xk2_mode = s->xk2_pending ? 2 : 0;
+    s->xk2_pending = !s->xk2_pending;
+}
+// a new solve (reset_cg / begin / residual): nothing pending, the recorded scalars void
+int xk2_reset(pdegpu_session* s) {
+    s->xk2 = xk2_eligible(s);
+    s->xk2_pending = false;
+    s->xk2_mode = 0;
+    if (s->d_xd) PG_HIP(s->ctx, hipMemsetAsync(s->d_xd, 0, 4 * sizeof(double), s->ctx->stream));
+    return PDEGPU_OK;
+}
+
 // lk_lo < lk_hi: one part of a split K1 (marching sessions only) — the launch covers the local planes [lk_lo, lk_hi), appends its
 // partials at part_off and leaves the p ping-pong alone (the caller flips it after the last part)
 // single-reduction form: how K1 / K2 read the all-reduced block {SC_PQ, SC_RR, SC_QQ} (dot_finish.h)
@@ -412,6 +438,10 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
         a.npt = s->npt;
         a.free_x = s->hybrid ? (s->ctx->hybrid_fx ? 2 : 1) : 0;
         a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
+        if (s->xk2) {                          // K1 leaves the solution vector alone and records its beta
+            a.x_in_k2 = 1;
+            a.xd = s->d_xd;
+        }
         rc = stencil_fast(s->ctx, a, APPLY_CG_K1, li);
         if (rc == PDEGPU_OK && s->hybrid) rc = hybrid_boundary(s, a, APPLY_CG_K1, li);
     } else {
@@ -456,6 +486,13 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         a.g = s->gk;
         fast_weights(s->hA, a.w, s->gk.flat2d != 0);
         a.npt = s->npt;
+        if (s->xk2) {                          // (the caller has chosen this iteration's mode: xk2_begin)
+            a.x_in_k2 = 1;
+            a.xmode = s->xk2_mode;
+            a.xd = s->d_xd;
+            a.x = s->x.v;
+            a.p_old = s->p[1 - s->pcur].v;     // p of the iteration before: read only when beta cannot rebuild it (restart)
+        }
         if (!s->hybrid) return stencil_fast(s->ctx, a, APPLY_CG_K2, li);
         a.free_x = s->ctx->hybrid_fx ? 2 : 1;
         a.fx_hi = ((s->g.NX - 1) % 128) != 0 ? 1 : 0;
@@ -508,7 +545,7 @@ static const char* const kTunableKeys[] = {
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
     "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
-    "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran", "el_xdefer"};
+    "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran", "el_xdefer", "cg_xdefer"};
 
 extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
     if (!out) return PDEGPU_EINVAL;
@@ -587,6 +624,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "el_fast_fit")) return &ctx->el_fast_fit;
     if (!strcmp(key, "el_bnd_gran")) return &ctx->el_bnd_gran;
     if (!strcmp(key, "el_xdefer")) return &ctx->el_xdefer;
+    if (!strcmp(key, "cg_xdefer")) return &ctx->cg_xdefer;
     if (!strcmp(key, "el_fast_yx")) return &ctx->el_fast_yx;
     if (!strcmp(key, "el_fast_xface")) return &ctx->el_fast_xface;
     if (!strcmp(key, "el_bnd_last")) return &ctx->el_bnd_last;
@@ -633,6 +671,7 @@ extern "C" void pdegpu_session_destroy(pdegpu_session* s) {
     vec_free(&s->x); vec_free(&s->r); vec_free(&s->p[0]); vec_free(&s->p[1]); vec_free(&s->q); vec_free(&s->b);
     tables_free(&s->tabs);
     if (s->d_scal) (void)hipFree(s->d_scal);
+    if (s->d_xd) (void)hipFree(s->d_xd);
     if (s->d_part) (void)hipFree(s->d_part);
     if (s->d_dense) (void)hipFree(s->d_dense);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
@@ -678,12 +717,23 @@ int time_k1_roles(pdegpu_session* s, const int32_t* roles4, int reps, double* av
     a.mask_dirichlet = 1;
     fast_weights(s->hA, a.w, s->gk.flat2d != 0);
     a.npt = s->npt;
+    int mode = APPLY_CG_K1;
+    if (s->xk2) {
+        // x_in_k2 sessions: the read-modify-write stream of the solution vector is in the K2 that carries the x update — time THAT launch:
+        // x = role 0, p (the stencil's input) = role 1, r (read and written) = role 2
+        mode = APPLY_CG_K2;
+        a.rhs = bufs[roles4[2]];
+        a.out = bufs[roles4[2]];
+        a.x_in_k2 = 1;
+        a.xmode = 2;
+        a.xd = s->d_xd;
+    }
     EventPair ev;
     PG_HIP(ctx, hipEventCreate(&ev.a));
     PG_HIP(ctx, hipEventCreate(&ev.b));
-    PG_TRY(stencil_fast(ctx, a, APPLY_CG_K1, nullptr));
+    PG_TRY(stencil_fast(ctx, a, mode, nullptr));
     PG_HIP(ctx, hipEventRecord(ev.a, ctx->stream));
-    for (int i = 0; i < reps; ++i) PG_TRY(stencil_fast(ctx, a, APPLY_CG_K1, nullptr));
+    for (int i = 0; i < reps; ++i) PG_TRY(stencil_fast(ctx, a, mode, nullptr));
     PG_HIP(ctx, hipEventRecord(ev.b, ctx->stream));
     PG_HIP(ctx, hipEventSynchronize(ev.b));
     float ms = 0;
@@ -705,6 +755,7 @@ int tune_x_placement(pdegpu_session* s) {
     const double one[SC_COUNT] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     static_assert(SC_COUNT <= 8, "scalar block");
     PG_HIP(ctx, hipMemcpyAsync(s->d_scal, one, SC_COUNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (s->xk2) PG_HIP(ctx, hipMemcpyAsync(s->d_xd, one, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));      // (x_in_k2: the K2 with the x update is timed)
     double t[6];
     for (int c = 0; c < 6; ++c) {
         int32_t roles[4] = {c, 0, 0, 0};
@@ -714,6 +765,7 @@ int tune_x_placement(pdegpu_session* s) {
         PG_TRY(time_k1_roles(s, roles, 2, &t[c]));
     }
     PG_HIP(ctx, hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream));
+    if (s->xk2) PG_HIP(ctx, hipMemsetAsync(s->d_xd, 0, 4 * sizeof(double), ctx->stream));
     int best = 0;
     for (int c = 1; c < 6; ++c)
         if (t[c] < t[best]) best = c;
@@ -726,7 +778,7 @@ int tune_x_placement(pdegpu_session* s) {
         s->place_choice = best;
     }
     if (getenv("PDEGPU_DEBUG_GEOM"))
-        fprintf(stderr, "[pdegpu placement] K1 with each buffer as x: %.4f %.4f %.4f %.4f %.4f %.4f ms -> x takes buffer %d\n", t[0], t[1], t[2], t[3], t[4], t[5],
+        fprintf(stderr, "[pdegpu placement] the launch that updates x, with each buffer as x: %.4f %.4f %.4f %.4f %.4f %.4f ms -> x takes buffer %d\n", t[0], t[1], t[2], t[3], t[4], t[5],
                 s->place_choice);
     return PDEGPU_OK;
 }
@@ -786,6 +838,8 @@ extern "C" int pdegpu_session_create(pdegpu_ctx* ctx, const pdegpu_grid* grid, c
     if (rc == PDEGPU_OK && hipHostMalloc(&s->h_pin, SC_COUNT * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipHostMalloc");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_scal, 0, SC_COUNT * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset scal");
     if (rc == PDEGPU_OK && hipMemsetAsync(s->d_part, 0, npart * sizeof(double), ctx->stream) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "memset partials");
+    if (rc == PDEGPU_OK && hipMalloc(&s->d_xd, 4 * sizeof(double)) != hipSuccess) rc = pdegpu_set_err(ctx, PDEGPU_EHIP, "hipMalloc xd");
+    if (rc == PDEGPU_OK) rc = xk2_reset(s);
     if (rc == PDEGPU_OK) rc = tune_x_placement(s);
     if (rc != PDEGPU_OK) { pdegpu_session_destroy(s); return rc; }
     *out = s;
@@ -802,6 +856,7 @@ extern "C" int pdegpu_session_begin(pdegpu_session* s, double x_fill) {
     s->pcur = 0;
     s->sr_k2_pending = s->sr_skip_x = false;
     s->rr_slot = SC_RR;
+    PG_TRY(xk2_reset(s));
     PG_TRY(set_bc_ext(s, s->x.v, x_fill, nullptr, 0));
     // constant-source right-hand side b = M (0 + f) = f m  (fenics_mcp_server.py:262, 394, 658)
     PG_TRY(vec_zero(ctx, s->g, &s->q));
@@ -972,19 +1027,20 @@ extern "C" int pdegpu_session_k2(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
     LaunchInfo li;
-    const int at = timed_begin(s, 1);
+    xk2_begin(s);
+    const int at = timed_begin(s, (s->xk2 && s->xk2_mode == 2) ? 2 : 1);      // (kind 2: a K2 that carries the x update of an x_in_k2 session)
     if (s->variant) {
         // r -= alpha A p with alpha from the all-reduced block; the r.r partials wait in the second block for the next K1's reduce launch
         PG_TRY(op_k2(s, &li, sr_dot_in(s), s->d_part + s->npart));
         timed_end(s, at);
-        if (s->timing && s->timing_now) ++s->timed_k2;
+        if (s->timing && s->timing_now) { ++s->timed_k2; if (s->xk2 && s->xk2_mode == 2) ++s->timed_k2x; }
         s->sr_k2_pending = true;
         s->sr_k2_grid = li.grid;
         return PDEGPU_OK;
     }
     PG_TRY(op_k2(s, &li));
     timed_end(s, at);
-    if (s->timing && s->timing_now) ++s->timed_k2;
+    if (s->timing && s->timing_now) { ++s->timed_k2; if (s->xk2 && s->xk2_mode == 2) ++s->timed_k2x; }
     return empty_dot(s, li, 1);
 }
 
@@ -1004,11 +1060,12 @@ extern "C" int pdegpu_session_k2_part(pdegpu_session* s, int part) {
     double* part_out = s->variant ? s->d_part + s->npart : s->d_part;
     LaunchInfo li;
     if (part == 0) {
+        xk2_begin(s);                          // (both parts of the iteration's K2 run in the mode chosen here)
         int e0[2] = {0, lo ? 1 : 0}, e1[2] = {hi ? std::max(g.nkl - 1, lo ? 1 : 0) : 0, hi ? g.nkl : 0};
         if (e0[1] <= e0[0]) { e0[0] = e1[0]; e0[1] = e1[1]; e1[0] = e1[1] = 0; }
         s->k2_parts = 0;
         if (e0[1] > e0[0]) {
-            const int at = timed_begin(s, 1);
+            const int at = timed_begin(s, (s->xk2 && s->xk2_mode == 2) ? 2 : 1);      // (kind 2: a K2 that carries the x update of an x_in_k2 session)
             PG_TRY(op_k2(s, &li, di, part_out, e0[0], e0[1], e1[0], e1[1]));
             timed_end(s, at);
             s->k2_parts = li.grid;
@@ -1022,12 +1079,12 @@ extern "C" int pdegpu_session_k2_part(pdegpu_session* s, int part) {
         PG_TRY(op_k2(s, &dry, di, part_out + s->k2_parts, a0, a1));
         if (s->k2_parts + dry.grid > s->npart)
             return pdegpu_set_err(s->ctx, PDEGPU_EUNSUPPORTED, "split K2: %d + %d workgroups exceed the %d partials of the session", s->k2_parts, dry.grid, s->npart);
-        const int at = timed_begin(s, 1);
+        const int at = timed_begin(s, (s->xk2 && s->xk2_mode == 2) ? 2 : 1);      // (kind 2: a K2 that carries the x update of an x_in_k2 session)
         PG_TRY(op_k2(s, &li, di, part_out + s->k2_parts, a0, a1));
         timed_end(s, at);
         s->k2_parts += li.grid;
     }
-    if (s->timing && s->timing_now) ++s->timed_k2;
+    if (s->timing && s->timing_now) { ++s->timed_k2; if (s->xk2 && s->xk2_mode == 2) ++s->timed_k2x; }
     if (s->variant) {
         s->sr_k2_pending = true;
         s->sr_k2_grid = s->k2_parts;
@@ -1061,7 +1118,7 @@ extern "C" int pdegpu_session_set_timing(pdegpu_session* s, int on) {
     s->timing_iter = 0;
     s->timing_now = false;
     s->tev_used = 0;
-    s->timed_k1 = s->timed_k2 = 0;
+    s->timed_k1 = s->timed_k2 = s->timed_k2x = 0;
     return PDEGPU_OK;
 }
 extern "C" int pdegpu_session_get_stats(pdegpu_session* s, pdegpu_stats* stats) {
@@ -1072,17 +1129,21 @@ extern "C" int pdegpu_session_get_stats(pdegpu_session* s, pdegpu_stats* stats) 
     for (size_t at = 0; at + 1 < s->tev_used; at += 2) {
         float ms = 0;
         PG_HIP(ctx, hipEventElapsedTime(&ms, s->tev[at], s->tev[at + 1]));
-        stats->kernel_ms[s->tev_kind[at / 2] == 0 ? 0 : 1] += ms;
+        const int kind = s->tev_kind[at / 2];
+        stats->kernel_ms[kind == 0 ? 0 : (kind == 2 ? 2 : 1)] += ms;
     }
     const double nloc = (double)s->g.nkl * s->g.NY * s->g.NX;
+    // x_in_k2 sessions: [0] K1 (24 B/DoF), [1] the K2 launches without the x update (24 B/DoF), [2] those with it (40 B/DoF)
     stats->kernel_launches[0] += s->timed_k1;
-    stats->kernel_launches[1] += s->timed_k2;
-    stats->alg_bytes[0] += (k2_is_stencil(s) ? 40.0 : 48.0) * nloc * (double)s->timed_k1;
-    stats->alg_bytes[1] += 24.0 * nloc * (double)s->timed_k2;
+    stats->kernel_launches[1] += s->timed_k2 - s->timed_k2x;
+    stats->kernel_launches[2] += s->timed_k2x;
+    stats->alg_bytes[0] += (s->xk2 ? 24.0 : (k2_is_stencil(s) ? 40.0 : 48.0)) * nloc * (double)s->timed_k1;
+    stats->alg_bytes[1] += 24.0 * nloc * (double)(s->timed_k2 - s->timed_k2x);
+    stats->alg_bytes[2] += 40.0 * nloc * (double)s->timed_k2x;
     stats->cg_iterations += s->timed_k2;
     stats->path = s->hybrid ? 3 : (s->fast ? 1 : 0);
     s->tev_used = 0;
-    s->timed_k1 = s->timed_k2 = 0;
+    s->timed_k1 = s->timed_k2 = s->timed_k2x = 0;
     return PDEGPU_OK;
 }
 
@@ -1125,12 +1186,18 @@ extern "C" int pdegpu_session_reset_cg(pdegpu_session* s) {
     s->pcur = 0;      // the old p only ever meets beta = 0 (see linear_solve)
     s->sr_k2_pending = s->sr_skip_x = false;
     s->rr_slot = SC_RR;
-    return PDEGPU_OK;
+    return xk2_reset(s);
 }
 
 extern "C" int pdegpu_session_flush(pdegpu_session* s) {
     if (!s) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    if (s->xk2) {
+        // x_in_k2: K1 never adds to x, so nothing is pending unless the latest K2 left its update out: x += (its recorded alpha) p
+        if (s->xk2_pending) PG_TRY(vec_axpy_flush(s->ctx, s->g, s->x.v, s->p[s->pcur].v, s->d_xd, 2));
+        s->xk2_pending = false;
+        return PDEGPU_OK;
+    }
     PG_TRY(vec_axpy_flush(s->ctx, s->g, s->x.v, s->p[s->pcur].v, s->d_scal, s->variant));
     // the pending update is applied: make the next K1 skip it (alpha_prev = 0) while beta stays valid
     if (s->variant) s->sr_skip_x = true;          // (beta needs p.Ap too in this form: the block stays, the kernel gets a flag)
@@ -1203,6 +1270,7 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
             d2.part = s->d_part;
             d2.n = l1.grid;
             d2.s_rr = cur;
+            xk2_begin(s);
             if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 2], ctx->stream));
             PG_TRY(op_k2(s, &l2, d2, s->d_part + s->npart));
             if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
@@ -1217,6 +1285,7 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
         PG_TRY(op_k1(s, &l1));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 1], ctx->stream));
         PG_TRY(empty_dot(s, l1, 0));
+        xk2_begin(s);
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 2], ctx->stream));
         PG_TRY(op_k2(s, &l2));
         if (time_kernels) PG_HIP(ctx, hipEventRecord(s->events[4 * it + 3], ctx->stream));
@@ -1238,8 +1307,10 @@ extern "C" int pdegpu_session_iterate(pdegpu_session* s, int iters, int time_ker
             stats->kernel_launches[0] += iters;
             stats->kernel_launches[1] += iters;
             const bool v1 = k2_is_stencil(s);
-            stats->alg_bytes[0] += (v1 ? 40.0 : 48.0) * nloc * iters;   // K1: read r, p, x; write p, (q,) x
-            stats->alg_bytes[1] += 24.0 * nloc * iters;                 // K2: read r, q|p; write r
+            // K1: read r, p, x; write p, (q,) x — x_in_k2: read r, p; write p.  K2: read r, q|p; write r — x_in_k2: every other one also reads
+            // and writes x (this loop runs pairs: iters / 2 of them, the odd one out is of the kind the pending flag says)
+            stats->alg_bytes[0] += (s->xk2 ? 24.0 : (v1 ? 40.0 : 48.0)) * nloc * iters;
+            stats->alg_bytes[1] += 24.0 * nloc * iters + (s->xk2 ? 16.0 * nloc * (iters / 2 + ((iters & 1) && !s->xk2_pending ? 1 : 0)) : 0.0);
         }
     }
     return PDEGPU_OK;
@@ -1532,6 +1603,7 @@ int linear_solve(pdegpu_session* s, bool x_is_lift_only, pdegpu_stats* st) {
     // p of the previous solve is left as it is: with the scalars zeroed the first K1 forms beta = 0 and skips the x-update,
     // so the finite old entries only ever meet a factor 0; they are zero on Dirichlet nodes and pads like every CG vector
     s->pcur = 0;
+    PG_TRY(xk2_reset(s));
     if (!x_is_lift_only) {
         // ||P (b - A g)||: g = Dirichlet values, zero elsewhere (held in q for this pass, result in r)
         PG_TRY(vec_zero(ctx, s->g, &s->q));

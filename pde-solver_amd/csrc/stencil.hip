@@ -259,7 +259,11 @@ __device__ __forceinline__ double2 load_pair_x(const double* p) {
 // the free range of a CG vector (Dirichlet / beyond the grid) need no load at all.
 // PF = 1 (bare apply / residual / stencil K2 only): the loads of plane lk+2 are issued before the stencil of plane lk, so a wave
 // waits for a plane one whole z-step after requesting it (these modes hold one vector, the registers are there).
-template <int NPT, int RY, int MODE, int NT, int EX, int PF>
+// XU (x_in_k2 sessions: the solution vector is updated by K2, every other iteration): K1 — 1 = x += alpha p here (the classic place), 0 = K1 never
+// touches x (24 instead of 40 B/DoF) and records its beta for K2; K2 — 1 = this launch also does x += cx_p p - cx_r r_in (+ cx_o p_other): the
+// pending update of the iteration before (its direction rebuilt from p_n = r_n + beta_n p_{n-1}) together with this iteration's; 0 = no x
+// (a x_in_k2 session's K2 of the iterations in between records its alpha instead).
+template <int NPT, int RY, int MODE, int NT, int EX, int PF, int XU>
 __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     __shared__ double sRed[4];
     __shared__ double sEdge[EX ? 2 : 1][4][RY + 2][2];
@@ -268,6 +272,8 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     constexpr bool K1 = (MODE == APPLY_CG_K1);
     constexpr bool K2 = (MODE == APPLY_CG_K2);
     static_assert(!(PF && MODE == APPLY_CG_K1), "the deeper prefetch is for the one-vector modes");
+    constexpr bool K1X = K1 && XU != 0;        // K1 with the x update
+    constexpr bool K2X = K2 && XU != 0;        // K2 with the x update
     constexpr bool RES = (MODE == APPLY_RESIDUAL) || K2;      // out = rhs - scale * (A in)
     constexpr bool W15 = (NPT == 15) || (NPT == 27);     // every held row of every plane is needed (x-diagonals)
     constexpr bool W27 = (NPT == 27);                     // Q1: all 26 neighbours, weights symmetric under every sign flip
@@ -299,6 +305,23 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
     if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
     if (K2) res_scale = cg_alpha_in(a.di, a.scal, sRed);      // alpha_n = rr_n / (p_n . A p_n)
+    // x_in_k2 sessions (a.xd != nullptr): xd[0] = alpha of the K2 that left its x update out, xd[1] = beta of the latest K1 (slots no workgroup
+    // of the recording launch reads)
+    double cx_p = 0.0, cx_r = 0.0, cx_o = 0.0;                // K2X: x += cx_p p_n - cx_r r_n (+ cx_o p_{n-1} read from the other p buffer)
+    if (K1 && !XU && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[1] = beta;
+    if (K2 && !XU && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[0] = res_scale;
+    if (K2X) {
+        cx_p = res_scale;
+        const double ap = a.xd[0], bn = a.xd[1];
+        if (a.xmode == 2 && ap != 0.0) {                      // make up for the iteration before: p_{n-1} = (p_n - r_n) / beta_n
+            if (bn > 1e-2) {
+                cx_r = ap / bn;
+                cx_p = res_scale + cx_r;
+            } else {
+                cx_o = ap;                                    // (a restart or a tiny beta: p_{n-1} still sits in the other buffer)
+            }
+        }
+    }
     // EX: every wave of a workgroup with work runs the loop (inactive ones with all loads / stores predicated off) so
     // that the barriers match; lk0 / lk1 depend on the workgroup only
     if (EX ? (lk0 < lk1) : active) {
@@ -446,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                 if (j <= fg.jmax && lane_ok) {
                     const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
                     store_pair<NT>(a.p_new + off, pn);
-                    if (alpha_prev != 0.0) {
+                    if (K1X && alpha_prev != 0.0) {
                         xv.x += alpha_prev * po.x;
                         xv.y += alpha_prev * po.y;
                         store_pair<NT>(a.x + off, xv);
@@ -468,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
             EP[r] = 0.0;
             double2 po = make_double2(0.0, 0.0);
             C[r] = value_row(lk0, j, &po);
-            if (K1 && own) own_update(lk0, j, C[r], po, own_xload(lk0, j));
+            if (K1 && own) own_update(lk0, j, C[r], po, K1X ? own_xload(lk0, j) : make_double2(0.0, 0.0));
         }
         double EG[RH], EGp[RH];
         if (W15) {
@@ -520,14 +543,19 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                     PO[r] = make_double2(0.0, 0.0);
                     N[r] = value_row(lk + 1, j, &PO[r]);
                 }
-                if (K1 && lk + 1 < lk1) {
+                if (K1X && lk + 1 < lk1) {
 #pragma unroll
                     for (int r = 0; r < RY; ++r) XV[r] = own_xload(lk + 1, j0 + r);
+                }
+                if (K1 && !XU) {
+#pragma unroll
+                    for (int r = 0; r < RY; ++r) XV[r] = make_double2(0.0, 0.0);
                 }
                 if (!EX) plane_edges(lk + 1, N, EN, W15, EG, EGp);      // global edge loads: issue them with the plane's loads
                 else edge_global(lk + 1, EG, EGp, W15);                 // (EX: the few that no wave of the workgroup can hand over)
             }
             double2 RHS[RY];
+            double2 XK[K2X ? RY : 1], PO2[K2X ? RY : 1];      // K2X: the x rows of plane lk (and, after a restart only, the other buffer's p rows)
             if (RES) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
@@ -536,6 +564,13 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                     if (a.rhs) {                                   // kernel-uniform; the load itself is unconditional (see value_row)
                         const bool ok = j <= fg.jmax && lane_ok;
                         RHS[r] = load_pair_x<NT>(a.rhs + (ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0));      // read once: streaming hint
+                    }
+                    if (K2X) {
+                        const bool ok = j <= fg.jmax && lane_ok;
+                        const long long off = ok ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0;
+                        XK[r] = load_pair_x<NT>(a.x + off);
+                        PO2[r] = make_double2(0.0, 0.0);
+                        if (cx_o != 0.0) PO2[r] = load_pair(a.p_old, off);      // kernel-uniform, rare
                     }
                 }
             }
@@ -613,6 +648,13 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
                         if (K1) acc2 += o.x * o.x + o.y * o.y;
                     }
                     if (lane_ok && (!K1 || a.out)) store_pair<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
+                    if (K2X && lane_ok) {
+                        // x += alpha_n p_n (+ the update the K2 before left out): p_n = C, r_n = RHS — both vanish on Dirichlet nodes and pads
+                        double2 xv = XK[r];
+                        xv.x += cx_p * C[c].x - cx_r * RHS[r].x + cx_o * PO2[r].x;
+                        xv.y += cx_p * C[c].y - cx_r * RHS[r].y + cx_o * PO2[r].y;
+                        store_pair<NT>(a.x + (long long)lk * g.PP + (long long)j * g.PX + i0, xv);
+                    }
                 }
             }
 
@@ -1072,10 +1114,10 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
         int nb = 0;
         hipError_t e = hipSuccess;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>, 256, 0); break;
-            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF, 0>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF, 0>, 256, 0); break;
+            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF, 1>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0, 1>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
         if (nb > 8) nb = 8;
@@ -1106,11 +1148,18 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
         }
     }
     if (G == 0 || (li && li->dry)) return PDEGPU_OK;
+    const bool k2x = a.x_in_k2 && a.xmode == 2, k1x = !a.x_in_k2;
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        case APPLY_CG_K2: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
-        default: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_PLAIN, NT, EX, PF, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_RESIDUAL, NT, EX, PF, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg); break;
+        case APPLY_CG_K2:
+            if (k2x) hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF, 1>), dim3(G), dim3(256), 0, ctx->stream, a, fg);
+            else hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K2, NT, EX, PF, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg);
+            break;
+        default:
+            if (k1x) hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0, 1>), dim3(G), dim3(256), 0, ctx->stream, a, fg);
+            else hipLaunchKernelGGL((k_fast<NPT, RY, APPLY_CG_K1, NT, EX, 0, 0>), dim3(G), dim3(256), 0, ctx->stream, a, fg);
+            break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void k_norm2(const double2* __restrict__ a, lo
 __global__ __launch_bounds__(256) void k_flush(double2* __restrict__ x, const double2* __restrict__ p, long long n2,
                                                 const double* __restrict__ scal, int sr) {
     const double pq = scal[SC_PQ], rr_prev = scal[sr ? SC_RR : SC_RR_PREV];       // (single-reduction form: the block holds r_n.r_n, p_n.Ap_n)
-    const double alpha = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
+    double alpha = (pq > 0.0 && rr_prev > 0.0) ? rr_prev / pq : 0.0;
+    if (sr == 2) alpha = scal[0];                 // x_in_k2 sessions: scal = {alpha the latest K2 recorded, ...}
     if (alpha == 0.0) return;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long long)gridDim.x * 256) {
         double2 xv = x[e];

@@ -772,7 +772,7 @@ def test_2d_tile_kernel_and_flat_view_agree(lib, gpu_ctx, steady, em):
                                      dict(extrapolate=0), dict(hybrid_bc=0), dict(hybrid_fx=0), dict(hybrid_k2=0), dict(fast_minlen=4), dict(fast_small_mult=4),
                                      dict(cg_variant=0), dict(cg_variant=2), dict(cg_variant=0, fast_ex=0, fast_ry=4), dict(fast_pf=1), dict(fast_pf=0),
                                      dict(fast_pf=1, fast_ry=4), dict(fast_zlen=3), dict(tile3d_max_nodes=0),
-                                     dict(fast_linear=0), dict(place_tune=0),
+                                     dict(fast_linear=0), dict(place_tune=0), dict(cg_xdefer=0), dict(cg_xdefer=0, cg_variant=2),
                                      # per-mode configuration words: ry + 16 wg + 256 ex + 512 pf
                                      dict(fast_cfg_plain=4 + 16 * 2 + 512, fast_cfg_res=2 + 256 + 512, fast_cfg_k1=4 + 16 * 3 + 256, fast_cfg_k2=1 + 16 + 512)])
 def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kernel_form):
@@ -781,7 +781,7 @@ def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kerne
     from pdegpu import heat, _lib
     defaults = dict(fast_ry=0, fast_nt=-1, fast_ex=1, fast_wg_per_cu=0, fast_wg_per_cu_k2=0, grid_mult=8, k2_grid_mult=2, extrapolate=1,
                     hybrid_bc=1, hybrid_fx=1, hybrid_k2=1, fast_minlen=1, fast_small_mult=1, cg_variant=1, fast_pf=-1, fast_zlen=0, tile3d_max_nodes=3000000,
-                    fast_cfg_plain=-1, fast_cfg_res=-1, fast_cfg_k1=-1, fast_cfg_k2=-1, fast_linear=1, place_tune=1)
+                    fast_cfg_plain=-1, fast_cfg_res=-1, fast_cfg_k1=-1, fast_cfg_k2=-1, fast_linear=1, place_tune=1, cg_xdefer=1)
     def runs():
         a = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 140, 13, 11, 0.9, 1.5, 20.0, 0.003, 1, steady=True, source_type="constant", source_value=2.0, rtol=1e-12)
         b = heat._solve_heat_3d_raw(1.0, 0.8, 0.6, 30, 17, 12, 0.9, 1.5, 20.0, 0.003, 3, rtol=1e-12)
@@ -895,3 +895,53 @@ def test_persistent_2d_cg_session_iterate_leaves_the_state_of_the_stepwise_loop(
             lib.pdegpu_session_destroy(s)
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", 1))
     assert np.allclose(out[0][0], out[1][0], rtol=1e-10) and rel_err(out[0][1], out[1][1]) < 1e-12
+
+
+@pytest.mark.parametrize("cells", [(140, 13, 11), (300, 40, 37)])
+def test_solution_vector_updated_by_every_other_k2_is_the_plain_iterate(lib, gpu_ctx, cells):
+    """cg_xdefer (marching sessions in the 64 B/DoF form): K1 leaves x alone; K2 updates it for two iterations at once, every other time, with the
+    direction of the iteration before rebuilt from p_n = r_n + beta_n p_(n-1); flush makes up for an odd last iteration.  After n = 1 ... 9
+    iterations + flush, x must be the iterate of the plain scheme (x += alpha p in the next K1) — through the native loop, the stepwise classic
+    protocol and the stepwise single-reduction protocol"""
+    import ctypes as C
+    from pdegpu import _lib
+    grid = _lib.make_grid(3, cells, (1.0, 0.9, 0.7))
+    nodes = (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+
+    def run(xdefer, n, protocol):
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_xdefer", xdefer))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 0))      # the marching kernels on the small grid too
+        h = _lib.Heat()
+        h.kappa, h.dt, h.steady, h.source = 1.0, 1.0, 1, 1.0
+        h.bc_mode, h.fast_path = _lib.BC_UNIFORM, 1
+        h.bc_present[0], h.bc_value[0] = 1, 0.5
+        s = C.c_void_p()
+        _lib.check(gpu_ctx, lib.pdegpu_session_create(gpu_ctx, grid, h, 0, cells[2] + 1, C.byref(s)))
+        try:
+            if protocol == "sr":
+                _lib.check(gpu_ctx, lib.pdegpu_session_set_cg_variant(s, 1))
+            _lib.check(gpu_ctx, lib.pdegpu_session_begin(s, 0.25))
+            _lib.check(gpu_ctx, lib.pdegpu_session_residual(s))
+            _lib.check(gpu_ctx, lib.pdegpu_session_reduce_local(s, 1, 1))
+            if protocol == "native":
+                _lib.check(gpu_ctx, lib.pdegpu_session_iterate(s, n, 0, None))
+            else:
+                for _ in range(n):
+                    _lib.check(gpu_ctx, lib.pdegpu_session_k1(s))
+                    _lib.check(gpu_ctx, lib.pdegpu_session_k2(s))
+            _lib.check(gpu_ctx, lib.pdegpu_session_flush(s))
+            x = np.empty(nodes)
+            _lib.check(gpu_ctx, lib.pdegpu_session_get_x(s, _lib.dptr(x)))
+            return x
+        finally:
+            lib.pdegpu_session_destroy(s)
+
+    try:
+        for protocol in ("native", "classic", "sr"):
+            for n in (1, 2, 3, 4, 5, 9):
+                a, b = run(1, n, protocol), run(0, n, protocol)
+                assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (protocol, n)
+            assert np.abs(run(0, 9, protocol) - run(0, 3, protocol)).max() > 1e-6      # (the iterations do move x)
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_xdefer", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 3000000))

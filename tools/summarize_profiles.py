@@ -69,6 +69,12 @@ if k1:
     (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "source": f"{rnd}{tag}_pmc_summary.json", "commit": commit}))
 k2 = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 3[,>]", k)]
 if k1 and k2:
-    (out / "pmc_latest.json").write_text(json.dumps({"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "k2_hbm_bytes_per_launch": k2[0]["hbm_bytes"],
-                                                      "source": f"{rnd}{tag}_pmc_summary.json", "commit": commit}))
+    latest = {"k1_hbm_bytes_per_launch": k1[0]["hbm_bytes"], "k2_hbm_bytes_per_launch": k2[0]["hbm_bytes"], "source": f"{rnd}{tag}_pmc_summary.json", "commit": commit}
+    # sessions whose K2 carries the x update of every other iteration launch two instantiations of K2 (template XU = 0 | 1)
+    k2x = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 3, \d+, \d+, \d+, 1>", k)]
+    k2n = [v for k, v in summary["kernels"].items() if re.search(r"k_fast<7, \d+, 3, \d+, \d+, \d+, 0>", k)]
+    if k2x and k2n:
+        latest["k2_hbm_bytes_per_launch"] = k2n[0]["hbm_bytes"]
+        latest["k2_with_x_hbm_bytes_per_launch"] = k2x[0]["hbm_bytes"]
+    (out / "pmc_latest.json").write_text(json.dumps(latest))
 print(json.dumps(summary, indent=1)[:3000])
