@@ -707,7 +707,8 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
         done(extras)
     if world == 1:
         # the system of a backward-Euler step (fenics_mcp_server.py:702-716): A = M + dt kappa K, 15-point on the Kuhn split — bare SpMV and the CG
-        # iteration (K1 stores q there: 72 B/DoF; the second stencil pass of the 64-byte form costs more than it saves with 15 points)
+        # iteration (K2 applies the stencil to the stored p again and carries the x update of every other iteration: 56 B/DoF; cg_xdefer = 0: K1
+        # stores q, 72 B/DoF)
         try:
             c5 = dict(case)
             c5.update(transient_dt=0.0025, spmv=True)
@@ -716,9 +717,9 @@ def run_extras_guarded(R, args, case, out, ms_per_step):
             sp = r5["spmv_ms"]
             extras["transient_step_system"] = {
                 "what": "same grid, A = M + dt kappa K with dt = 0.0025 (one backward-Euler step of the reference's default transient solve): "
-                        "15-point stencil; CG iteration = K1 (48 B/DoF, q stored) + K2 (24 B/DoF)",
+                        "15-point stencil; CG iteration = K1 (%d B/DoF) + K2 (%.0f B/DoF on average)" % (r5["k1_per_dof"], r5.get("k2_per_dof", 24.0)),
                 "steps": st5, "value": r5["unknowns"] * st5 / r5["elapsed"], "unit": "DoF/s", "ms_per_step": r5["elapsed"] / st5 * 1e3,
-                "k1_ms": r5["k1_ms"], "k2_ms": r5["k2_ms"], "k1_bytes_per_dof": r5["k1_per_dof"],
+                "k1_ms": r5["k1_ms"], "k2_ms": r5["k2_ms"], "k1_bytes_per_dof": r5["k1_per_dof"], "k2_bytes_per_dof": r5.get("k2_per_dof", 24.0), "k2_forms": r5.get("k2_forms"),
                 "k1_frac": float(r5["k1_per_dof"]) * r5["unknowns"] / (r5["k1_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "spmv_15pt": {"avg_ms": sp, "achieved": 16.0 * r5["unknowns"] / (sp * 1e-3) / 1e9,
                               "frac": 16.0 * r5["unknowns"] / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS}, "rr_after": r5["rr_after"]}

@@ -130,7 +130,8 @@ const char* pdegpu_version(void);
  * key                | default | meaning
  * -------------------+---------+----------------------------------------------------------------------------------------------
  * heat, z-marching kernels (3-D; 2-D through the flat view)
- * fast_ry            | 0       | rows per thread (1|2|4|8); 0 = 4 for the bare apply / residual pass, 2 for the CG kernels
+ * fast_ry            | 0       | rows per thread (1|2|4|8); 0 = 4 for the bare apply / residual pass and the K1 that leaves x alone (cg_xdefer),
+ *                    |         | 2 for the other CG kernels
  * fast_nt            | -1      | non-temporal hints: bit 0 stores, bit 1 loads of x; -1 = both where a slab vector exceeds 64 MiB
  * fast_ex            | 1       | CG kernels hand tile-edge x-neighbours between the workgroup's waves through LDS
  * fast_pf            | -1      | deeper prefetch (plane k+2 requested before plane k is computed): -1 = bare apply / residual pass,
@@ -142,8 +143,9 @@ const char* pdegpu_version(void);
  * fast_minlen        | 1       | shortest z-chunk on grids too small to fill the device
  * fast_small_mult    | 1       | resident rounds of workgroups such grids may launch
  * fast_cfg_plain|res|k1|k2 | -1 | per-mode word ry + 16 wg_per_cu + 256 ex + 512 pf; -1 = the global tunables
- * cg_variant         | 1       | 1 = K2 applies the marching stencil to the stored p again (64 B/DoF, 7-point operator); 2 = also for
- *                    |         | the 15-point operator of transient runs; 0 = K1 stores q, flat K2 (72 B/DoF)
+ * cg_variant         | 1       | 1 = K2 applies the marching stencil to the stored p again (64 B/DoF; 56 with cg_xdefer): the 7-point operator, and
+ *                    |         | the 15-point operator of transient runs on pure marching sessions with cg_xdefer; 2 = the 15-point operator
+ *                    |         | everywhere; 0 = K1 stores q, flat K2 (72 B/DoF)
  * cg_xdefer          | 1       | marching sessions in the 64 B/DoF form: the solution vector is updated by K2 (which holds p_n, r_n and alpha_n) instead
  *                    |         | of the next K1, and only by every other K2 — the one in between records its alpha, the next forms both updates
  *                    |         | with p_(n-1) = (p_n - r_n) / beta_n.  K1 24 B/DoF, K2 24 | 40 B/DoF: 56 instead of 64 B/DoF per iteration

@@ -1132,6 +1132,8 @@ int launch_fast(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li)
     int slack8 = 0;
     if (mc.wg >= 1 && mc.wg <= 16) wg_per_cu = mc.wg;
     else if (hbm) { wg_per_cu = 2; slack8 = 1; }
+    // (a K1 that leaves x alone streams what the stencil-K2 streams — two vectors read, one written — but K2's chunk policy does not suit it better
+    // than its own: measured over 16 cube sizes, round 4)
     FastGeom fg = fast_geom(ctx, a.g, RY, wg_per_cu, mode, a.lk_lo, a.lk_hi, slack8, res_occ * ctx->num_cu, a.lk_lo2, a.lk_hi2);
     // a multiple of 8 workgroups, so that the XCD-aware tile order of the kernel always applies (the surplus ones find zc >= nzc and idle;
     // 701 nodes per row: 525 workgroups -> 528)
@@ -1305,9 +1307,13 @@ GridDev stencil_flat2d_view(const GridDev& g) {
 }
 
 // rows per thread of a marching launch (7- / 15-point operator; Q1 is fixed at 2)
-static int fast_rows(const pdegpu_ctx* ctx, const GridDev& g, int npt, int mode) {
+static int fast_rows(const pdegpu_ctx* ctx, const GridDev& g, int npt, int mode, int x_in_k2 = 0) {
     const bool hbm = (long long)g.nkl * g.PP * 8 > (64LL << 20);
     int ry = mode_cfg(ctx, mode).ry;
+    // a K1 that leaves the solution vector alone (x_in_k2 sessions) holds two vectors instead of three per row: with 4 rows per thread (182 VGPRs; 212 with
+    // 15 points; half the halo rows per owned row) it is faster at every cube from 256 to 1024 cells but 512, where it is the same (7 points: K1
+    // 0.59-0.69 -> 0.62-0.72 of the HBM peak, 448^3 +3 %, 640^3 +4 % per iteration in one process; 15 points at 512^3: 0.613 -> 0.555 ms)
+    if (mode == APPLY_CG_K1 && x_in_k2 && ctx->fast_ry == 0 && ctx->fast_cfg[mode & 3] < 0 && (npt == 7 || npt == 15) && g.dim == 3 && !g.flat2d && hbm) ry = 4;
     // stencil-K2 with 4 rows per thread: only where that makes ONE resident round of (almost) exactly two workgroups per CU and 2 rows do not
     // (1024^3: 8 tiles x 256 row tiles / 4 = 512 workgroups, K2 0.757 of the HBM peak against 0.644 with many chunks of 2-row tiles; at
     // 832^3 / 896^3 / 960^3, where neither fits, 2 rows win by 2-10 % under the fitted chunk policy: profiles/r02_ab_k2_rows.log)
@@ -1328,7 +1334,7 @@ static int fast_rows(const pdegpu_ctx* ctx, const GridDev& g, int npt, int mode)
 int stencil_fast(pdegpu_ctx* ctx, const StencilArgs& a_in, int mode, LaunchInfo* li) {
     StencilArgs a = a_in;
     if (a.npt == 27) return launch_fast_nt<27, 2>(ctx, a, mode, li);        // Q1: rows per thread fixed at 2
-    const int ry = fast_rows(ctx, a.g, a.npt, mode);
+    const int ry = fast_rows(ctx, a.g, a.npt, mode, a.x_in_k2);
     if (a.npt == 7) {
         if (ry == 1) return launch_fast_nt<7, 1>(ctx, a, mode, li);
         if (ry == 2) return launch_fast_nt<7, 2>(ctx, a, mode, li);
@@ -1360,7 +1366,7 @@ extern "C" int pdegpu_marching_geometry(int num_cu, int nx_nodes, int ny_nodes, 
     g.k0 = 0;
     g.bc_mode = PDEGPU_BC_UNIFORM;
     g.bc_present[0] = 1;
-    const int ry = fast_rows(&c, g, 7, mode);
+    const int ry = fast_rows(&c, g, 7, mode, c.cg_xdefer != 0);      // (the default configuration: K1 leaves the solution vector to K2)
     const bool hbm = (long long)g.nkl * g.PP * 8 > (64LL << 20);
     const ModeCfg mc = mode_cfg(&c, mode);
     int wg = resident_wg_per_cu, slack8 = 0;

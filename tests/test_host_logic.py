@@ -348,17 +348,21 @@ def _geom(lib, nodes, mode, occ={0: 2, 1: 2, 2: 3, 3: 4}, cus=256):
 def test_marching_geometry_of_the_baseline_grids_is_pinned(lib):
     """The z-chunk policy of the marching kernels is FITTED to sweeps (profiles/r02_exp16_chunk_count_sweep.log); this pins what it
     must give on BASELINE's grids so that a re-fit cannot silently move the headline geometry (host-only entry point, no GPU):
-    configs[2] 512^3: one resident round of 2 x 256 = 512 workgroups in both CG kernels, 4 x 128 (4 rows per thread) in the bare SpMV;
+    configs[2] 512^3: one resident round of 512 workgroups in both CG kernels — 2 x 256 (2 rows per thread) in the stencil K2, 4 x 128 (4 rows
+    per thread) in K1, which leaves the solution vector to K2 in the default configuration, and in the bare SpMV;
     configs[3] 1024x512x512 on one GPU and on 2 / 4 / 8 slabs across the long axis: the same 512 workgroups, longer or shorter chunks."""
-    for mode in (2, 3):
-        g = _geom(lib, (513, 513, 513), mode)
-        assert (g["ry"], g["wg_per_chunk"], g["chunks"], g["planes"]) == (2, 256, 2, 256), g
+    g = _geom(lib, (513, 513, 513), 3)
+    assert (g["ry"], g["wg_per_chunk"], g["chunks"], g["planes"]) == (2, 256, 2, 256), g
+    g = _geom(lib, (513, 513, 513), 2)
+    assert (g["ry"], g["wg_per_chunk"], g["chunks"], g["planes"]) == (4, 128, 4, 128), g
     g = _geom(lib, (513, 513, 513), 0)
     assert (g["ry"], g["wg_per_chunk"], g["chunks"]) == (4, 128, 4), g
     for planes in (1025, 513, 257, 129):
         g = _geom(lib, (513, 513, planes), 2)
-        assert (g["ry"], g["wg_per_chunk"], g["chunks"]) == (2, 256, 2), (planes, g)
+        assert (g["ry"], g["wg_per_chunk"], g["chunks"]) == (4, 128, 4), (planes, g)
         assert g["chunks"] * g["planes"] >= planes - 2 > (g["chunks"] - 1) * g["planes"]
+        g = _geom(lib, (513, 513, planes), 3)
+        assert (g["ry"], g["wg_per_chunk"], g["chunks"]) == (2, 256, 2), (planes, g)
 
 
 def test_marching_geometry_away_from_512_uses_many_chunks_or_a_fitting_round(lib):
@@ -368,7 +372,7 @@ def test_marching_geometry_away_from_512_uses_many_chunks_or_a_fitting_round(lib
         g = _geom(lib, (n + 1,) * 3, 2)
         W = g["wg_per_chunk"] * g["chunks"]
         assert W >= 4 * 512 and 24 <= g["planes"] <= 160, (n, g)
-    for n, fit in ((320, 480), (384, 432), (448, 448), (480, 480)):
+    for n, fit in ((320, 480), (384, 504), (448, 448), (480, 480)):      # K1 (4 rows per thread): a round of at most 2 workgroups per CU
         g = _geom(lib, (n + 1,) * 3, 2)
         assert g["wg_per_chunk"] * g["chunks"] == fit, (n, g)
     g = _geom(lib, (1025,) * 3, 3)                  # stencil-K2 at 8 tiles per row: 4 rows make the one fitting round

@@ -24,5 +24,7 @@ for n in sizes:
     st = L.Stats()
     L.check(ctx, lib.pdegpu_session_iterate(s, 20, 1, st))
     k1, k2 = st.kernel_ms[0] / 20, st.kernel_ms[1] / 20
-    print(f"n={n:4d}: K1 {k1:.4f} ms ({40*N/k1/8e9:.3f})  K2 {k2:.4f} ms ({24*N/k2/8e9:.3f})  SpMV {ms.value:.4f} ms ({16*N/ms.value/8e9:.3f})  -> {N/(k1+k2)/1e6:.1f} GDoF/s", flush=True)
+    nodes = (n + 1) ** 3
+    b1, b2 = st.alg_bytes[0] / 20 / nodes, st.alg_bytes[1] / 20 / nodes      # algorithmic B/DoF of K1 / of K2 (average over its two forms where K2 updates x)
+    print(f"n={n:4d}: K1 {k1:.4f} ms ({b1:.0f} B/DoF, {b1*N/k1/8e9:.3f})  K2 {k2:.4f} ms ({b2:.0f} B/DoF, {b2*N/k2/8e9:.3f})  SpMV {ms.value:.4f} ms ({16*N/ms.value/8e9:.3f})  -> {N/(k1+k2)/1e6:.1f} GDoF/s", flush=True)
     lib.pdegpu_session_destroy(s)
