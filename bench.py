@@ -435,7 +435,7 @@ def roofline_of(res, general):
     if general:
         k1_name = "k_general<CG_K1>"
     elif x_in_k2:
-        k1_name = "k_fast<7,2,CG_K1,nt,ex,xu=0> (p=r+b*p; q=A p [not stored]; p.q — x is updated by K2, every other iteration)"
+        k1_name = "k_fast<7,4,CG_K1,nt,ex,xu=0> (p=r+b*p; q=A p [not stored]; p.q — x is updated by K2, every other iteration)"
     else:
         k1_name = "k_fast<7,2,CG_K1,nt,ex> (x+=a*p; p=r+b*p; q=A p [not stored]; p.q)"
     others = []

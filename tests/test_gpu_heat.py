@@ -945,3 +945,45 @@ def test_solution_vector_updated_by_every_other_k2_is_the_plain_iterate(lib, gpu
     finally:
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_xdefer", 1))
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 3000000))
+
+
+def test_stepwise_timing_tells_the_two_forms_of_k2_apart(lib, gpu_ctx):
+    """pdegpu_stats of a session whose K2 carries the x update of every other iteration (cg_xdefer): [0] K1 at 24 B per node, [1] the K2 launches
+    without the update at 24, [2] those with it at 40 — what bench.py's roofline block is computed from; with cg_xdefer = 0: [0] 40, [1] 24, [2] empty"""
+    import ctypes as C
+    from pdegpu import _lib
+    cells = (140, 20, 18)
+    nodes = (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+    grid = _lib.make_grid(3, cells, (1.0, 0.9, 0.7))
+    try:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 0))
+        for xdefer in (1, 0):
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_xdefer", xdefer))
+            h = _lib.Heat()
+            h.kappa, h.dt, h.steady, h.source = 1.0, 1.0, 1, 1.0
+            h.bc_mode, h.fast_path = _lib.BC_UNIFORM, 1
+            h.bc_present[0] = 1
+            s = C.c_void_p()
+            _lib.check(gpu_ctx, lib.pdegpu_session_create(gpu_ctx, grid, h, 0, cells[2] + 1, C.byref(s)))
+            try:
+                _lib.check(gpu_ctx, lib.pdegpu_session_set_cg_variant(s, 1))
+                _lib.check(gpu_ctx, lib.pdegpu_session_begin(s, 0.0))
+                _lib.check(gpu_ctx, lib.pdegpu_session_residual(s))
+                _lib.check(gpu_ctx, lib.pdegpu_session_set_timing(s, 1))
+                for _ in range(7):
+                    _lib.check(gpu_ctx, lib.pdegpu_session_k1(s))
+                    _lib.check(gpu_ctx, lib.pdegpu_session_k2(s))
+                st = _lib.Stats()
+                _lib.check(gpu_ctx, lib.pdegpu_session_get_stats(s, st))
+            finally:
+                lib.pdegpu_session_destroy(s)
+            per = [st.alg_bytes[k] / max(1, st.kernel_launches[k]) / nodes for k in range(3)]
+            if xdefer:
+                assert [st.kernel_launches[k] for k in range(3)] == [7, 4, 3] and per == [24.0, 24.0, 40.0], (list(st.kernel_launches), per)
+                assert st.kernel_ms[0] > 0 and st.kernel_ms[1] > 0 and st.kernel_ms[2] > 0
+            else:
+                assert [st.kernel_launches[k] for k in range(3)] == [7, 7, 0] and per[:2] == [40.0, 24.0], (list(st.kernel_launches), per)
+            assert st.cg_iterations == 7
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_xdefer", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 3000000))
