@@ -72,6 +72,24 @@ __device__ __forceinline__ double cg_alpha_in(const DotIn& di, double* scal, dou
     return (pq > 0.0) ? rr / pq : 0.0;
 }
 
+// x_in_k2 sessions (StencilArgs::x_in_k2): the K2 that carries the x update does  x += cx_p p_n - cx_r r_n + cx_o p_{n-1}  — this iteration's
+// alpha_n p_n and, when the K2 before left its update out (xmode 2, its alpha in xd[0]), that one too, with p_{n-1} = (p_n - r_n) / beta_n rebuilt
+// from K1's p_n = r_n + beta_n p_{n-1} (beta_n in xd[1]); a restart or a tiny beta cannot rebuild it: cx_o then takes p_{n-1} from the other p buffer
+__device__ __forceinline__ void xk2_coefficients(const double* xd, int xmode, double alpha, double* cx_p, double* cx_r, double* cx_o) {
+    *cx_p = alpha;
+    *cx_r = 0.0;
+    *cx_o = 0.0;
+    const double ap = xd[0], bn = xd[1];
+    if (xmode == 2 && ap != 0.0) {
+        if (bn > 1e-2) {
+            *cx_r = ap / bn;
+            *cx_p = alpha + *cx_r;
+        } else {
+            *cx_o = ap;
+        }
+    }
+}
+
 // block_total is valid in thread 0: one partial per workgroup.
 __device__ __forceinline__ void dot_finish(double block_total, double* partials) {
     if (threadIdx.x == 0) partials[blockIdx.x] = block_total;

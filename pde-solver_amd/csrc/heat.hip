@@ -367,7 +367,8 @@ bool k2_is_stencil(const pdegpu_session* s) {
 
 // x_in_k2: pure marching sessions (no boundary launch, no tile forms, no weights) in the 64 B/DoF form
 bool xk2_eligible(const pdegpu_session* s) {
-    return s->ctx->cg_xdefer != 0 && s->d_xd && k2_is_stencil(s) && s->fast && !s->hybrid && !s->tile3d && !s->plane2d && !s->weighted && !s->wfast;
+    // (hybrid sessions: both launches of K1 and of K2 — marching kernel and boundary pass — follow the same protocol)
+    return s->ctx->cg_xdefer != 0 && s->d_xd && k2_is_stencil(s) && s->fast && !s->tile3d && !s->plane2d && !s->weighted && !s->wfast;
 }
 // before the K2 launch(es) of an iteration: leave x out (and record alpha) or update it for this iteration and the one before, alternating
 void xk2_begin(pdegpu_session* s) {

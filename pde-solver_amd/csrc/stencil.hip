@@ -66,6 +66,13 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
     double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
     if (MODE == APPLY_CG_K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);
     if (MODE == APPLY_CG_K2) res_scale = cg_alpha_in(a.di, a.scal, sRed);      // r -= alpha A p on the boundary nodes of a hybrid session
+    // x_in_k2 sessions (hybrid: this is the boundary launch next to the marching one, which records the same two scalars): K1 leaves x alone, the
+    // K2 of every other iteration updates it for two iterations at once (see k_fast, dot_finish.h)
+    const bool k2x = MODE == APPLY_CG_K2 && a.x_in_k2 && a.xmode == 2;
+    double cx_p = 0.0, cx_r = 0.0, cx_o = 0.0;
+    if (MODE == APPLY_CG_K1 && a.x_in_k2 && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[1] = beta;
+    if (MODE == APPLY_CG_K2 && a.x_in_k2 && !k2x && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[0] = res_scale;
+    if (k2x) xk2_coefficients(a.xd, a.xmode, res_scale, &cx_p, &cx_r, &cx_o);
 
     double acc = 0.0, acc2 = 0.0;                              // acc2 (K1): (A p).(A p) of the single-reduction form
     for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += (long long)gridDim.x * 256) {
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
             const bool theirs = bnd && j >= 1 && j <= g.NY - 2 && kg >= 1 && kg <= g.NZ - 2 && i < a.bnd_xcover;
             if (!theirs) {
                 a.p_new[idx] = pn;
-                if (alpha_prev != 0.0) a.x[idx] += alpha_prev * po;
+                if (!a.x_in_k2 && alpha_prev != 0.0) a.x[idx] += alpha_prev * po;
             }
         }
         // Neighbour loads are unconditional and separated from their use: every neighbour address of every index of the slab lies
@@ -187,7 +194,17 @@ __global__ __launch_bounds__(256) void k_general(StencilArgs a) {
             if (real) acc += a.in[idx] * s;
         } else if (MODE == APPLY_RESIDUAL || MODE == APPLY_CG_K2) {
             double rv = 0.0;
-            if (real && !dir) rv = (a.rhs ? a.rhs[idx] : a.rhs_const) - res_scale * s;
+            const double r_in = a.rhs ? a.rhs[idx] : a.rhs_const;
+            if (real && !dir) rv = r_in - res_scale * s;
+            if (k2x) {
+                // the nodes whose p / x this launch owns (as in K1): p_n and r_n vanish on Dirichlet nodes and pads, which then keep their x
+                const bool theirs = bnd && j >= 1 && j <= g.NY - 2 && kg >= 1 && kg <= g.NZ - 2 && i < a.bnd_xcover;
+                if (!theirs && real) {
+                    double xv = a.x[idx] + cx_p * a.in[idx] - cx_r * r_in;
+                    if (cx_o != 0.0) xv += cx_o * a.p_old[idx];
+                    a.x[idx] = xv;
+                }
+            }
             a.out[idx] = rv;
             acc += rv * rv;
         } else {
@@ -310,18 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_fast(StencilArgs a, FastGeom fg) {
     double cx_p = 0.0, cx_r = 0.0, cx_o = 0.0;                // K2X: x += cx_p p_n - cx_r r_n (+ cx_o p_{n-1} read from the other p buffer)
     if (K1 && !XU && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[1] = beta;
     if (K2 && !XU && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[0] = res_scale;
-    if (K2X) {
-        cx_p = res_scale;
-        const double ap = a.xd[0], bn = a.xd[1];
-        if (a.xmode == 2 && ap != 0.0) {                      // make up for the iteration before: p_{n-1} = (p_n - r_n) / beta_n
-            if (bn > 1e-2) {
-                cx_r = ap / bn;
-                cx_p = res_scale + cx_r;
-            } else {
-                cx_o = ap;                                    // (a restart or a tiny beta: p_{n-1} still sits in the other buffer)
-            }
-        }
-    }
+    if (K2X) xk2_coefficients(a.xd, a.xmode, res_scale, &cx_p, &cx_r, &cx_o);
     // EX: every wave of a workgroup with work runs the loop (inactive ones with all loads / stores predicated off) so
     // that the barriers match; lk0 / lk1 depend on the workgroup only
     if (EX ? (lk0 < lk1) : active) {
