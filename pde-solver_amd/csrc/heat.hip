@@ -361,7 +361,8 @@ bool k2_is_stencil(const pdegpu_session* s) {
     // the 15-point operator (transient steps): the second stencil pass costs about what the 8 B/DoF of q save (1.535 vs 1.555 ms at 512^3) — but it is
     // what lets K2 carry the x update of every other iteration (cg_xdefer: 56 instead of 72 B/DoF, 81.9 -> 98.6 GDoF/s; natural-face sessions
     // 82.8 -> 92.5 / 79.4 -> 85.7), so marching sessions take it by default; the tile forms keep the stored q unless cg_variant = 2 asks
-    const bool march15 = s->npt == 15 && s->ctx->cg_xdefer != 0 && !s->tile3d && !s->plane2d && !s->weighted;
+    // (the 27-point operator of the Q1 element mode alike: its K1 stored q too)
+    const bool march15 = (s->npt == 15 || s->npt == 27) && s->ctx->cg_xdefer != 0 && !s->tile3d && !s->plane2d && !s->weighted;
     return s->fast && (!s->hybrid || hyb_ok) && ((s->ctx->cg_variant == 1 && (s->npt == 7 || march15)) || (s->ctx->cg_variant == 2 && (s->npt == 7 || s->npt == 15)));
 }
 

@@ -24,7 +24,7 @@ for em, name in ((L.ELEM_Q1, "Q1 27-point"), (L.ELEM_P1SPLIT, "P1 split")):
             L.check(ctx, lib.pdegpu_session_iterate(s, 20, 1, st))
             ms = C.c_double(); L.check(ctx, lib.pdegpu_session_time_apply(s, 20, C.byref(ms)))
             k1, k2 = st.kernel_ms[0] / 20, st.kernel_ms[1] / 20
-            per = st.alg_bytes[0] / 20 / ((n + 1) ** 3) + 24
+            per = (st.alg_bytes[0] + st.alg_bytes[1]) / 20 / ((n + 1) ** 3)      # K1 + K2 (the average of K2's two forms where it carries the x update)
             print(f"{name} steady={steady} fast={fast}: K1 {k1:.3f} ms  K2 {k2:.3f} ms -> {N/(k1+k2)/1e6:.1f} GDoF/s ({per:.0f} B/DoF: {per*N/(k1+k2)/1e6:.0f} GB/s); "
                   f"SpMV {ms.value:.3f} ms = {16*N/ms.value/1e6:.0f} GB/s", flush=True)
             lib.pdegpu_session_destroy(s)
