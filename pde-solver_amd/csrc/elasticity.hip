@@ -1184,6 +1184,17 @@ __global__ __launch_bounds__(256) void k_el_flush(ElArgs a, const double* __rest
         for (int c = 0; c < D; ++c) a.x[c * a.stride + idx] += alpha * p[c * a.stride + idx];
 }
 
+// el_xdefer: the x += alpha p_old an update pass left out (recorded in the scalars), applied on its own — where the loop stops between two passes
+template <int D>
+__global__ __launch_bounds__(256) void k_el_xflush(ElArgs a, const double* __restrict__ p) {
+    if (a.scal[ESC_XD_FLAG] == 0.0) return;
+    const double alpha = a.scal[ESC_XD_ALPHA];
+    const long long total = (long long)a.g.nkl * a.g.PP;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+#pragma unroll
+        for (int c = 0; c < D; ++c) a.x[c * a.stride + idx] += alpha * p[c * a.stride + idx];
+}
+
 // b_c(node) = body_c * m(node), m = int phi  (`dot(b, v)*dx`, :1678, :1828)
 __global__ __launch_bounds__(256) void k_el_load(GridDev g, long long stride, int D, const double* __restrict__ load27,
                                                   double b0, double b1, double b2, double* __restrict__ b) {
@@ -1400,6 +1411,7 @@ struct ElSession {
     ElW36 w36{};
     ElW18 w18{};               // what k_el_fast is launched with (w36 in 18 numbers + the faces bits)
     ElFastGeom fgeom{};
+    bool xd_pending = false;        // el_xdefer: the latest update pass may have left its x += alpha p out (the scalars say whether it did)
     unsigned* d_mask = nullptr;
     int last_apply_blocks = 1;      // workgroups (= partials) of the most recent apply launch
     int k1_parts = 0;               // workgroups (partials) of the parts of a split K1 so far
@@ -1857,8 +1869,11 @@ int el_k1(ElSession* s, ElLazy* lazy = nullptr, int part = -1) {
 // ---- single-reduction PCG (variant 1) ---------------------------------------------------------------------------------------------------
 // update pass over the owned planes; lazy: sum the previous block from partials in the prologue (single-slab loops) unless the block has just
 // been reduced into the scalars (sr_mem)
-int el_sr_update(ElSession* s, bool lazy, int xmode = 0) {
+int el_sr_update(ElSession* s, bool lazy, int xmode = -1) {
     const GridDev& g = s->g;
+    // xmode -1 (the stepwise protocol): the passes alternate by themselves — leave x out | make up for it; el_xflush covers a stop in between
+    if (xmode < 0) xmode = !s->ctx->el_xdefer ? 0 : (s->xd_pending ? 2 : 1);
+    s->xd_pending = xmode == 1;
     ElArgs a = s->args();
     a.p_old = s->p[s->pcur];
     a.p_new = s->p[1 - s->pcur];
@@ -1915,7 +1930,7 @@ int el_sr_reduce(ElSession* s, int n_apply) {
 // One iteration = update pass + apply.  part: -1 whole (slabs without neighbours; lazy: no reduce launch), 0 = the update pass of the owned planes
 // (the host then posts the exchange of r), 1 = the apply on the planes away from the ghosts (overlaps the exchange), 2 = the ghost planes'
 // p-update, the remaining apply and the block reduce.
-int el_sr_k1(ElSession* s, bool lazy, int part, int xmode = 0) {
+int el_sr_k1(ElSession* s, bool lazy, int part, int xmode = -1) {
     const GridDev& g = s->g;
     const int lo = g.k0 > 0 ? 1 : 0, hi = (g.k0 + g.nkl < g.NZ) ? 1 : 0;
     ElArgs b = s->args();
@@ -1932,7 +1947,7 @@ int el_sr_k1(ElSession* s, bool lazy, int part, int xmode = 0) {
         if (lazy) return PDEGPU_OK;
         return el_sr_reduce(s, s->last_apply_blocks);
     }
-    if (part == 0) return el_sr_update(s, false);
+    if (part == 0) return el_sr_update(s, false, xmode);
     const bool split = el_k1_splittable(s);
     if (part == 1) {
         s->k1_parts = 0;
@@ -2070,6 +2085,7 @@ int el_begin(ElSession* s, const pdegpu_elasticity* el) {
     s->pcur = 0;
     s->ucur = 0;
     s->sr_mem = true;
+    s->xd_pending = false;
     hipLaunchKernelGGL(k_el_load, dim3(s->nblk), dim3(256), 0, ctx->stream, s->g, s->stride, s->D, s->ht.d_load, el->body[0], el->body[1],
                        s->D == 3 ? el->body[2] : 0.0, s->b);
     PG_HIP(ctx, hipGetLastError());
@@ -2079,6 +2095,20 @@ int el_begin(ElSession* s, const pdegpu_elasticity* el) {
     a.out = s->r;
     PG_TRY(el_apply(s, a, APPLY_RESIDUAL));
     return el_k2(s, 0);
+}
+
+// single-reduction form with el_xdefer: apply the x update the latest pass left out, if it did (the device flag decides)
+int el_xflush(ElSession* s) {
+    if (!s->xd_pending) return PDEGPU_OK;
+    ElArgs a = s->args();
+    a.x = s->x;
+    const double* p_old = s->p[1 - s->pcur];                  // (the pass has flipped the buffers: its p_old is the other one now)
+    if (s->D == 3) hipLaunchKernelGGL(k_el_xflush<3>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, p_old);
+    else hipLaunchKernelGGL(k_el_xflush<2>, dim3(s->nblk), dim3(256), 0, s->ctx->stream, a, p_old);
+    PG_HIP(s->ctx, hipGetLastError());
+    PG_HIP(s->ctx, hipMemsetAsync(s->scal + ESC_XD_FLAG, 0, sizeof(double), s->ctx->stream));
+    s->xd_pending = false;
+    return PDEGPU_OK;
 }
 
 int el_flush(ElSession* s) {
@@ -2505,7 +2535,8 @@ extern "C" int pdegpu_el_session_k2(pdegpu_el_session* h) {
 }
 extern "C" int pdegpu_el_session_flush(pdegpu_el_session* h) {
     if (!h) return PDEGPU_EINVAL;
-    return h->s.variant ? PDEGPU_OK : el_flush(&h->s);      // (single-reduction form: nothing is pending, x matches the r that r.r reports)
+    // (single-reduction form: x matches the r that r.r reports — up to the update a pass of the deferred form may have left out)
+    return h->s.variant ? el_xflush(&h->s) : el_flush(&h->s);
 }
 // ---- exchange and scalar reduction through the library's own RCCL communicator (comm.hip): same protocol as the heat session ----
 namespace {
@@ -2612,6 +2643,7 @@ extern "C" int pdegpu_el_session_scalars_host(pdegpu_el_session* h, double* out4
 extern "C" int pdegpu_el_session_get_u(pdegpu_el_session* h, double* u_out) {
     if (!h || !u_out) return PDEGPU_EINVAL;
     ElSession& s = h->s;
+    if (s.variant) PG_TRY(el_xflush(&s));      // (a deferred x update must not be missing from what is read)
     const size_t n = (size_t)s.g.nkl * s.g.NY * s.g.NX;
     double* d_dense = nullptr;
     PG_HIP(s.ctx, hipMalloc(&d_dense, n * sizeof(double)));

@@ -199,6 +199,47 @@ def test_deferred_x_update_of_the_pcg_gives_the_same_solve(lib, gpu_ctx, dim):
     assert it0 > 50 and abs(it1 - it0) <= max(2, 0.01 * it0), (it1, it0)
 
 
+def test_stepwise_elasticity_session_with_deferred_x_stops_anywhere(lib, gpu_ctx):
+    """the stepwise protocol (the multi-GPU driver's: pdegpu_el_session_k1 = update pass + apply + reduce) alternates the two forms of the update
+    pass by itself; flush / get_u apply an update that was left out.  After n = 1 ... 7 iterations the displacement must be the plain form's"""
+    import ctypes as C
+    from pdegpu import _lib
+    n = (40, 9, 7)
+    grid = _lib.make_grid(3, n, (1.0, 0.25, 0.2))
+    el = _lib.Elasticity()
+    el.E, el.nu = 210e9, 0.3
+    el.body[0], el.body[2] = 3.0e3, -76518.0
+    nodes = (n[0] + 1) * (n[1] + 1) * (n[2] + 1)
+
+    def run(xd, iters, flush):
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_xdefer", xd))
+        h = C.c_void_p()
+        _lib.check(gpu_ctx, lib.pdegpu_el_session_create(gpu_ctx, grid, el, 0, n[2] + 1, C.byref(h)))
+        try:
+            assert lib.pdegpu_el_session_cg_variant(h) == 1
+            _lib.check(gpu_ctx, lib.pdegpu_el_session_begin(h))
+            for _ in range(iters):
+                _lib.check(gpu_ctx, lib.pdegpu_el_session_k1(h))
+                _lib.check(gpu_ctx, lib.pdegpu_el_session_k2(h))
+            if flush:
+                _lib.check(gpu_ctx, lib.pdegpu_el_session_flush(h))
+            u = np.empty((nodes, 3))
+            _lib.check(gpu_ctx, lib.pdegpu_el_session_get_u(h, _lib.dptr(u)))
+            return u
+        finally:
+            lib.pdegpu_el_session_destroy(h)
+
+    try:
+        for iters in (1, 2, 3, 4, 5, 7):
+            ref = run(0, iters, True)
+            for flush in (True, False):                 # (get_u applies a pending update itself)
+                got = run(1, iters, flush)
+                assert np.isfinite(got).all() and np.abs(got - ref).max() <= 1e-11 * max(np.abs(ref).max(), 1e-300), (iters, flush)
+        assert np.abs(run(0, 7, True) - run(0, 3, True)).max() > 0.0
+    finally:
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"el_xdefer", 1))
+
+
 def test_elasticity_zero_load_and_errors(lib, gpu_ctx):
     from pdegpu import elasticity, _lib
     f = elasticity._solve_elasticity_3d_static(1, 1, 1, 4, 4, 4, 210e9, 0.3)          # no load -> u = 0 (:2639-2642)
