@@ -358,7 +358,9 @@ int  pdegpu_session_get_stats(pdegpu_session* s, pdegpu_stats* stats);
 int  pdegpu_session_step_rhs(pdegpu_session* s);
 int  pdegpu_session_lift_norm(pdegpu_session* s);
 int  pdegpu_session_reset_cg(pdegpu_session* s);
-int  pdegpu_session_flush(pdegpu_session* s);               /* pending x += alpha*p */
+int  pdegpu_session_flush(pdegpu_session* s);               /* pending x += alpha*p: call before x is read.  Between iterations x lags the residual by
+                                                                * one update (deferred into the next K1) or — cg_xdefer, where K2 updates x for two
+                                                                * iterations at once — by none or one; after flush it is the iterate r belongs to */
 /* run `iters` full CG iterations on a single slab without the host in the loop (k1,k2 back to back).
  * If time_kernels != 0, brackets every launch with hipEvents and accumulates stats->kernel_ms. */
 int  pdegpu_session_iterate(pdegpu_session* s, int iters, int time_kernels, pdegpu_stats* stats);
