@@ -174,6 +174,8 @@ const char* pdegpu_version(void);
  * wfast              | 1       | weighted 3-D operators on a box whose boundary nodes are all constrained, compact rows: z-marching kernels with the weights
  *                    |         | in registers (weight independent of the marching coordinate) or SGPRs (independent of x), 72 B/DoF per PCG
  *                    |         | iteration (csrc/wmarch.hip); 0 = class-table kernels reading the rows (88 B/DoF, 45 loads per node)
+ * wfast_xdefer       | -1      | (-1 = where one vector exceeds 32 MiB; smaller grids are cache-resident and keep the flat K2) those sessions' K2 applies the weighted stencil to the stored p again (z -= alpha D^-1 A p: K1 stores no q) and updates x for
+ *                    |         | two iterations at once, every other iteration (as cg_xdefer does for the plain operators): 56 instead of 72 B/DoF; 0 = flat K2
  * wfast_ry           | 2       | rows per wavefront column of those kernels where the weights are wave-uniform (1|2)
  * wfast_wg_per_cu    | 0       | workgroups per CU their z-chunking aims for (0 = occupancy API)
  * wfast_k2_mult      | 4       | workgroups per CU of their K2 (a wavefront per grid row)

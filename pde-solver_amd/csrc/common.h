@@ -38,6 +38,8 @@ struct pdegpu_ctx {
                                 // longer-lived streams move more bytes per second on this memory system (512^3: K1 1.03 -> 0.92 ms,
                                 // K2 0.62 -> 0.55 ms against the occupancy limit of 5-8) — and the occupancy API on cache-resident grids
     int grid_mult = 8;          // flat kernels: workgroups per CU
+    int wfast_xdefer = -1;      // weighted marching sessions (-1 = where one vector exceeds 32 MiB): 1 = K2 applies the weighted stencil to the stored p again (z -= alpha D^-1 A p: no q) and updates x
+                                // for two iterations at once, every other iteration, as the plain marching sessions do (cg_xdefer): 56 instead of 72 B/DoF
     int cg_xdefer = 1;          // marching sessions in the 64 B/DoF form: 1 = the solution vector is updated by K2 (which holds p_n, r_n and alpha_n) instead of
                                 // the next K1, and only by every other K2 — the one in between records its alpha, the next forms both updates with
                                 // p_{n-1} = (p_n - r_n) / beta_n: K1 24 B/DoF, K2 24 | 40 B/DoF = 56 instead of 64 B/DoF per iteration; 0 = x += alpha p in K1

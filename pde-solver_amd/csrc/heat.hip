@@ -369,7 +369,12 @@ bool k2_is_stencil(const pdegpu_session* s) {
 // x_in_k2: pure marching sessions (no boundary launch, no tile forms, no weights) in the 64 B/DoF form
 bool xk2_eligible(const pdegpu_session* s) {
     // (hybrid sessions: both launches of K1 and of K2 — marching kernel and boundary pass — follow the same protocol)
-    return s->ctx->cg_xdefer != 0 && s->d_xd && k2_is_stencil(s) && s->fast && !s->tile3d && !s->plane2d && !s->weighted && !s->wfast;
+    if (s->ctx->cg_xdefer == 0 || !s->d_xd) return false;
+    // weighted operators whose applications march (wmarch.hip): K2 applies the weighted stencil to the stored p again (z -= alpha D^-1 A p) and carries x
+    // (-1: where a vector exceeds 32 MiB — 128^3 cells, everything cache-resident: 44 -> 40 GDoF/s, the second stencil pass costs more than the bytes it
+    // saves; 192^3: 54 -> 58, 256^3: 61 -> 77, 512^3: 71 -> 93)
+    if (s->wfast) return s->ctx->wfast_xdefer < 0 ? (long long)s->g.nkl * s->g.PP * 8 > (32LL << 20) : s->ctx->wfast_xdefer != 0;
+    return k2_is_stencil(s) && s->fast && !s->tile3d && !s->plane2d && !s->weighted;
 }
 // before the K2 launch(es) of an iteration: leave x out (and record alpha) or update it for this iteration and the one before, alternating
 void xk2_begin(pdegpu_session* s) {
@@ -427,6 +432,11 @@ int op_k1(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), int lk_l
     if (s->wfast) {                            // p = D^-1 r + beta p formed in the kernel: no z vector
         a.in = s->r.v;
         a.out = s->q.v;
+        if (s->xk2) {                          // K1 neither touches x nor stores q: K2 applies the stencil again and carries the x update
+            a.out = nullptr;
+            a.x_in_k2 = 1;
+            a.xd = s->d_xd;
+        }
         wfast_args(s, 0, &a);
         rc = wmarch_apply(s->ctx, a, APPLY_CG_K1, li);
     } else if (s->plane2d) {
@@ -510,6 +520,23 @@ int op_k2(pdegpu_session* s, LaunchInfo* li, const DotIn& di = DotIn(), double* 
         if (li) *li = lf;
         return PDEGPU_OK;
     }
+    if (s->wfast && s->xk2) {
+        StencilArgs a{};
+        a.di = di;
+        a.in = s->p[s->pcur].v;
+        a.rhs = s->r.v;                        // (the session's r holds z = D^-1 r)
+        a.out = s->r.v;
+        a.scal = s->d_scal;
+        a.partials = part_out;
+        a.mask_dirichlet = 1;
+        a.x_in_k2 = 1;
+        a.xmode = s->xk2_mode;
+        a.xd = s->d_xd;
+        a.x = s->x.v;
+        a.p_old = s->p[1 - s->pcur].v;
+        wfast_args(s, 0, &a);
+        return wmarch_apply(s->ctx, a, APPLY_CG_K2, li);
+    }
     if (s->wfast) return wmarch_k2(s->ctx, s->g, s->ell_mode, s->r.v, s->q.v, s->ell_mode == 1 ? s->ellA + s->g.PP : s->rowA,
                                    s->ell_mode == 1 ? s->dinv + s->g.PP : nullptr, s->rowAf[0], s->rowAf[1], s->d_scal, part_out, li, di);
     if (s->weighted) return vec_k2_pc(s->ctx, s->g, s->r.v, s->q.v, s->z.v, s->dinv, s->d_scal, part_out, 1, li, di);
@@ -551,7 +578,7 @@ static const char* const kTunableKeys[] = {
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
     "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
-    "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran", "el_xdefer", "cg_xdefer"};
+    "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran", "el_xdefer", "cg_xdefer", "wfast_xdefer"};
 
 extern "C" int pdegpu_create(pdegpu_ctx** out, int device_id, void* stream) {
     if (!out) return PDEGPU_EINVAL;
@@ -631,6 +658,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "el_bnd_gran")) return &ctx->el_bnd_gran;
     if (!strcmp(key, "el_xdefer")) return &ctx->el_xdefer;
     if (!strcmp(key, "cg_xdefer")) return &ctx->cg_xdefer;
+    if (!strcmp(key, "wfast_xdefer")) return &ctx->wfast_xdefer;
     if (!strcmp(key, "el_fast_yx")) return &ctx->el_fast_yx;
     if (!strcmp(key, "el_fast_xface")) return &ctx->el_fast_xface;
     if (!strcmp(key, "el_bnd_last")) return &ctx->el_bnd_last;

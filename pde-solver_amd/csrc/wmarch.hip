@@ -95,15 +95,19 @@ struct WRow { double l, x, y, r; };
 // EX: the tile-edge x-neighbours (node i0-1 of lane 0, node i0+2 of lane 63) are handed between the x-adjacent wavefronts of the workgroup through LDS
 // (one barrier per plane; the four waves of a workgroup march in lockstep anyway) instead of 2-lane global loads — 2 (RY + 2) of them per plane and
 // vector, more load instructions than the wide ones; only a wave whose neighbour tile belongs to another workgroup still loads its edge from memory.
-template <int CM, int RY, int MODE, int LQ, bool FX, bool NT, bool EX>
+// MODE CG_K2 + XU (x_in_k2 sessions, as in k_fast — tunable cg_xdefer): K2 applies the weighted stencil to the stored p again,
+// z -= alpha D^-1 (A p) with the partial sum of D z^2, instead of reading a stored q; every other such launch (XU = 1) also updates x for two iterations
+// at once with p_{n-1} = (p_n - z_n) / beta_n.  K1 of such a session (XU = 0) neither touches x nor stores q: 24 + 24 | 40 = 56 instead of 72 B/DoF.
+template <int CM, int RY, int MODE, int LQ, bool FX, bool NT, bool EX, int XU>
 __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     __shared__ double sEdge[EX ? 2 : 1][4][RY + 2][2];
     static_assert(!FX || CM == 2, "natural x-faces: weights independent of x only");
     __shared__ double sRed[4];
     __shared__ double2 sC[LQ > 0 ? 4 : 1][LQ > 0 ? RY : 1][LQ > 0 ? LQ : 1][LQ > 0 ? 64 : 1];
     constexpr int NQR = 15 - LQ;               // weights of a node pair kept in registers
-    constexpr bool K1 = (MODE == APPLY_CG_K1), RES = (MODE == APPLY_RESIDUAL);
-    constexpr bool DI = RES;                   // the pass needs the Jacobi diagonal^-1 (of its own rows)
+    constexpr bool K1 = (MODE == APPLY_CG_K1), RES = (MODE == APPLY_RESIDUAL), K2 = (MODE == APPLY_CG_K2);
+    constexpr bool K1X = K1 && XU != 0, K2X = K2 && XU != 0;
+    constexpr bool DI = RES || K2;             // the pass needs the Jacobi diagonal^-1 (of its own rows)
     constexpr int RH = RY + 2;
     const GridDev& g = a.g;
     const int lane = threadIdx.x & 63;
@@ -126,8 +130,13 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
     const bool active = EX ? wg_active : wave_active;
     int estep = 0;                                                          // edge hand-off counter (the same in every wave of the workgroup)
 
-    double alpha_prev = 0.0, beta = 0.0;
+    double alpha_prev = 0.0, beta = 0.0, res_scale = 1.0;
     if (K1) cg_scalars_in(a.di, a.scal, sRed, &alpha_prev, &beta);          // (every thread of every workgroup: the prologue sum has barriers)
+    if (K2) res_scale = cg_alpha_in(a.di, a.scal, sRed);
+    double cx_p = 0.0, cx_r = 0.0, cx_o = 0.0;
+    if (K1 && !XU && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[1] = beta;
+    if (K2 && !XU && a.xd && blockIdx.x == 0 && threadIdx.x == 0) a.xd[0] = res_scale;
+    if (K2X) xk2_coefficients(a.xd, a.xmode, res_scale, &cx_p, &cx_r, &cx_o);
     double acc = 0.0;
     if (active) {
         const double shift = a.in_shift;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
             if (K1 && j <= jmax && lane_ok) {
                 const long long off = (long long)lk * g.PP + (long long)j * g.PX + i0;
                 wm_st<NT>(a.p_new + off, make_double2(pn.x, pn.y));
-                if (alpha_prev != 0.0) {
+                if (K1X && alpha_prev != 0.0) {
                     xv.x += alpha_prev * po.x;
                     xv.y += alpha_prev * po.y;
                     wm_st<NT>(a.x + off, xv);
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
         load_plane(lk0, C, PO);
         if (K1) {
 #pragma unroll
-            for (int r = 1; r <= RY; ++r) own_update(lk0, j0 - 1 + r, C[r], PO[r], own_xload(lk0, j0 - 1 + r));
+            for (int r = 1; r <= RY; ++r) own_update(lk0, j0 - 1 + r, C[r], PO[r], K1X ? own_xload(lk0, j0 - 1 + r) : make_double2(0.0, 0.0));
         }
 
         // CM 2: the 128-byte line of every own row of a plane (15 weights + D^-1), requested a whole plane step AHEAD: at the end of the step before, behind
@@ -293,17 +302,26 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                 }
             }
             double2 XV[RY];
-            if (K1 && lk + 1 < lk1) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) XV[r] = make_double2(0.0, 0.0);
+            if (K1X && lk + 1 < lk1) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) XV[r] = own_xload(lk + 1, j0 + r);
             }
             double2 RHS[RY];
-            if (RES) {
+            double2 XK[K2X ? RY : 1], PO2[K2X ? RY : 1];      // K2X: the x rows of this plane (and, after a restart only, p of the iteration before)
+            if (RES || K2) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     const int j = j0 + r;
+                    const long long off = (j <= jmax && lane_ok) ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0;
                     RHS[r] = make_double2(a.rhs_const, a.rhs_const);
-                    if (a.rhs) RHS[r] = load2(a.rhs, (j <= jmax && lane_ok) ? (long long)lk * g.PP + (long long)j * g.PX + i0 : 0);
+                    if (a.rhs) RHS[r] = load2(a.rhs, off);
+                    if (K2X) {
+                        XK[r] = wm_ld<NT>(a.x + off);
+                        PO2[r] = make_double2(0.0, 0.0);
+                        if (cx_o != 0.0) PO2[r] = load2(a.p_old, off);      // kernel-uniform, rare
+                    }
                 }
             }
             load_plane(lk + 1, N, PO);
@@ -369,12 +387,23 @@ __global__ __launch_bounds__(256, 2) void k_wmarch(StencilArgs a, WGeom wgm) {
                     o.x = fra ? da * (RHS[r].x - qa) : 0.0;
                     o.y = frb ? db * (RHS[r].y - qb) : 0.0;
                     acc += diag_a * o.x * o.x + diag_b * o.y * o.y;          // (the centre weight IS the diagonal)
+                } else if (K2) {                                             // z -= alpha D^-1 (A p);  r.z = D z^2  (in = the stored p_n, rhs = out = z)
+                    o.x = fra ? RHS[r].x - res_scale * da * qa : 0.0;
+                    o.y = frb ? RHS[r].y - res_scale * db * qb : 0.0;
+                    acc += diag_a * o.x * o.x + diag_b * o.y * o.y;
                 } else {
                     o.x = fra ? qa : 0.0;
                     o.y = frb ? qb : 0.0;
                     acc += (C[c].x - (K1 ? 0.0 : shift)) * o.x + (C[c].y - (K1 ? 0.0 : shift)) * o.y;
                 }
-                if (lane_ok && jok) wm_st<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
+                if (lane_ok && jok && (!K1 || a.out)) wm_st<NT>(a.out + (long long)lk * g.PP + (long long)j * g.PX + i0, o);
+                if (K2X && lane_ok && jok) {
+                    // x += alpha_n p_n (+ the update the K2 before left out, p_{n-1} = (p_n - z_n) / beta_n): p_n = C, z_n = RHS (0 on Dirichlet nodes and pads)
+                    double2 xv = XK[r];
+                    xv.x += cx_p * C[c].x - cx_r * RHS[r].x + cx_o * PO2[r].x;
+                    xv.y += cx_p * C[c].y - cx_r * RHS[r].y + cx_o * PO2[r].y;
+                    wm_st<NT>(a.x + (long long)lk * g.PP + (long long)j * g.PX + i0, xv);
+                }
             }
             if (K1 && lk + 1 < lk1) {
 #pragma unroll
@@ -551,9 +580,10 @@ int launch_wmarch_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo
         int nb = 0;
         hipError_t e;
         switch (mode) {
-            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX, NT, EX>, 256, 0); break;
-            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX, NT, EX>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX, NT, EX>, 256, 0); break;
+            case APPLY_PLAIN: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX, NT, EX, 0>, 256, 0); break;
+            case APPLY_RESIDUAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX, NT, EX, 0>, 256, 0); break;
+            case APPLY_CG_K2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K2, LQ, FX, NT, EX, 1>, 256, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX, NT, EX, 1>, 256, 0); break;
         }
         if (e != hipSuccess || nb < 1) nb = 2;
         occ[mode & 3] = std::min(nb, 8);
@@ -578,9 +608,16 @@ int launch_wmarch_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo
     if (G > stencil_max_partials(ctx))         // one partial per workgroup (rows of more than ~80 000 x 2 tiles: nothing this device holds)
         return pdegpu_set_err(ctx, PDEGPU_EUNSUPPORTED, "weighted marching kernels: %d workgroups exceed the %d partials of a session", G, stencil_max_partials(ctx));
     switch (mode) {
-        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
-        default: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX, NT, EX>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_PLAIN: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_PLAIN, LQ, FX, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_RESIDUAL: hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_RESIDUAL, LQ, FX, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, wgm); break;
+        case APPLY_CG_K2:
+            if (a.xmode == 2) hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K2, LQ, FX, NT, EX, 1>), dim3(G), dim3(256), 0, ctx->stream, a, wgm);
+            else hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K2, LQ, FX, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, wgm);
+            break;
+        default:
+            if (a.x_in_k2) hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX, NT, EX, 0>), dim3(G), dim3(256), 0, ctx->stream, a, wgm);
+            else hipLaunchKernelGGL((k_wmarch<CM, RY, APPLY_CG_K1, LQ, FX, NT, EX, 1>), dim3(G), dim3(256), 0, ctx->stream, a, wgm);
+            break;
     }
     PG_HIP(ctx, hipGetLastError());
     return PDEGPU_OK;
@@ -618,7 +655,8 @@ bool wmarch_supported(const GridDev& g, int cm) {
 
 // a.ell / a.ell_stride / a.ell_mode (= CM) / a.wdinv describe the coefficients (see the header comment); mode: PLAIN, RESIDUAL, CG_K1
 int wmarch_apply(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
-    if (mode != APPLY_PLAIN && mode != APPLY_RESIDUAL && mode != APPLY_CG_K1) return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weighted marching: PLAIN, RESIDUAL or K1");
+    if (mode != APPLY_PLAIN && mode != APPLY_RESIDUAL && mode != APPLY_CG_K1 && mode != APPLY_CG_K2)
+        return pdegpu_set_err(ctx, PDEGPU_EINVAL, "weighted marching: PLAIN, RESIDUAL, K1 or K2");
     const int ry = ctx->wfast_ry;
     if (a.ell_mode == 1) return ctx->wfast_ry1 == 2 ? launch_wmarch<1, 2, 8, false>(ctx, a, mode, li) : launch_wmarch<1, 1, 0, false>(ctx, a, mode, li);
     if (a.wface[0] || a.wface[1]) return ry == 1 ? launch_wmarch<2, 1, 0, true>(ctx, a, mode, li) : launch_wmarch<2, 2, 0, true>(ctx, a, mode, li);

@@ -234,3 +234,30 @@ def test_marching_and_class_table_pcg_agree(lib, gpu_ctx, case):
     assert outs[0].meta["solver_path"] == "weighted-marching" and outs[1].meta["solver_path"] != "weighted-marching"
     assert abs(outs[0].meta["cg_iterations"] - outs[1].meta["cg_iterations"]) <= 2 and outs[0].meta["cg_iterations"] > 10
     assert np.abs(outs[0].values - outs[1].values).max() <= 1e-9 * np.abs(outs[1].values).max()
+
+
+@pytest.mark.parametrize("case", ["spherical", "box_core", "cylinder_lr"])
+def test_stencil_k2_with_deferred_x_update_gives_the_flat_k2_solve(lib, gpu_ctx, case):
+    """wfast_xdefer: K2 of the weighted marching PCG applies the weighted stencil to the stored p again (z -= alpha D^-1 A p: K1 stores no q) and updates
+    x for two iterations at once, every other iteration, with p_(n-1) = (p_n - z_n) / beta_n; the flat K2 on a stored q (wfast_xdefer = 0) must give
+    the same solve: fields to 1e-9, iteration counts within two — per-lane weights, wave-uniform weights, and natural faces (the cylinder tool's
+    T_left / T_right call)"""
+    from pdegpu import _lib as L, curvilinear as cv, heat
+    outs = []
+    try:
+        for xd in (1, 0):
+            L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_xdefer", xd))
+            if case == "spherical":
+                f = _spherical(cv, (150, 37, 41), rtol=1e-11)
+            elif case == "box_core":
+                f = heat._solve_heat_3d_raw(Lx=1.0, Ly=1.0, Lz=1.0, nx=150, ny=38, nz=40, diffusivity=1.0, T_boundary=5.0, T_initial=70.0, dt=0.002, num_steps=2,
+                                            core_radius=0.4, core_diffusivity=20.0, rtol=1e-11)
+            else:
+                f = heat._solve_heat_3d_raw(Lx=1.0, Ly=1.0, Lz=1.0, nx=140, ny=20, nz=22, diffusivity=1.0, T_boundary=0.0, T_initial=50.0, dt=0.004, num_steps=2,
+                                            geometry_type="cylinder", cylinder_radius=0.5, T_left=10.0, T_right=30.0, T_side=None, rtol=1e-11)
+            assert f.meta.get("solver_path", "weighted-marching") == "weighted-marching"
+            outs.append(f)
+    finally:
+        L.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"wfast_xdefer", -1))
+    assert abs(outs[0].meta["cg_iterations"] - outs[1].meta["cg_iterations"]) <= 2 and outs[0].meta["cg_iterations"] > 10
+    assert np.abs(outs[0].values - outs[1].values).max() <= 1e-9 * np.abs(outs[1].values).max()
