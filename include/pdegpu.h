@@ -178,6 +178,7 @@ const char* pdegpu_version(void);
  *                    |         | two iterations at once, every other iteration (as cg_xdefer does for the plain operators): 56 instead of 72 B/DoF; 0 = flat K2
  * wfast_ry           | 2       | rows per wavefront column of those kernels where the weights are wave-uniform (1|2)
  * wfast_wg_per_cu    | 0       | workgroups per CU their z-chunking aims for (0 = occupancy API)
+ * wfast_one_round    | 1       | HBM-resident grids: the z-chunking with the most workgroups that are all resident at once, where one fills 1.6 per CU
  * wfast_k2_mult      | 4       | workgroups per CU of their K2 (a wavefront per grid row)
  * wfast_ex           | -1      | those kernels hand tile-edge x-neighbours between the workgroup's waves through LDS (0 = 2-lane global loads;
  *                    |         | -1 = per-lane weights always, wave-uniform weights on cache-resident grids: where it measured faster)

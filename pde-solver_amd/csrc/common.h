@@ -55,6 +55,7 @@ struct pdegpu_ctx {
     int wfast_nt = -1;          // their marching kernels: non-temporal stores of q / p / x and loads of x: 1 | 0; -1 = where one vector exceeds 64 MiB
     int wfast_k2_nt = -1;       // K2 of those sessions: non-temporal loads / stores 1 | 0; -1 = where one vector exceeds 64 MiB
     int wfast_k2_mult = 4;      // K2 of those sessions: workgroups per CU (a wavefront per grid row; 192^3 composite core: 57 -> 60 GDoF/s from 2 to 4)
+    int wfast_one_round = 1;    // their z-chunking on HBM-resident grids: 1 = the chunking with the most workgroups that are all resident at once, where one exists
     int wfast_wg_per_cu = 0;    // workgroups per CU their z-chunking aims for; 0 = what the occupancy API reports
     int ell_compact = 1;        // weighted operators whose weight does not depend on one coordinate keep the coefficient rows of three representative
                                 // planes / columns instead of one row per node (0: always one row per node)

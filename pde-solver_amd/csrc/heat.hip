@@ -574,7 +574,7 @@ extern "C" const char* pdegpu_version(void) { return "pdegpu 0.1 (gfx950)"; }
 
 // every tunable of a context: PDEGPU_<KEY> in the environment at pdegpu_create, pdegpu_set_tunable afterwards (table in include/pdegpu.h)
 static const char* const kTunableKeys[] = {
-    "ell_compact", "wfast", "wfast_ry", "wfast_ry1", "wfast_wg_per_cu", "wfast_k2_mult", "wfast_k2_nt", "wfast_nt", "wfast_ex", "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
+    "ell_compact", "wfast", "wfast_ry", "wfast_ry1", "wfast_wg_per_cu", "wfast_one_round", "wfast_k2_mult", "wfast_k2_nt", "wfast_nt", "wfast_ex", "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
     "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
@@ -615,6 +615,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "wfast")) return &ctx->wfast;
     if (!strcmp(key, "wfast_ry")) return &ctx->wfast_ry;
     if (!strcmp(key, "wfast_wg_per_cu")) return &ctx->wfast_wg_per_cu;
+    if (!strcmp(key, "wfast_one_round")) return &ctx->wfast_one_round;
     if (!strcmp(key, "wfast_k2_mult")) return &ctx->wfast_k2_mult;
     if (!strcmp(key, "wfast_ry1")) return &ctx->wfast_ry1;
     if (!strcmp(key, "wfast_k2_nt")) return &ctx->wfast_k2_nt;

@@ -545,7 +545,12 @@ void wmarch_ranges(const GridDev& g, int* jlo, int* jhi, int* klo, int* khi, int
     if (xhi) *xhi = (dirn && !g.bc_present[1]) ? g.NX - 1 : g.NX - 2;
 }
 
-WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu) {
+// one_round_cap > 0 (HBM-resident grids, wfast_one_round): the workgroups the device really holds at once (occupancy x CUs).  If some chunking fills at
+// least 1.6 workgroups per CU within that, the one with the most workgroups is taken — ONE resident round; the cost model below counts rounds against
+// wg_per_cu x CUs, but the hardware places what fits: 385^3 nodes, wave-uniform weights (occupancy 3), modelled as two rounds of 504 (7 chunks) is in fact
+// one of 768 and a tail of 240.  Composite core 384^3: 7 chunks 74.2, 3 chunks (432 workgroups) 77.5, 5 chunks (720) 83.3 GDoF/s; spherical
+// (occupancy 2) 7 chunks 78.4, 3 chunks 81.4.
+WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu, int one_round_cap = 0) {
     WGeom w{};
     wmarch_ranges(g, &w.jlo, &w.jhi, &w.klo, &w.khi, &w.xlo, &w.xhi);
     w.ntx = (w.xhi + 1 + 127) / 128;          // tiles start at node 0 and must reach the last free column
@@ -567,6 +572,10 @@ WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu
             best_c = c;
         }
     }
+    if (one_round_cap > 0 && w.nwg_xy > 0) {
+        const int c1 = (int)std::min<long long>(std::min(maxc, one_round_cap / w.nwg_xy), std::max(1, pcap / w.nwg_xy));
+        if (c1 >= 1 && (long long)w.nwg_xy * c1 * 10 >= 16LL * ctx->num_cu) best_c = c1;
+    }
     if (ctx->fast_zlen > 0) best_c = std::max(1, (planes + ctx->fast_zlen - 1) / ctx->fast_zlen);
     w.zlen = (planes + best_c - 1) / best_c;
     w.nzc = (planes + w.zlen - 1) / w.zlen;
@@ -575,7 +584,7 @@ WGeom wmarch_geom(const pdegpu_ctx* ctx, const GridDev& g, int RY, int wg_per_cu
 
 template <int CM, int RY, int LQ, bool FX, bool NT, bool EX>
 int launch_wmarch_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo* li) {
-    static int occ[4] = {0, 0, 0, 0};
+    static int occ[4] = {0, 0, 0, 0};      // (of the instantiation that carries x: the two forms of a mode share one geometry)
     if (occ[mode & 3] == 0) {
         int nb = 0;
         hipError_t e;
@@ -592,7 +601,8 @@ int launch_wmarch_nt(pdegpu_ctx* ctx, const StencilArgs& a, int mode, LaunchInfo
     // kernels' finding, §4b of docs/history.md; here composite core 320^3 70.2 -> 71.1, 384^3 65.7 -> 73.0, spherical 384^3 61.7 -> 69.8 GDoF/s; 512^3 unchanged)
     const bool hbm = (long long)a.g.nkl * a.g.PP * 8 > (64LL << 20);
     const int wg = ctx->wfast_wg_per_cu > 0 ? ctx->wfast_wg_per_cu : (hbm ? std::min(occ[mode & 3], 2) : occ[mode & 3]);
-    const WGeom wgm = wmarch_geom(ctx, a.g, RY, wg);
+    const int cap1 = (hbm && ctx->wfast_wg_per_cu <= 0 && ctx->wfast_one_round) ? occ[mode & 3] * ctx->num_cu : 0;
+    const WGeom wgm = wmarch_geom(ctx, a.g, RY, wg, cap1);
     const int G = (wgm.nwg_xy * wgm.nzc + 7) / 8 * 8;      // a multiple of 8: the XCD-aware order always applies (surplus workgroups idle)
     if (li) { li->grid = G; li->block = 256; }
     {

@@ -1,14 +1,11 @@
 #!/bin/bash
-# weighted marching kernels: rocprofv3 kernel stats of one spherical + one composite-core solve at 192^3, then the rates under a few tunables
+# weighted marching PCG: whole-call rates under PDEGPU_* overrides, one process per setting (each argument: "" or "KEY=V KEY2=V2"); sizes from $SIZES
+# -> gpurun_out/w_sweep.log
 set -o pipefail
-mkdir -p gpurun_out/r4
-export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$PWD}
-rm -rf gpurun_out/prof_w
-(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_w/stats -- python3 $R/tools/w_prof.py 192 > $R/gpurun_out/r4/prof_w.log 2>&1); echo "rocprof stats exit $?"
-find gpurun_out/prof_w -name "*kernel_stats.csv" -exec head -12 {} \;
-find gpurun_out/prof_w -size +8M -name "*_kernel_trace.csv" -delete 2>/dev/null
-for cfg in "" "PDEGPU_WFAST_RY=1" "PDEGPU_WFAST_WG_PER_CU=2" "PDEGPU_WFAST_WG_PER_CU=3" "PDEGPU_WFAST_WG_PER_CU=4" "PDEGPU_WFAST_WG_PER_CU=6" "PDEGPU_WFAST_RY=1 PDEGPU_WFAST_WG_PER_CU=2" "PDEGPU_WFAST_K2_MULT=2" "PDEGPU_WFAST_K2_MULT=8"; do
-  echo "== $cfg"
-  env $cfg PDEGPU_DEBUG_GEOM=1 timeout -k 10 200 python tools/w_rate.py 192 2>&1 | grep -v "plain box\|amdgpu.ids" | grep "192\|wmarch"
+mkdir -p gpurun_out
+: > gpurun_out/w_sweep.log
+if [ $# -eq 0 ]; then set -- "" "PDEGPU_WFAST_WG_PER_CU=3" "PDEGPU_WFAST_EX=1" "PDEGPU_WFAST_EX=0" "PDEGPU_WFAST_NT=0" "PDEGPU_WFAST_XDEFER=0"; fi
+for s in "$@"; do
+    env $s timeout -k 10 300 python tools/w_sweep.py ${SIZES:-256 384 512} 2>&1 | grep "\^3" >> gpurun_out/w_sweep.log || exit 1
 done
+cat gpurun_out/w_sweep.log
