@@ -16,7 +16,9 @@
 // recurrence, no diagonal in K1); the residual pass stores z = D^-1 (b - A x), K2 updates z -= alpha D^-1 q and sums r.z = sum D z^2 with D^-1 from
 // the compact table (a flat pass with registers to spare).  An iteration moves  K1: read z, p, x; write p, x, q (48 B/DoF)  +  K2: read z, q; write
 // z (24 B/DoF)  =  72 B/DoF instead of the 88 of the class-table form (k_general<..., ELL> + k_k2_pc, which also costs 45 load instructions per
-// node).  Sessions: one slab owning every plane, every boundary node Dirichlet (the uniform boundary value of the tools).
+// node).  Where a vector exceeds 32 MiB (wfast_xdefer) K2 is a mode of the marching kernel instead — the weighted stencil on the stored p again — and
+// carries the x update of every other iteration: K1 24 + K2 24 | 40 = 56 B/DoF (see the comment above k_wmarch).
+// Sessions: one slab owning every plane, every boundary node Dirichlet (the uniform boundary value of the tools).
 #include "common.h"
 #include "dot_finish.h"
 #include <algorithm>
