@@ -218,6 +218,36 @@ __device__ __forceinline__ double block_sum(double v, double* sRed) {
     return t;
 }
 
+// the two sums of the single-reduction form in ONE pass: one LDS round / one round of sc1 loads instead of two (each value is summed in the order of
+// block_sum / sum_partials, so the scalars are bit for bit those of two separate passes)
+__device__ __forceinline__ void block_sum2(double va, double vb, double* sRed2 /* [2 * kNW] */, double* oa, double* ob) {
+    va = p2_wave_sum(va);
+    vb = p2_wave_sum(vb);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sRed2[threadIdx.x >> 6] = va;
+        sRed2[kNW + (threadIdx.x >> 6)] = vb;
+    }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNW; ++k) {
+        ta += sRed2[k];
+        tb += sRed2[kNW + k];
+    }
+    *oa = ta;
+    *ob = tb;
+}
+__device__ __forceinline__ void sum_partials2(const double* part /* [2][G] */, int G, double* sRed2, double* oa, double* ob) {
+    double va = 0.0, vb = 0.0;
+    for (int e = threadIdx.x; e < G; e += kNW * 64) {
+        const double ta = ld_sc1(part + e), tb = ld_sc1(part + G + e);     // both loads in flight before the first is used
+        va += ta;
+        vb += tb;
+    }
+    block_sum2(va, vb, sRed2, oa, ob);
+}
+
 template <int RB>
 __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
     __shared__ double sRed[kNW];
@@ -386,7 +416,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent(P2dArgs a) {
 // Used for fresh solves only (it starts from p = s = 0); leaves x fully updated (no pending alpha p) and SC_PQ = 0.
 template <int RB>
 __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_sr(P2dArgs a) {
-    __shared__ double sRed[kNW];
+    __shared__ double sRed[2 * kNW];
     __shared__ double sEdge[RB + 2][kNW][2];
     __shared__ int sFail;
     __shared__ int sCensus[4];
@@ -446,8 +476,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_sr(P2dArgs a) {
             arr += R[c].x * R[c].x + R[c].y * R[c].y;
             awr += W[q].x * R[c].x + W[q].y * R[c].y;
         }
-        *rr_out = block_sum(arr, sRed);
-        *wr_out = block_sum(awr, sRed);
+        block_sum2(arr, awr, sRed, rr_out, wr_out);
     };
 
     BarrierState bs;
@@ -467,8 +496,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_sr(P2dArgs a) {
         ++phase;
         ok = grid_barrier(a, bs, &sFail);
         if (ok) {
-            gamma = sum_partials(a.part + (size_t)ph * 2 * a.G, a.G, sRed);
-            delta = sum_partials(a.part + (size_t)ph * 2 * a.G + a.G, a.G, sRed);
+            sum_partials2(a.part + (size_t)ph * 2 * a.G, a.G, sRed, &gamma, &delta);
             alpha = delta > 0.0 ? gamma / delta : 0.0;
         }
     }
@@ -531,8 +559,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_sr(P2dArgs a) {
         ++phase;
         ok = grid_barrier(a, bs, &sFail);
         if (!ok) break;
-        const double gamma_new = sum_partials(a.part + (size_t)ph * 2 * a.G, a.G, sRed);
-        const double delta_new = sum_partials(a.part + (size_t)ph * 2 * a.G + a.G, a.G, sRed);
+        double gamma_new, delta_new;
+        sum_partials2(a.part + (size_t)ph * 2 * a.G, a.G, sRed, &gamma_new, &delta_new);
         beta = gamma > 0.0 ? gamma_new / gamma : 0.0;
         const double den = delta_new - beta * gamma_new / alpha;
         alpha = den > 0.0 ? gamma_new / den : 0.0;
