@@ -1002,6 +1002,26 @@ __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __res
     __shared__ double sRed4[16];
     __shared__ double sDinv[27 * 3];
     if (threadIdx.x < 81) sDinv[threadIdx.x] = a.dinv[threadIdx.x];
+    // the first node pair of this thread (config 5: one or two pairs per thread) is requested BEFORE the scalars of the iteration are summed: p_old, r and q
+    // do not depend on them (x does: the deferred form may skip it), so three of the pass's four read streams are in flight during the prologue
+    const bool second = (int)blockIdx.x >= nb1;               // workgroup-uniform
+    if (second) {
+        first = first2;
+        total = total2;
+    }
+    const int bid = second ? (int)blockIdx.x - nb1 : (int)blockIdx.x, nbl = second ? (int)gridDim.x - nb1 : nb1;
+    const long long pairs = total / 2;
+    long long e = (long long)bid * 256 + threadIdx.x;
+    double2 ppo[D], prv[D], pqv[D];
+    if (e < pairs) {
+        const long long idx = first + 2 * e;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            ppo[c] = el_ld2<NT>(a.p_old + c * a.stride + idx);
+            prv[c] = el_ld2<NT>(r + c * a.stride + idx);
+            pqv[c] = ghost ? make_double2(0.0, 0.0) : el_ld2<NT>(q + c * a.stride + idx);
+        }
+    }
     __syncthreads();
     double pq, qmq, rz;
     if (a.din) {
@@ -1060,19 +1080,12 @@ __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __res
         sc[ESC_XD_BETA] = beta;
     }
     const GridDev& g = a.g;
-    const bool second = (int)blockIdx.x >= nb1;               // workgroup-uniform
-    if (second) {
-        first = first2;
-        total = total2;
-    }
-    const int bid = second ? (int)blockIdx.x - nb1 : (int)blockIdx.x, nbl = second ? (int)gridDim.x - nb1 : nb1;
-    const long long pairs = total / 2;
     const int PX2 = g.PX / 2;
     const long long step = (long long)nbl * 256;
     const int di = (int)(step % PX2);
     const long long drow = step / PX2;
     const int dj = (int)(drow % g.NY), dk = (int)(drow / g.NY);
-    long long e = (long long)bid * 256 + threadIdx.x;
+    bool pre = true;                                          // the first pair's p_old / r / q are already on their way
     int i2 = (int)(e % PX2), j = (int)((e / PX2) % g.NY), lk = (int)((e / PX2) / g.NY) + (int)(first / g.PP);
     double acc_rz = 0.0, acc_rr = 0.0;
     for (; e < pairs; e += step) {
@@ -1092,14 +1105,26 @@ __global__ __launch_bounds__(256) void k_el_update(ElArgs a, const double* __res
         const bool upd = !ghost && alpha != 0.0;              // kernel-uniform
         const bool xdo = !ghost && ((upd && !skip_x) || dbl);
         double2 po[D], rv[D], qv[D], xv[D];
+        if (pre) {
 #pragma unroll
-        for (int c = 0; c < D; ++c) {
-            po[c] = el_ld2<NT>(a.p_old + c * a.stride + idx);
-            rv[c] = el_ld2<NT>(r + c * a.stride + idx);
-            qv[c] = make_double2(0.0, 0.0);
-            xv[c] = make_double2(0.0, 0.0);
-            if (upd) qv[c] = el_ld2<NT>(q + c * a.stride + idx);
-            if (xdo) xv[c] = el_ld2<NT>(a.x + c * a.stride + idx);
+            for (int c = 0; c < D; ++c) {
+                po[c] = ppo[c];
+                rv[c] = prv[c];
+                qv[c] = upd ? pqv[c] : make_double2(0.0, 0.0);
+                xv[c] = make_double2(0.0, 0.0);
+                if (xdo) xv[c] = el_ld2<NT>(a.x + c * a.stride + idx);
+            }
+            pre = false;
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                po[c] = el_ld2<NT>(a.p_old + c * a.stride + idx);
+                rv[c] = el_ld2<NT>(r + c * a.stride + idx);
+                qv[c] = make_double2(0.0, 0.0);
+                xv[c] = make_double2(0.0, 0.0);
+                if (upd) qv[c] = el_ld2<NT>(q + c * a.stride + idx);
+                if (xdo) xv[c] = el_ld2<NT>(a.x + c * a.stride + idx);
+            }
         }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
