@@ -88,8 +88,11 @@ struct BarrierState {
 
 __device__ __forceinline__ bool poll_ge(const P2dArgs& a, const unsigned* word, unsigned want, bool nap) {
     for (int spins = 0;; ++spins) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-        if (__hip_atomic_load(a.sync + SY_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins >= a.spin_limit) {
+        // both loads are in flight together: one memory round trip per poll, not two
+        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = __hip_atomic_load(a.sync + SY_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= want) return true;
+        if (f != 0u || spins >= a.spin_limit) {
             __hip_atomic_store(a.sync + SY_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -529,12 +532,23 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_sr(P2dArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(a.flags + 16 * b, hepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool okn = true;
-            if (b > 0) okn = poll_ge(a, a.flags + 16 * (b - 1), hepoch, false);
-            if (okn && b + 1 < a.G) okn = poll_ge(a, a.flags + 16 * (b + 1), hepoch, false);
-            sFail = okn ? 0 : 1;
+        if (threadIdx.x < 64) {                                   // wave 0: lanes 0 / 1 watch the band below / above, lane 2 the failure flag — one
+            if (lane == 0) __hip_atomic_store(a.flags + 16 * b, hepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // round trip per poll for all
+            const int nbk = lane == 0 ? b - 1 : b + 1;
+            const bool has = lane < 2 && nbk >= 0 && nbk < a.G;
+            int fail = 0;
+            for (int spins = 0;; ++spins) {
+                unsigned v = hepoch, f = 0u;
+                if (has) v = __hip_atomic_load(a.flags + 16 * nbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 2) f = __hip_atomic_load(a.sync + SY_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(v >= hepoch)) break;
+                if (__any(f != 0u) || spins >= a.spin_limit) {
+                    if (lane == 0) __hip_atomic_store(a.sync + SY_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fail = 1;
+                    break;
+                }
+            }
+            if (lane == 0) sFail = fail;
         }
         __syncthreads();
         if (sFail != 0) { ok = false; break; }
