@@ -166,6 +166,7 @@ const char* pdegpu_version(void);
  *                    |         | limit and a fail flag): for runs under rocprofv3, whose exit handler faults inside libhsa-runtime64 after a
  *                    |         | cooperative launch (profiles/r03_rocprofv3_exit_abort.log)
  * persist2d_sr       | 1       | that launch uses the single-reduction recurrences (one grid barrier + one neighbour hand-off)
+ * snapshot_async     | 1       | transient solves: the snapshot of a step leaves the device beside the next step (helper thread, second stream)
  * hybrid_bc          | 1       | natural faces: marching kernel on the interior + class-table kernel on the boundary nodes
  * hybrid_fx          | 1       | ... with the natural x-face rows inside the marching kernel
  * hybrid_k2          | 1       | ... steady sessions on one slab use the 64 B/DoF form

@@ -78,6 +78,7 @@ struct pdegpu_ctx {
     int tile3d_max_nodes = 3000000;   // 3-D grids up to this many nodes (vectors resident in L2) use the one-round tile kernels; 0 = never
     int tile3d_plain = 1;       // tile sessions: the bare masked apply uses the tile form too
     int plane2d_ry = 4;         // rows per wavefront tile of k_plane2d (2 | 4 | 8)
+    int snapshot_async = 1;     // transient solves: 1 = the snapshot of a step is copied to the host beside the next step (helper thread, second stream)
     int persist2d_sr = 1;       // persistent 2-D CG: 1 = fresh solves use the single-reduction (Chronopoulos-Gear) recurrences: one grid barrier +
                                 // one neighbour hand-off per iteration instead of two grid barriers (same iterates in exact arithmetic; measured
                                 // the same iteration counts, config 2: 13.3 -> 11.7 us per iteration); 0 = classic recurrences

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cctype>
 #include <cstdlib>
+#include <future>
 
 struct pdegpu_session {
     pdegpu_ctx* ctx = nullptr;
@@ -576,7 +577,7 @@ extern "C" const char* pdegpu_version(void) { return "pdegpu 0.1 (gfx950)"; }
 static const char* const kTunableKeys[] = {
     "ell_compact", "wfast", "wfast_ry", "wfast_ry1", "wfast_wg_per_cu", "wfast_one_round", "wfast_k2_mult", "wfast_k2_nt", "wfast_nt", "wfast_ex", "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
-    "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "plane2d_ry", "tile3d_max_nodes",
+    "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "snapshot_async", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
     "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran", "el_xdefer", "cg_xdefer", "wfast_xdefer"};
 
@@ -648,6 +649,7 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "plane2d")) return &ctx->plane2d;
     if (!strcmp(key, "persist2d")) return &ctx->persist2d;
     if (!strcmp(key, "persist2d_sr")) return &ctx->persist2d_sr;
+    if (!strcmp(key, "snapshot_async")) return &ctx->snapshot_async;
     if (!strcmp(key, "persist2d_launch")) return &ctx->persist2d_launch;
     if (!strcmp(key, "tile3d_max_nodes")) return &ctx->tile3d_max_nodes;
     if (!strcmp(key, "plane2d_ry")) return &ctx->plane2d_ry;
@@ -1556,6 +1558,75 @@ int put_vec(pdegpu_session* s, const double* host_in, double* v) {
 }
 }  // namespace
 
+namespace {
+// Snapshots of a transient solve leave the device BESIDE the next step's solve: the field is packed into one of two device buffers on the compute stream,
+// and a helper thread copies it to the caller's (pageable) array on a stream of its own — the host-side staging of a pageable copy blocks that thread, not
+// the one that issues the next step (config 2: 8.4 MB per step, ~1 ms of every 9.6 ms step).  The TimeSeriesField loops of fenics_mcp_server.py:307-318,
+// 436-468, 705-716 append a snapshot per step; nothing reads it before the solve returns.
+struct SnapCopier {
+    pdegpu_session* s = nullptr;
+    hipStream_t cs = nullptr;
+    hipEvent_t packed[2] = {nullptr, nullptr};
+    double* buf[2] = {nullptr, nullptr};
+    std::future<int> fut[2];
+    size_t n = 0;
+    int turn = 0;
+    bool ok = false;
+
+    int init(pdegpu_session* sess) {
+        s = sess;
+        n = (size_t)s->g.nkl * s->g.NY * s->g.NX;
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return PDEGPU_EHIP;
+        for (int k = 0; k < 2; ++k)
+            if (hipEventCreateWithFlags(&packed[k], hipEventDisableTiming) != hipSuccess || hipMalloc(&buf[k], n * sizeof(double)) != hipSuccess) return PDEGPU_EHIP;
+        ok = true;
+        return PDEGPU_OK;
+    }
+    // the copy issued two snapshots ago used the same buffer: it has to be over before the buffer is packed again
+    int wait(int k) {
+        if (!fut[k].valid()) return PDEGPU_OK;
+        const int e = fut[k].get();
+        return e == 0 ? PDEGPU_OK : pdegpu_set_err(s->ctx, PDEGPU_EHIP, "snapshot copy: %s", hipGetErrorString((hipError_t)e));
+    }
+    int push(const double* v, double* host_out) {
+        const int k = turn;
+        turn ^= 1;
+        PG_TRY(wait(k));
+        PG_TRY(vec_pack(s->ctx, s->g, v, buf[k]));
+        PG_HIP(s->ctx, hipEventRecord(packed[k], s->ctx->stream));
+        const int dev = s->ctx->device;
+        hipStream_t st = cs;
+        hipEvent_t ev = packed[k];
+        const double* src = buf[k];
+        const size_t bytes = n * sizeof(double);
+        fut[k] = std::async(std::launch::async, [dev, st, ev, src, host_out, bytes]() -> int {
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            return (int)e;
+        });
+        return PDEGPU_OK;
+    }
+    int drain() {
+        int rc = PDEGPU_OK;
+        for (int k = 0; k < 2; ++k) {
+            const int r = wait(k);
+            if (rc == PDEGPU_OK) rc = r;
+        }
+        return rc;
+    }
+    ~SnapCopier() {
+        for (int k = 0; k < 2; ++k) {
+            if (fut[k].valid()) (void)fut[k].get();
+            if (buf[k]) (void)hipFree(buf[k]);
+            if (packed[k]) (void)hipEventDestroy(packed[k]);
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+    }
+};
+}  // namespace
+
 extern "C" int pdegpu_session_get_x(pdegpu_session* s, double* x_out) {
     if (!s || !x_out) return PDEGPU_EINVAL;
     PG_HIP(s->ctx, hipSetDevice(s->ctx->device));
@@ -1915,6 +1986,10 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
             rc = get_vec(s, s->x.v, values_out);
             times_out[snap++] = 0.0;
         }
+        // more than one snapshot to come: they are copied out beside the following steps (snapshot_async = 0: each one in line, as the first is)
+        SnapCopier snaps;
+        bool async_snaps = false;
+        if (!direct && rc == PDEGPU_OK && ctx->snapshot_async && heat.num_steps / stride >= 2) async_snaps = snaps.init(s) == PDEGPU_OK;
         for (int n = 0; !direct && n < heat.num_steps && rc == PDEGPU_OK; ++n) {
             // b = M (u^n + dt f)   — `u_n*v*dx + dt*f*v*dx` (:305, :434, :703)
             rc = op_plain(s, 1, s->x.v, heat.dt * heat.source, s->b.v, 0);
@@ -1926,9 +2001,13 @@ int heat_solve_impl(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat*
             if (rc == PDEGPU_OK) rc = linear_solve(s, false, &st);
             const int step = n + 1;
             if ((rc == PDEGPU_OK) && (step % stride == 0 || step == heat.num_steps)) {
-                rc = get_vec(s, s->x.v, values_out + (size_t)snap * N);
+                rc = async_snaps ? snaps.push(s->x.v, values_out + (size_t)snap * N) : get_vec(s, s->x.v, values_out + (size_t)snap * N);
                 times_out[snap++] = step * heat.dt;
             }
+        }
+        if (async_snaps) {
+            const int r = snaps.drain();                      // every snapshot is in the caller's array before the solve returns
+            if (rc == PDEGPU_OK) rc = r;
         }
     }
     (void)hipEventRecord(e1, ctx->stream);

@@ -987,3 +987,34 @@ def test_stepwise_timing_tells_the_two_forms_of_k2_apart(lib, gpu_ctx):
     finally:
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"cg_xdefer", 1))
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"tile3d_max_nodes", 3000000))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim, stride", [(2, 1), (3, 1), (3, 2), (1, 1)])
+def test_snapshots_copied_beside_the_next_step_are_the_snapshots_copied_in_line(lib, gpu_ctx, dim, stride):
+    """snapshot_async (SnapCopier in csrc/heat.hip): the TimeSeriesField of a transient solve (fenics_mcp_server.py:307-318, 436-468, 705-716 append one
+    snapshot per step) leaves the device through two device buffers and a helper thread while the next step is solved.  Every snapshot must be in the
+    caller's array when the solve returns, bit for bit what the in-line copies deliver — odd step counts, a stride, the CG path in 1-D — and match the oracle."""
+    from pdegpu import heat, _lib
+    if dim == 2:
+        kw = dict(Lx=1.0, Ly=0.7, nx=37, ny=29, diffusivity=0.8, T_boundary=2.0, T_initial=20.0, dt=0.003, num_steps=7)
+        solve, ref = heat._solve_heat_2d_raw, o.solve_heat_2d
+    elif dim == 3:
+        kw = dict(Lx=1.0, Ly=0.8, Lz=0.6, nx=17, ny=13, nz=11, diffusivity=0.8, T_boundary=2.0, T_initial=20.0, dt=0.003, num_steps=7)
+        solve, ref = heat._solve_heat_3d_raw, o.solve_heat_3d
+    else:
+        kw = dict(length=2.0, nx=50, diffusivity=1.0, T_left=20.0, T_right=0.0, T_initial=5.0, dt=0.01, num_steps=7)
+        solve, ref = heat._solve_heat_1d_raw, o.solve_heat_1d
+    got = {}
+    for mode in (0, 1):
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"snapshot_async", mode))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"direct_1d", 0))          # 1-D through the step loop (CG), not the one-launch Thomas path
+        try:
+            got[mode] = solve(**kw, rtol=1e-12, snapshot_stride=stride)
+        finally:
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"snapshot_async", 1))
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"direct_1d", 1))
+    assert got[0].values.shape == got[1].values.shape and got[0].values.shape[0] == 1 + (7 + stride - 1) // stride
+    assert np.array_equal(got[0].values, got[1].values) and np.array_equal(got[0].times, got[1].times)
+    if stride == 1:
+        assert rel_err(got[1].values, ref(**kw).values) < TOL
