@@ -800,7 +800,7 @@ def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kerne
 
 
 @pytest.mark.parametrize("n,Ls", [((2, 2), (1.0, 1.0)), ((5, 3), (1.0, 0.4)), ((130, 37), (1.0, 0.6)), ((300, 513), (0.7, 1.3)),
-                                  ((1023, 260), (2.0, 0.5)), ((640, 2049), (1.0, 3.0))])
+                                  ((1023, 260), (2.0, 0.5)), ((640, 2049), (1.0, 3.0)), ((200, 1022), (0.3, 1.5)), ((129, 1000), (0.3, 1.5))])
 @pytest.mark.parametrize("single_reduction", [0, 1])
 def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib, gpu_ctx, n, Ls, single_reduction):
     """the register-resident cooperative CG of the 2-D tools (persist2d.hip: bands of 1 / 2 / 4 / 8 rows, short last bands, fewer
@@ -810,7 +810,8 @@ def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib,
     kw = dict(Lx=Ls[0], Ly=Ls[1], nx=n[0], ny=n[1], diffusivity=0.9, T_boundary=1.5, T_initial=20.0, dt=0.002, num_steps=2)
 
     def run(persist, **extra):
-        # single_reduction = 1: the Chronopoulos-Gear recurrences (one grid barrier + one neighbour hand-off per iteration)
+        # single_reduction = 1: the Chronopoulos-Gear recurrences (one grid barrier + one neighbour hand-off per iteration); the 260- and 1022-row grids end in
+        # a band of ONE row (bands of 2 / 4 rows)
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", persist))
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_sr", single_reduction if persist else 0))
         try:
@@ -824,7 +825,7 @@ def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib,
         assert a.meta["solver_path"] == "fast"
         # the cooperative launch stops at the first iteration with r.r <= target; the polled loop may run up to a chunk longer
         solves = 1 if extra else kw["num_steps"]
-        assert b.meta["cg_iterations"] - 64 * solves <= a.meta["cg_iterations"] <= b.meta["cg_iterations"] + (2 + 0.02 * b.meta["cg_iterations"] * single_reduction) * solves
+        assert b.meta["cg_iterations"] - 64 * solves <= a.meta["cg_iterations"] <= b.meta["cg_iterations"] + (2 + 0.02 * b.meta["cg_iterations"] * min(single_reduction, 1)) * solves
         assert rel_err(a.values, b.values) < 1e-10
         if (n[0] + 1) * (n[1] + 1) <= 200000:
             assert rel_err(a.values, o.solve_heat_2d(**{**kw, **extra}).values) < TOL
