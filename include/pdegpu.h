@@ -217,7 +217,10 @@ int         pdegpu_marching_geometry(int num_cu, int nx_nodes, int ny_nodes, int
  *      (:229-318, :369-447, :533-716).  Node order of every array: x fastest, then y, then z
  *      (N = (nx+1)(ny+1)(nz+1)); the reference exposes its dof order only through coordinates.
  *      values_out [n_snap][N], times_out [n_snap], n_snap = pdegpu_heat_num_snapshots(...);
- *      u0 = nodal initial values [N] when ic_type == PDEGPU_IC_NODAL, else NULL. */
+ *      u0 = nodal initial values [N] when ic_type == PDEGPU_IC_NODAL, else NULL.
+ *      Transient solves (snapshot_async = 1, the default): while step n + 1 is solved, a helper thread of the library copies the snapshot of step n
+ *      into values_out on a stream of its own; every snapshot is in place when the call returns (also when it returns an error), none of the
+ *      caller's memory is touched afterwards, and the caller must not read values_out before that.  The fields are those of in-line copies. */
 int pdegpu_heat_num_snapshots(const pdegpu_heat* h);
 int pdegpu_heat_solve(pdegpu_ctx* ctx, const pdegpu_grid* grid, const pdegpu_heat* heat,
                       const double* u0, double* values_out, double* times_out, pdegpu_stats* stats);

@@ -1599,13 +1599,19 @@ struct SnapCopier {
         hipEvent_t ev = packed[k];
         const double* src = buf[k];
         const size_t bytes = n * sizeof(double);
-        fut[k] = std::async(std::launch::async, [dev, st, ev, src, host_out, bytes]() -> int {
+        auto copy = [dev, st, ev, src, host_out, bytes]() -> int {
             hipError_t e = hipSetDevice(dev);
             if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
             if (e == hipSuccess) e = hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             return (int)e;
-        });
+        };
+        try {
+            fut[k] = std::async(std::launch::async, copy);
+        } catch (...) {                                         // no thread to be had: the copy runs here, in line
+            const int e = copy();
+            if (e != 0) return pdegpu_set_err(s->ctx, PDEGPU_EHIP, "snapshot copy: %s", hipGetErrorString((hipError_t)e));
+        }
         return PDEGPU_OK;
     }
     int drain() {
