@@ -166,6 +166,9 @@ const char* pdegpu_version(void);
  *                    |         | limit and a fail flag): for runs under rocprofv3, whose exit handler faults inside libhsa-runtime64 after a
  *                    |         | cooperative launch (profiles/r03_rocprofv3_exit_abort.log)
  * persist2d_sr       | 1       | that launch uses the single-reduction recurrences (one grid barrier + one neighbour hand-off)
+ * persist2d_cheb     | 8       | ... and a Chebyshev polynomial preconditioner of that many terms (bands of <= 4 rows; one grid barrier per 8 stencil
+ *                    |         | applications instead of one per application; the iteration count reported is that of the OUTER iterations); 0 = plain CG
+ * persist2d_cheb_ratio | 100   | ... built on [lambda_max / ratio, lambda_max], lambda_max = Gershgorin's bound of the stencil row
  * snapshot_async     | 1       | transient solves: the snapshot of a step leaves the device beside the next step (helper thread, second stream)
  * hybrid_bc          | 1       | natural faces: marching kernel on the interior + class-table kernel on the boundary nodes
  * hybrid_fx          | 1       | ... with the natural x-face rows inside the marching kernel

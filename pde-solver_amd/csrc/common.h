@@ -79,6 +79,8 @@ struct pdegpu_ctx {
     int tile3d_plain = 1;       // tile sessions: the bare masked apply uses the tile form too
     int plane2d_ry = 4;         // rows per wavefront tile of k_plane2d (2 | 4 | 8)
     int snapshot_async = 1;     // transient solves: 1 = the snapshot of a step is copied to the host beside the next step (helper thread, second stream)
+    int persist2d_cheb = 8;     // persistent 2-D CG, fresh solves: > 1 = Chebyshev polynomial preconditioner with that many terms (bands of <= 4 rows); 0 = plain CG
+    int persist2d_cheb_ratio = 100;  // ... built on [lambda_max / ratio, lambda_max]
     int persist2d_sr = 1;       // persistent 2-D CG: 1 = fresh solves use the single-reduction (Chronopoulos-Gear) recurrences: one grid barrier +
                                 // one neighbour hand-off per iteration instead of two grid barriers (same iterates in exact arithmetic; measured
                                 // the same iteration counts, config 2: 13.3 -> 11.7 us per iteration); 0 = classic recurrences

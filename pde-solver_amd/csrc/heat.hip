@@ -577,7 +577,7 @@ extern "C" const char* pdegpu_version(void) { return "pdegpu 0.1 (gfx950)"; }
 static const char* const kTunableKeys[] = {
     "ell_compact", "wfast", "wfast_ry", "wfast_ry1", "wfast_wg_per_cu", "wfast_one_round", "wfast_k2_mult", "wfast_k2_nt", "wfast_nt", "wfast_ex", "fast_ry", "fast_nt", "fast_ex", "fast_pf", "fast_zlen", "fast_cfg_plain", "fast_cfg_res", "fast_cfg_k1", "fast_cfg_k2", "fast_linear",
     "place_tune", "tile3d_plain", "fast_wg_per_cu", "fast_wg_per_cu_k2", "grid_mult", "k2_grid_mult", "cg_variant", "el_grid_mult", "direct_1d",
-    "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "snapshot_async", "plane2d_ry", "tile3d_max_nodes",
+    "lazy_dot", "extrapolate", "hybrid_bc", "hybrid_fx", "hybrid_k2", "plane2d", "persist2d", "persist2d_launch", "persist2d_sr", "persist2d_cheb", "persist2d_cheb_ratio", "snapshot_async", "plane2d_ry", "tile3d_max_nodes",
     "fast_minlen", "fast_small_mult", "el_fast", "el_fast_yx", "el_fast_xface", "el_fast_yzface", "el_bnd_last", "el_fast_nt", "el_fast_ry",
     "el_fast_waves", "el_split_min_mb", "el_cg_variant", "el_fast_fit", "el_bnd_gran", "el_xdefer", "cg_xdefer", "wfast_xdefer"};
 
@@ -650,6 +650,8 @@ int* tunable_slot(pdegpu_ctx* ctx, const char* key) {
     if (!strcmp(key, "persist2d")) return &ctx->persist2d;
     if (!strcmp(key, "persist2d_sr")) return &ctx->persist2d_sr;
     if (!strcmp(key, "snapshot_async")) return &ctx->snapshot_async;
+    if (!strcmp(key, "persist2d_cheb")) return &ctx->persist2d_cheb;
+    if (!strcmp(key, "persist2d_cheb_ratio")) return &ctx->persist2d_cheb_ratio;
     if (!strcmp(key, "persist2d_launch")) return &ctx->persist2d_launch;
     if (!strcmp(key, "tile3d_max_nodes")) return &ctx->tile3d_max_nodes;
     if (!strcmp(key, "plane2d_ry")) return &ctx->plane2d_ry;

@@ -22,6 +22,7 @@
 // Sums are formed in a fixed order and every workgroup adds the same partials in the same order: all workgroups hold bitwise
 // identical scalars and take the same branch at the convergence test, which therefore needs no host poll at all.
 #include "common.h"
+#include <cmath>
 
 namespace {
 
@@ -68,6 +69,8 @@ struct P2dArgs {
     int spin_limit;
     unsigned* flags;           // [G] x 16 words: epoch of the rows of r each band has published (single-reduction form)
     int single_reduction;      // 1: Chronopoulos-Gear CG — one grid barrier + one neighbour hand-off per iteration (fresh solves only)
+    int cheb_k;                // > 1: Chebyshev polynomial preconditioner of that many terms (k_cg2d_persistent_cheb)
+    double cheb_theta, cheb_delta;   // centre / half-width of the interval [lambda_max / ratio, lambda_max] the polynomial is built on
     int barrier_kind;          // 1: XCD-hierarchical (group leaders + generation words; default); 2: sharded counters polled by every
                                // workgroup; 3: hierarchical arrival, every workgroup polls the top counter
 };
@@ -601,6 +604,280 @@ __global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_sr(P2dArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Single-reduction PCG with a Chebyshev polynomial preconditioner (cheb_k terms).  What bounds an iteration of the forms above is the grid barrier
+// (~4.5 us) and the reduction rounds around it, not the stencil (~1 us) or the neighbour hand-off (profiles/r04_config2_two_row_halo_negative.log):
+// z = p(A) r costs cheb_k - 1 more stencil applications with neighbour hand-offs and NO grid barrier, and cuts the number of iterations — of barriers —
+// by about cheb_k / 1.2.  p is the Chebyshev polynomial of the interval [lambda_max / ratio, lambda_max] (Saad, Iterative Methods, Alg. 12.1 from z = 0):
+// positive on (0, lambda_max], so the preconditioner is SPD whatever the smallest eigenvalue is; lambda_max from Gershgorin's bound on the stencil row.
+//   z = p(A) r;  w = A z;  gamma = r.z, delta = w.z, rr = r.r   [ONE grid barrier]   beta = gamma' / gamma;  alpha = gamma' / (delta' - beta gamma' / alpha)
+//   p = z + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s
+// Every stencil application hands the first / last row of its input to the two neighbouring bands; the rows of consecutive hand-offs alternate between
+// two buffers (a band can be at most one hand-off ahead of its neighbour: it needs the neighbour's flag of the current one to go on).
+// Fresh solves only; leaves x fully updated, r.r in SC_RR; the iterates differ from plain CG's, the answer at the tolerance does not.
+__device__ __forceinline__ void block_sum3(double va, double vb, double vc, double* sRed3 /* [3 * kNW] */, double* oa, double* ob, double* oc) {
+    va = p2_wave_sum(va);
+    vb = p2_wave_sum(vb);
+    vc = p2_wave_sum(vc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sRed3[threadIdx.x >> 6] = va;
+        sRed3[kNW + (threadIdx.x >> 6)] = vb;
+        sRed3[2 * kNW + (threadIdx.x >> 6)] = vc;
+    }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNW; ++k) {
+        ta += sRed3[k];
+        tb += sRed3[kNW + k];
+        tc += sRed3[2 * kNW + k];
+    }
+    *oa = ta;
+    *ob = tb;
+    *oc = tc;
+}
+
+template <int RB>
+__global__ __launch_bounds__(kNW * 64, 1) void k_cg2d_persistent_cheb(P2dArgs a) {
+    __shared__ double sRed[3 * kNW];
+    __shared__ double sEdge2[2][RB + 2][kNW][2];
+    __shared__ int sFail;
+    __shared__ int sCensus[4];
+    const GridDev& g = a.g;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x;
+    const int i0 = wv * 128 + 2 * lane;
+    const int j0 = 1 + b * RB;
+    const bool col_ok = i0 < g.PX;
+    const bool ma = i0 >= 1 && i0 <= g.NX - 2, mb = i0 + 1 <= g.NX - 2;
+    const double w0 = a.w[0], wx = a.w[1], wy = a.w[2], wd1 = a.w[3], wd2 = a.w[4];
+    int nact = g.NY - 1 - j0;
+    if (nact > RB) nact = RB;
+    if (nact < 0) nact = 0;
+    double2 X[RB], P[RB], S[RB], R[RB], W[RB], Z[RB], D[RB], T[RB];
+    auto ld2 = [&](const double* v, int j) {
+        const bool ok = col_ok && j >= 0 && j <= g.NY - 1;
+        const double2 t = *reinterpret_cast<const double2*>(v + (ok ? (long long)j * g.PX + i0 : 0));
+        return ok ? t : make_double2(0.0, 0.0);
+    };
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const bool act = q < nact;
+        X[q] = act ? ld2(a.x, j0 + q) : make_double2(0.0, 0.0);
+        R[q] = act ? ld2(a.r, j0 + q) : make_double2(0.0, 0.0);
+        P[q] = S[q] = W[q] = Z[q] = D[q] = T[q] = make_double2(0.0, 0.0);
+    }
+    unsigned hepoch = 0;
+    const size_t prow = (size_t)a.G * g.PX;
+    bool ok = true;
+
+    // out = A v on the band's rows (masked like every CG vector); v's first / last active row goes to the neighbouring bands first (the flag hand-off of
+    // the form above; the rows of consecutive hand-offs alternate between two buffers).  A hand-off WITHOUT flags — the published words as the signal: every
+    // slot holds an all-ones pattern until its producer lane stores a value, the consumer lane polls its own four words and puts the pattern back, no
+    // workgroup barrier — was built and measured: the same iterates, 3.4 instead of 3.6 us per application at 512^2 (bands of 2 rows), not worth its
+    // protocol; its 1024^2 figure was spoiled by a build whose arrays sat in scratch memory (see always_inline below).  profiles/r04_config2_chebyshev.log
+    // (always_inline: with the body shared between its call sites the arrays it is handed live in scratch memory — 704 bytes per lane, 4x the time)
+    auto matvec = [&](const double2* V, double2* out) __attribute__((always_inline)) {
+        ++hepoch;
+        double* pubp = a.pub + (size_t)(hepoch & 1u) * 2 * prow;
+        if (col_ok) {
+            double2 first = V[0], last = V[0];
+#pragma unroll
+            for (int q = 1; q < RB; ++q)
+                if (q < nact) last = V[q];
+            double* pf = pubp + (size_t)b * g.PX + i0;
+            double* pl = pubp + prow + (size_t)b * g.PX + i0;
+            st_sc1(pf, first.x);
+            st_sc1(pf + 1, first.y);
+            st_sc1(pl, last.x);
+            st_sc1(pl + 1, last.y);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int fail = 0;
+        if (threadIdx.x < 64) {
+            if (lane == 0) __hip_atomic_store(a.flags + 16 * b, hepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int nbk = lane == 0 ? b - 1 : b + 1;
+            const bool has = lane < 2 && nbk >= 0 && nbk < a.G;
+            for (int spins = 0;; ++spins) {
+                unsigned v = hepoch, f = 0u;
+                if (has) v = __hip_atomic_load(a.flags + 16 * nbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 2) f = __hip_atomic_load(a.sync + SY_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(v >= hepoch)) break;
+                if (__any(f != 0u) || spins >= a.spin_limit) {
+                    if (lane == 0) __hip_atomic_store(a.sync + SY_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fail = 1;
+                    break;
+                }
+            }
+        }
+        if (__syncthreads_or(fail)) {
+            ok = false;
+            return;
+        }
+        double2 H0 = make_double2(0.0, 0.0), H1 = make_double2(0.0, 0.0);
+        if (col_ok && b > 0) {
+            const double* sp = pubp + prow + (size_t)(b - 1) * g.PX + i0;
+            H0 = make_double2(ld_sc1(sp), ld_sc1(sp + 1));
+        }
+        if (col_ok && b + 1 < a.G && nact == RB) {
+            const double* sp = pubp + (size_t)(b + 1) * g.PX + i0;
+            H1 = make_double2(ld_sc1(sp), ld_sc1(sp + 1));
+        }
+        auto row = [&](int c) { return c == 0 ? H0 : (c == RB + 1 ? H1 : V[c - 1]); };
+#pragma unroll
+        for (int c = 0; c < RB + 2; ++c) {
+            const double2 v = row(c);
+            if (lane == 0) sEdge2[hepoch & 1u][c][wv][0] = v.x;
+            if (lane == 63) sEdge2[hepoch & 1u][c][wv][1] = v.y;
+        }
+        __syncthreads();
+        double Lf[RB + 2], Rt[RB + 2];
+#pragma unroll
+        for (int c = 0; c < RB + 2; ++c) {
+            const double2 v = row(c);
+            double l = p2_dpp_lower(v.y), rt = p2_dpp_upper(v.x);
+            if (lane == 0) l = wv > 0 ? sEdge2[hepoch & 1u][c][wv - 1][1] : 0.0;
+            if (lane == 63) rt = wv < kNW - 1 ? sEdge2[hepoch & 1u][c][wv + 1][0] : 0.0;
+            Lf[c] = l;
+            Rt[c] = rt;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int c = q + 1;
+            const double2 vm = row(c - 1), v0 = row(c), vp = row(c + 1);
+            const double qa = w0 * v0.x + wx * (Lf[c] + v0.y) + wy * (vm.x + vp.x) + wd1 * (vp.y + Lf[c - 1]) + wd2 * (vm.y + Lf[c + 1]);
+            const double qb = w0 * v0.y + wx * (v0.x + Rt[c]) + wy * (vm.y + vp.y) + wd1 * (Rt[c + 1] + vm.x) + wd2 * (Rt[c - 1] + vp.x);
+            const bool act = q < nact;
+            out[q] = make_double2((act && ma) ? qa : 0.0, (act && mb) ? qb : 0.0);
+        }
+    };
+    // z = p(A) r: cheb_k terms of the Chebyshev iteration for A z = r from z = 0 (T: its residual, D: its direction), then w = A z
+    const double theta = a.cheb_theta, cdel = a.cheb_delta, sigma1 = theta / cdel;
+    auto precondition_and_apply = [&]() __attribute__((always_inline)) {
+        double rho = 1.0 / sigma1;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            T[q] = R[q];
+            D[q] = make_double2(R[q].x / theta, R[q].y / theta);
+            Z[q] = D[q];
+        }
+        for (int i = 1; i < a.cheb_k && ok; ++i) {
+            matvec(D, W);                                          // W = A d (scratch here)
+            const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+            const double c1 = rho_new * rho, c2 = 2.0 * rho_new / cdel;
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                T[q].x -= W[q].x;
+                T[q].y -= W[q].y;
+                D[q].x = c1 * D[q].x + c2 * T[q].x;
+                D[q].y = c1 * D[q].y + c2 * T[q].y;
+                Z[q].x += D[q].x;
+                Z[q].y += D[q].y;
+            }
+            rho = rho_new;
+        }
+        if (ok) matvec(Z, W);
+    };
+    auto local_sums = [&](double* g_out, double* d_out, double* rr_out) __attribute__((always_inline)) {
+        double ag = 0.0, ad = 0.0, ar = 0.0;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            ag += R[q].x * Z[q].x + R[q].y * Z[q].y;
+            ad += W[q].x * Z[q].x + W[q].y * Z[q].y;
+            ar += R[q].x * R[q].x + R[q].y * R[q].y;
+        }
+        block_sum3(ag, ad, ar, sRed, g_out, d_out, rr_out);
+    };
+    auto global_sums = [&](unsigned ph, double* g_out, double* d_out, double* rr_out) __attribute__((always_inline)) {
+        const double* part = a.part + (size_t)ph * 3 * a.G;
+        double va = 0.0, vb = 0.0, vc = 0.0;
+        for (int e = threadIdx.x; e < a.G; e += kNW * 64) {
+            const double ta = ld_sc1(part + e), tb = ld_sc1(part + a.G + e), tc = ld_sc1(part + 2 * a.G + e);
+            va += ta;
+            vb += tb;
+            vc += tc;
+        }
+        block_sum3(va, vb, vc, sRed, g_out, d_out, rr_out);
+    };
+
+    BarrierState bs;
+    ok = barrier_init(a, bs, sCensus);
+    unsigned phase = 0;
+    int it = 0;
+    double gamma = 0.0, delta = 0.0, rr = 0.0, alpha = 0.0, beta = 0.0;
+    if (ok) precondition_and_apply();
+    if (ok) {
+        double lg, ld, lr;
+        local_sums(&lg, &ld, &lr);
+        const unsigned ph = phase & 1u;
+        if (threadIdx.x == 0) {
+            st_sc1(a.part + (size_t)ph * 3 * a.G + b, lg);
+            st_sc1(a.part + (size_t)ph * 3 * a.G + a.G + b, ld);
+            st_sc1(a.part + (size_t)ph * 3 * a.G + 2 * a.G + b, lr);
+        }
+        ++phase;
+        ok = grid_barrier(a, bs, &sFail);
+        if (ok) {
+            global_sums(ph, &gamma, &delta, &rr);
+            alpha = delta > 0.0 ? gamma / delta : 0.0;
+        }
+    }
+    while (ok && it < a.iters_max && !(a.target > 0.0 && rr <= a.target) && alpha != 0.0) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            P[q].x = Z[q].x + beta * P[q].x;
+            P[q].y = Z[q].y + beta * P[q].y;
+            S[q].x = W[q].x + beta * S[q].x;
+            S[q].y = W[q].y + beta * S[q].y;
+            X[q].x += alpha * P[q].x;
+            X[q].y += alpha * P[q].y;
+            R[q].x -= alpha * S[q].x;
+            R[q].y -= alpha * S[q].y;
+        }
+        precondition_and_apply();
+        if (!ok) break;
+        double lg, ld, lr;
+        local_sums(&lg, &ld, &lr);
+        const unsigned ph = phase & 1u;
+        if (threadIdx.x == 0) {
+            st_sc1(a.part + (size_t)ph * 3 * a.G + b, lg);
+            st_sc1(a.part + (size_t)ph * 3 * a.G + a.G + b, ld);
+            st_sc1(a.part + (size_t)ph * 3 * a.G + 2 * a.G + b, lr);
+        }
+        ++phase;
+        ok = grid_barrier(a, bs, &sFail);
+        if (!ok) break;
+        double gamma_new, delta_new, rr_new;
+        global_sums(ph, &gamma_new, &delta_new, &rr_new);
+        beta = gamma > 0.0 ? gamma_new / gamma : 0.0;
+        const double den = delta_new - beta * gamma_new / alpha;
+        alpha = den > 0.0 ? gamma_new / den : 0.0;
+        gamma = gamma_new;
+        rr = rr_new;
+        ++it;
+    }
+    if (col_ok) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+            if (q < nact) {
+                const long long off = (long long)(j0 + q) * g.PX + i0;
+                *reinterpret_cast<double2*>(a.x + off) = X[q];
+                *reinterpret_cast<double2*>(a.r + off) = R[q];
+                *reinterpret_cast<double2*>(a.p_out + off) = P[q];
+            }
+    }
+    if (b == 0 && threadIdx.x == 0) {
+        a.scal[SC_PQ] = 0.0;
+        a.scal[SC_PQ_LOCAL] = 0.0;
+        a.scal[SC_RR] = rr;
+        a.scal[SC_RR_LOCAL] = rr;
+        a.scal[SC_RR_PREV] = 0.0;
+        a.sync[SY_ITERS] = (unsigned)it;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -648,13 +925,13 @@ int persist2d_create(pdegpu_ctx* ctx, const GridDev& g, Persist2d** out) {
     Persist2d* p = new Persist2d();
     p->G = G;
     p->rb = rb;
-    if (hipMalloc(&p->part, 4 * (size_t)G * sizeof(double)) != hipSuccess || hipMalloc(&p->flags, 16 * (size_t)G * sizeof(unsigned)) != hipSuccess || hipMalloc(&p->pub, 2 * (size_t)G * g.PX * sizeof(double)) != hipSuccess ||
+    if (hipMalloc(&p->part, 6 * (size_t)G * sizeof(double)) != hipSuccess || hipMalloc(&p->flags, 16 * (size_t)G * sizeof(unsigned)) != hipSuccess || hipMalloc(&p->pub, 4 * (size_t)G * g.PX * sizeof(double)) != hipSuccess ||
         hipMalloc(&p->sync, SY_WORDS * sizeof(unsigned)) != hipSuccess || hipHostMalloc(&p->h_sync, 64) != hipSuccess) {
         persist2d_free(p);
         return pdegpu_set_err(ctx, PDEGPU_EHIP, "persistent 2-D CG: allocation failed");
     }
-    (void)hipMemsetAsync(p->part, 0, 4 * (size_t)G * sizeof(double), ctx->stream);
-    (void)hipMemsetAsync(p->pub, 0, 2 * (size_t)G * g.PX * sizeof(double), ctx->stream);
+    (void)hipMemsetAsync(p->part, 0, 6 * (size_t)G * sizeof(double), ctx->stream);
+    (void)hipMemsetAsync(p->pub, 0, 4 * (size_t)G * g.PX * sizeof(double), ctx->stream);
     *out = p;
     return PDEGPU_OK;
 }
@@ -681,11 +958,26 @@ int persist2d_run(pdegpu_ctx* ctx, Persist2d* p, const GridDev& g, const double*
     a.barrier_kind = (ctx->persist2d == 2 || ctx->persist2d == 3) ? ctx->persist2d : 1;
     a.flags = p->flags;
     a.single_reduction = (fresh && ctx->persist2d_sr) ? 1 : 0;
+    a.cheb_k = 0;
+    if (a.single_reduction && ctx->persist2d_cheb > 1 && p->rb <= 4) {
+        // Gershgorin: no eigenvalue of A exceeds the absolute row sum of the interior stencil (boundary rows have fewer entries)
+        const double lmax = std::fabs(w5[0]) + 2.0 * (std::fabs(w5[1]) + std::fabs(w5[2]) + std::fabs(w5[3]) + std::fabs(w5[4]));
+        const double lmin = lmax / (double)(ctx->persist2d_cheb_ratio > 1 ? ctx->persist2d_cheb_ratio : 30);
+        a.cheb_k = ctx->persist2d_cheb;
+        a.cheb_theta = 0.5 * (lmax + lmin);
+        a.cheb_delta = 0.5 * (lmax - lmin);
+    }
     PG_HIP(ctx, hipMemsetAsync(p->sync, 0, SY_WORDS * sizeof(unsigned), ctx->stream));
     if (a.single_reduction) PG_HIP(ctx, hipMemsetAsync(p->flags, 0, 16 * (size_t)p->G * sizeof(unsigned), ctx->stream));
     void* args[] = {&a};
     const void* fn = nullptr;
-    if (a.single_reduction) {
+    if (a.cheb_k > 1) {
+        switch (p->rb) {
+            case 1: fn = reinterpret_cast<const void*>(k_cg2d_persistent_cheb<1>); break;
+            case 2: fn = reinterpret_cast<const void*>(k_cg2d_persistent_cheb<2>); break;
+            default: fn = reinterpret_cast<const void*>(k_cg2d_persistent_cheb<4>); break;
+        }
+    } else if (a.single_reduction) {
         switch (p->rb) {
             case 1: fn = reinterpret_cast<const void*>(k_cg2d_persistent_sr<1>); break;
             case 2: fn = reinterpret_cast<const void*>(k_cg2d_persistent_sr<2>); break;

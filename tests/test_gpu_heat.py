@@ -801,7 +801,7 @@ def test_every_tunable_leaves_the_solution_alone(lib, gpu_ctx, setting, cg_kerne
 
 @pytest.mark.parametrize("n,Ls", [((2, 2), (1.0, 1.0)), ((5, 3), (1.0, 0.4)), ((130, 37), (1.0, 0.6)), ((300, 513), (0.7, 1.3)),
                                   ((1023, 260), (2.0, 0.5)), ((640, 2049), (1.0, 3.0)), ((200, 1022), (0.3, 1.5)), ((129, 1000), (0.3, 1.5))])
-@pytest.mark.parametrize("single_reduction", [0, 1])
+@pytest.mark.parametrize("single_reduction", [0, 1, 2])
 def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib, gpu_ctx, n, Ls, single_reduction):
     """the register-resident cooperative CG of the 2-D tools (persist2d.hip: bands of 1 / 2 / 4 / 8 rows, short last bands, fewer
     bands than CUs, 1- and 8-wave-wide grids, a one-node grid) against the launch-per-kernel loop (persist2d = 0) — same
@@ -810,22 +810,28 @@ def test_persistent_2d_cg_matches_the_launch_per_kernel_loop_and_the_oracle(lib,
     kw = dict(Lx=Ls[0], Ly=Ls[1], nx=n[0], ny=n[1], diffusivity=0.9, T_boundary=1.5, T_initial=20.0, dt=0.002, num_steps=2)
 
     def run(persist, **extra):
-        # single_reduction = 1: the Chronopoulos-Gear recurrences (one grid barrier + one neighbour hand-off per iteration); the 260- and 1022-row grids end in
-        # a band of ONE row (bands of 2 / 4 rows)
+        # single_reduction = 1: the Chronopoulos-Gear recurrences (one grid barrier + one neighbour hand-off per iteration); 2: the same with the Chebyshev
+        # polynomial preconditioner (the default; bands of <= 4 rows — the 2049-row grid runs form 1); the 260- and 1022-row grids end in a band of ONE row
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", persist))
-        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_sr", single_reduction if persist else 0))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_sr", min(single_reduction, 1) if persist else 0))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_cheb", 8 if single_reduction == 2 else 0))
         try:
             return heat._solve_heat_2d_raw(**{**kw, **extra}, rtol=1e-12)
         finally:
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d", 1))
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_sr", 1))
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_cheb", 8))
 
     for extra in (dict(), dict(steady=True, source_type="constant", source_value=3.0)):
         a, b = run(1, **extra), run(0, **extra)
         assert a.meta["solver_path"] == "fast"
         # the cooperative launch stops at the first iteration with r.r <= target; the polled loop may run up to a chunk longer
         solves = 1 if extra else kw["num_steps"]
-        assert b.meta["cg_iterations"] - 64 * solves <= a.meta["cg_iterations"] <= b.meta["cg_iterations"] + (2 + 0.02 * b.meta["cg_iterations"] * min(single_reduction, 1)) * solves
+        if single_reduction == 2 and n[1] <= 1025:
+            # outer iterations of the preconditioned form: every one applies the stencil 8 times and passes ONE grid barrier
+            assert 0 < a.meta["cg_iterations"] <= b.meta["cg_iterations"] // 2 + 2 * solves
+        else:
+            assert b.meta["cg_iterations"] - 64 * solves <= a.meta["cg_iterations"] <= b.meta["cg_iterations"] + (2 + 0.02 * b.meta["cg_iterations"] * min(single_reduction, 1)) * solves
         assert rel_err(a.values, b.values) < 1e-10
         if (n[0] + 1) * (n[1] + 1) <= 200000:
             assert rel_err(a.values, o.solve_heat_2d(**{**kw, **extra}).values) < TOL
@@ -854,13 +860,17 @@ def test_persistent_2d_cg_at_a_tight_tolerance_single_reduction_vs_classic(lib, 
               source_type="constant", source_value=1.0, rtol=1e-13)
     outs = []
     try:
-        for sr in (1, 0):
+        for sr, cheb in ((1, 0), (0, 0), (1, 8)):
             _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_sr", sr))
+            _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_cheb", cheb))
             outs.append(heat._solve_heat_2d_raw(**kw))
     finally:
         _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_sr", 1))
+        _lib.check(gpu_ctx, lib.pdegpu_set_tunable(gpu_ctx, b"persist2d_cheb", 8))
     assert all(f.meta["cg_converged"] if "cg_converged" in f.meta else True for f in outs)
     assert rel_err(outs[0].values, outs[1].values) < 1e-10
+    # the preconditioned form (default) at the same tolerance: same field, far fewer grid barriers
+    assert rel_err(outs[2].values, outs[1].values) < 1e-10 and 0 < outs[2].meta["cg_iterations"] < outs[1].meta["cg_iterations"]
     assert abs(outs[0].meta["cg_iterations"] - outs[1].meta["cg_iterations"]) <= 0.05 * outs[1].meta["cg_iterations"] + 4
 
 

@@ -73,3 +73,19 @@ def test_wave_uniform_weights_arrive_by_scalar_loads():
         per_lane_two_rows = "k_wmarchILi1ELi2E" in name
         if not per_lane_two_rows or edge_handoff:      # (per-lane weights, two rows, WITHOUT the LDS edge hand-off: 5 dwords of spill, not a default)
             assert scratch == 0, (name, scratch)
+
+
+def test_the_persistent_2d_kernels_keep_their_state_in_registers():
+    """csrc/persist2d.hip: the CG state of a band lives in statically indexed register arrays.  A helper that is handed such an array by pointer and is not
+    inlined at every call site moves it to scratch memory (the Chebyshev form once: 704 bytes per lane, four times the time per stencil application) —
+    no instantiation may have a private segment."""
+    f = BUILD / "persist2d-hip-amdgcn-amd-amdhsa-gfx950.s"
+    if not f.exists():
+        pytest.skip("no device assembly of persist2d.hip in pde-solver_amd/build")
+    text = f.read_text(errors="replace")
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*k_cg2d_persistent\S*)(.*?)\.end_amdhsa_kernel", text, re.S):
+        name, meta = m.group(1), m.group(2)
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta).group(1)) == 0, name
+        seen += 1
+    assert seen >= 11      # classic / single-reduction forms of 1, 2, 4, 8 rows + the Chebyshev form of 1, 2, 4 rows
