@@ -535,6 +535,9 @@ def main():
             try:
                 j = json.loads(pmc.read_text())
                 rl["traffic"] = j.get("k1_hbm_bytes_per_launch")
+                for o, key in zip(rl["other_kernels"], ("k2_with_x_hbm_bytes_per_launch", "k2_hbm_bytes_per_launch")):
+                    if len(rl["other_kernels"]) == 2 and j.get(key):
+                        o["traffic"] = j[key]
                 rl["traffic_source"] = (f"profiles/pmc_latest.json ({j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')}, "
                                         f"collected at {j.get('commit', 'an earlier commit')}): a committed counter value, NOT taken in this run")
             except Exception:
